@@ -1,0 +1,37 @@
+# Builds libnexus_amd.so (HIP device layer for gfx950 + C++ host classes + flat C API) in-tree.
+# Plain make + hipcc: no cmake needed.  `make oracle` builds the CPU oracle (test infrastructure only).
+HIPCC     ?= /opt/rocm/bin/hipcc
+ARCH      ?= gfx950
+OUT       := nexus_amd/lib/libnexus_amd.so
+OBJDIR    := build/obj
+COMMON    := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Inexus_amd/csrc/device -Inexus_amd/csrc/host -Wall -Wno-unused-function
+DEVFLAGS  := $(COMMON) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
+HOSTFLAGS := $(COMMON)
+
+DEV_SRCS  := $(wildcard nexus_amd/csrc/device/*.hip)
+HOST_SRCS := $(wildcard nexus_amd/csrc/host/*.cpp) $(wildcard nexus_amd/csrc/capi/*.cpp)
+DEV_OBJS  := $(patsubst %.hip,$(OBJDIR)/%.o,$(DEV_SRCS))
+HOST_OBJS := $(patsubst %.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
+HDRS      := $(wildcard include/*.h include/nexus/*.h nexus_amd/csrc/device/*.h nexus_amd/csrc/host/*.h)
+
+all: $(OUT)
+
+$(OBJDIR)/%.o: %.hip $(HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(DEVFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.o: %.cpp $(HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HOSTFLAGS) -c $< -o $@
+
+$(OUT): $(DEV_OBJS) $(HOST_OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lpthread
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+
+clean:
+	rm -rf build $(OUT)
+
+.PHONY: all oracle clean

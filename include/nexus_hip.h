@@ -1,0 +1,148 @@
+/*
+ * nexus_hip.h — C-ABI of the MI355X (gfx950) device layer: the wavefront path-tracing hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its host classes reach the device
+ * through CUDA symbols and bare kernel pointers (17 GetDevice*Address() getters,
+ * /root/reference/Nexus/src/Cuda/PathTracer/PathTracer.cuh:86-103, and (void*)XxxKernel pointers,
+ * Renderer/PathTracer.cpp:99-107).  Each entry point below names the reference interface it replaces.
+ * Plain C: opaque context, plain pointers and sizes, int status (0 = ok, message via
+ * nxhip_last_error()); no HIP, torch or C++ types in any signature.  Host arrays passed in are copied
+ * before the call returns.  A context belongs to one host thread at a time; one context per GPU.
+ */
+#ifndef NEXUS_HIP_H
+#define NEXUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "nexus_pod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nxhip_ctx nxhip_ctx;
+
+enum {
+    NXHIP_OK = 0,
+    NXHIP_ERR_INVALID = 1, /* bad argument / state */
+    NXHIP_ERR_HIP = 2,     /* a HIP runtime call failed */
+    NXHIP_ERR_NO_DEVICE = 3
+};
+
+/* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
+const char *nxhip_last_error(void);
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int nxhip_device_count(void);
+
+/* PathTracer::PathTracer(width, height) + Reset() — Renderer/PathTracer.cpp:5-28, 92-241: allocates every
+ * queue for `localPixels` paths.  `stream` is a hipStream_t passed as void* (NULL: the context creates its own). */
+int nxhip_create(int device, uint32_t width, uint32_t height, void *stream, nxhip_ctx **out);
+/* PathTracer::~PathTracer / FreeDeviceBuffers — PathTracer.cpp:30-90 */
+void nxhip_destroy(nxhip_ctx *ctx);
+/* PathTracer::OnResize — PathTracer.cpp:290-303 (frees and re-allocates queues, resets the frame number) */
+int nxhip_resize(nxhip_ctx *ctx, uint32_t width, uint32_t height);
+int nxhip_sync(nxhip_ctx *ctx);
+
+/* ---- scene upload -------------------------------------------------------------------------------- */
+
+/* BVH8::InitDeviceData + AssetManager::InitDeviceData — Geometry/BVH/BVH8.cpp:28-33, Assets/AssetManager.cpp:45-49
+ * (symbol `bvhs`).  Returns the BLAS id == index instances refer to as bvhIdx.  ids are dense from 0. */
+int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const nx_triangle *tris,
+                      uint32_t triCount, const uint32_t *triIdx, int32_t *blasId);
+int nxhip_clear_blas(nxhip_ctx *ctx);
+/* TLAS::UpdateDeviceData — Geometry/BVH/TLAS.cpp:93-100 (symbols `tlas`, `blas`). */
+int nxhip_set_tlas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const uint32_t *instanceIdx,
+                   const nx_bvh_instance *instances, uint32_t instanceCount);
+/* AssetManager device materials — Assets/AssetManager.cpp:57-62,106-116 */
+int nxhip_set_materials(nxhip_ctx *ctx, const nx_material *materials, uint32_t count);
+/* Scene::m_DeviceLights — Scene/Scene.cpp:142-176 */
+int nxhip_set_lights(nxhip_ctx *ctx, const nx_light *lights, uint32_t count);
+/* Texture::ToDevice — Assets/Texture.cpp:10-39 (RGBA8, sRGB, wrap, bilinear).  kind: 0 diffuse, 1 emissive, 2 hdr map.
+ * Diffuse/emissive maps get ids in upload order; the hdr map replaces the previous one. */
+int nxhip_upload_texture(nxhip_ctx *ctx, int kind, const uint8_t *rgba8, uint32_t width, uint32_t height, int32_t *texId);
+int nxhip_clear_textures(nxhip_ctx *ctx);
+/* PathTracer::UpdateDeviceScene / Scene::ToDevice — Renderer/PathTracer.cpp:305-308, Scene/Scene.cpp:115-140 */
+int nxhip_set_camera(nxhip_ctx *ctx, const nx_camera *camera);
+int nxhip_set_render_settings(nxhip_ctx *ctx, const nx_render_settings *settings);
+/* Extensions that do not exist in the reference (see nexus_pod.h): RNG keying, compaction order, conductor. */
+int nxhip_set_modes(nxhip_ctx *ctx, int rngMode, int compactMode, int conductorMode);
+/* Multi-GPU tile split: this context renders `localCount` pixels; pixelMap[i] = global pixel index of local
+ * pixel i (NULL: identity over width*height).  Re-allocates the queues for localCount paths. */
+int nxhip_set_pixel_map(nxhip_ctx *ctx, const uint32_t *pixelMap, uint32_t localCount);
+
+/* ---- rendering ----------------------------------------------------------------------------------- */
+
+/* PathTracer::ResetFrameNumber — PathTracer.cpp:243-246 */
+int nxhip_reset_frame_number(nxhip_ctx *ctx);
+int nxhip_set_frame_number(nxhip_ctx *ctx, uint32_t frameNumber); /* next render uses frameNumber + 1 */
+uint32_t nxhip_frame_number(nxhip_ctx *ctx);
+/* PathTracer::Render minus AccumulateKernel — PathTracer.cpp:248-276: frameNumber++, Generate, Trace, then
+ * pathLength x (Logic, 4 x Shade, Trace || TraceShadow), replayed as one hipGraph.  Asynchronous. */
+int nxhip_render_frame(nxhip_ctx *ctx);
+/* AccumulateKernel — Cuda/PathTracer/PathTracer.cu:480-496, PathTracer.cpp:278.  Asynchronous. */
+int nxhip_accumulate(nxhip_ctx *ctx);
+/* nxhip_render_frame + nxhip_accumulate `frames` times (one graph replay per frame). */
+int nxhip_render(nxhip_ctx *ctx, uint32_t frames);
+
+/* Read-back (synchronises).  radiance/accumulation: localCount x 3 floats; rgba8: localCount uint32
+ * (the reference's GL pixel buffer, OpenGL/PixelBuffer.cpp:4-41). */
+int nxhip_read_radiance(nxhip_ctx *ctx, float *dst);
+int nxhip_read_accumulation(nxhip_ctx *ctx, float *dst);
+int nxhip_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);
+/* Device pointers for zero-copy consumers on the same GPU (e.g. an RCCL gather of radiance tiles):
+ * float4 per local pixel (xyz = radiance, w unused).  Valid until the next resize / set_pixel_map. */
+void *nxhip_radiance_device_ptr(nxhip_ctx *ctx);
+void *nxhip_accumulation_device_ptr(nxhip_ctx *ctx);
+/* Root-side accumulate of an externally gathered full image: src = device float4[count] radiance. */
+int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t frameNumber);
+
+/* D_QueueSize after the last rendered frame — Cuda/PathTracer/PathTracer.cuh:61-73.  Each array NX_PATH_MAX_LENGTH ints. */
+typedef struct nxhip_queue_sizes {
+    int32_t traceSize[NX_PATH_MAX_LENGTH];
+    int32_t traceShadowSize[NX_PATH_MAX_LENGTH];
+    int32_t diffuseSize[NX_PATH_MAX_LENGTH];
+    int32_t plasticSize[NX_PATH_MAX_LENGTH];
+    int32_t dielectricSize[NX_PATH_MAX_LENGTH];
+    int32_t conductorSize[NX_PATH_MAX_LENGTH];
+} nxhip_queue_sizes;
+int nxhip_read_queue_sizes(nxhip_ctx *ctx, nxhip_queue_sizes *out);
+
+/* PathTracer::SetPixelQuery / GetSelectedInstance — PathTracer.cpp:310-317, PathTracer.h:25 */
+int nxhip_set_pixel_query(nxhip_ctx *ctx, uint32_t x, uint32_t y);
+int nxhip_get_selected_instance(nxhip_ctx *ctx, int32_t *instanceIdx);
+
+/* ---- kernel-level hooks (tests, bench) ----------------------------------------------------------- */
+
+/* TraceKernel on a caller-supplied ray batch — Cuda/BVH/BVH8Traversal.cuh:148-322.  Host buffers. */
+int nxhip_trace_batch(nxhip_ctx *ctx, const nx_ray *rays, uint32_t count, nx_hit *hits);
+/* TraceShadowKernel's any-hit test — BVH8Traversal.cuh:326-518.  occluded[i] = 1 if blocked within tmax[i]. */
+int nxhip_trace_shadow_batch(nxhip_ctx *ctx, const nx_ray *rays, const float *tmax, uint32_t count, uint8_t *occluded);
+
+/* Visit counters of the two trace kernels (algorithmic bytes for the roofline).  When enabled
+ * the trace kernels run their counting variant; off by default. */
+typedef struct nxhip_trace_stats {
+    uint64_t rays, nodes, tris, instances;
+} nxhip_trace_stats;
+int nxhip_enable_trace_stats(nxhip_ctx *ctx, int enable);
+int nxhip_read_trace_stats(nxhip_ctx *ctx, nxhip_trace_stats *closest, nxhip_trace_stats *shadow, int reset);
+
+/* Per-kernel-class device time.  When enabled, frames are launched kernel by kernel on the context's stream
+ * with a hipEvent pair around every launch (no graph).  Classes: 0 generate, 1 trace, 2 shadow, 3 logic,
+ * 4 shade, 5 accumulate. */
+enum { NXHIP_K_GENERATE = 0, NXHIP_K_TRACE = 1, NXHIP_K_SHADOW = 2, NXHIP_K_LOGIC = 3, NXHIP_K_SHADE = 4, NXHIP_K_ACCUMULATE = 5, NXHIP_K_COUNT = 6 };
+typedef struct nxhip_kernel_times {
+    double ms[NXHIP_K_COUNT];
+    uint64_t launches[NXHIP_K_COUNT];
+} nxhip_kernel_times;
+int nxhip_enable_kernel_timing(nxhip_ctx *ctx, int enable);
+int nxhip_read_kernel_times(nxhip_ctx *ctx, nxhip_kernel_times *out, int reset);
+
+/* Build-time facts for tests: 1 if the library was compiled with device code for gfx950. */
+int nxhip_has_gfx950_code(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXUS_HIP_H */

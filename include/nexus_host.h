@@ -1,0 +1,47 @@
+/*
+ * nexus_host.h — flat C view of the host-side data producers (BVH2 / BVH8 / TLAS builders, instance and
+ * camera set-up) for callers that cannot use the C++ classes in include/nexus/ (the Python tests and bench).
+ * The C++ classes mirror the reference's host API; these functions only wrap them.
+ *   nxh_bvh8_build      BVH8Builder(tris).Init(); Build()     /root/reference/Nexus/src/Assets/AssetManager.cpp:23-37
+ *   nxh_bvh2_build      BVH2(tris).Build()                     Geometry/BVH/BVH.cpp:13-26
+ *   nxh_instance_init   BVHInstance::SetTransform + ToDevice   Geometry/BVH/BVHInstance.cpp:4-45
+ *   nxh_tlas_build      TLAS::Build(); TLAS::Convert()         Geometry/BVH/TLAS.cpp:13-68
+ *   nxh_camera_init     Camera::ToDevice                       Scene/Camera.cpp:142-168
+ * All functions return 0 on success.
+ */
+#ifndef NEXUS_HOST_H
+#define NEXUS_HOST_H
+
+#include <stdint.h>
+
+#include "nexus_pod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nxh_bvh8 nxh_bvh8; /* owns nodes + primitive indices */
+
+/* threads = 0: all hardware threads.  The result does not depend on the thread count. */
+int nxh_bvh8_build(const nx_triangle *tris, uint32_t triCount, uint32_t threads, nxh_bvh8 **out);
+int nxh_tlas_build(const nx_bvh_instance *instances, uint32_t instanceCount, nxh_bvh8 **out);
+uint32_t nxh_bvh8_node_count(const nxh_bvh8 *b);
+uint32_t nxh_bvh8_prim_count(const nxh_bvh8 *b);
+const nx_bvh8_node *nxh_bvh8_nodes(const nxh_bvh8 *b);
+const uint32_t *nxh_bvh8_prim_indices(const nxh_bvh8 *b);
+void nxh_bvh8_free(nxh_bvh8 *b);
+
+/* BVH2 only (tests): nodes32 receives 2*triCount-1 32-byte nodes, triIdx triCount indices. */
+int nxh_bvh2_build(const nx_triangle *tris, uint32_t triCount, uint32_t threads, void *nodes32, uint32_t *triIdx);
+
+void nxh_mat4_from_trs(const float pos[3], const float rotDeg[3], const float scale[3], float out16[16]);
+void nxh_mat4_invert(const float in16[16], float out16[16]);
+int nxh_instance_init(nx_bvh_instance *out, uint32_t bvhIdx, int32_t materialId, const float transform16[16],
+                      const nx_bvh8_node *blasRoot);
+int nxh_camera_init(nx_camera *out, const float position[3], const float forward[3], float horizontalFovDeg,
+                    uint32_t width, uint32_t height, float focusDist, float defocusAngleDeg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

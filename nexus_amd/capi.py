@@ -1,0 +1,412 @@
+"""ctypes binding of ``nexus_amd/lib/libnexus_amd.so`` — the C-ABI declared in ``include/nexus_hip.h`` (device
+layer) and ``include/nexus_host.h`` (host builders).
+
+There is no Python / CPU fallback: if the library is missing or a device call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import pod
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnexus_amd.so")
+
+# every symbol include/nexus_hip.h and include/nexus_host.h declare
+HIP_SYMBOLS = [
+    "nxhip_last_error", "nxhip_device_count", "nxhip_create", "nxhip_destroy", "nxhip_resize", "nxhip_sync",
+    "nxhip_upload_blas", "nxhip_clear_blas", "nxhip_set_tlas", "nxhip_set_materials", "nxhip_set_lights",
+    "nxhip_upload_texture", "nxhip_clear_textures", "nxhip_set_camera", "nxhip_set_render_settings", "nxhip_set_modes",
+    "nxhip_set_pixel_map", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
+    "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
+    "nxhip_read_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external",
+    "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
+    "nxhip_trace_shadow_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
+    "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
+]
+HOST_SYMBOLS = [
+    "nxh_bvh8_build", "nxh_tlas_build", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
+    "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
+    "nxh_instance_init", "nxh_camera_init",
+]
+
+
+class NexusError(RuntimeError):
+    pass
+
+
+class QueueSizes(C.Structure):
+    _fields_ = [(n, C.c_int32 * pod.PATH_MAX_LENGTH) for n in
+                ("traceSize", "traceShadowSize", "diffuseSize", "plasticSize", "dielectricSize", "conductorSize")]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("instances", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_uint64 * 6)]
+
+
+KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate")
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises NexusError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NexusError(f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+    L.nxhip_last_error.restype = C.c_char_p
+    L.nxhip_create.argtypes = [C.c_int, u32, u32, vp, C.POINTER(vp)]
+    L.nxhip_destroy.argtypes = [vp]
+    L.nxhip_destroy.restype = None
+    L.nxhip_resize.argtypes = [vp, u32, u32]
+    L.nxhip_sync.argtypes = [vp]
+    L.nxhip_upload_blas.argtypes = [vp, vp, u32, vp, u32, vp, C.POINTER(i32)]
+    L.nxhip_clear_blas.argtypes = [vp]
+    L.nxhip_set_tlas.argtypes = [vp, vp, u32, vp, vp, u32]
+    L.nxhip_set_materials.argtypes = [vp, vp, u32]
+    L.nxhip_set_lights.argtypes = [vp, vp, u32]
+    L.nxhip_upload_texture.argtypes = [vp, C.c_int, vp, u32, u32, C.POINTER(i32)]
+    L.nxhip_clear_textures.argtypes = [vp]
+    L.nxhip_set_camera.argtypes = [vp, vp]
+    L.nxhip_set_render_settings.argtypes = [vp, vp]
+    L.nxhip_set_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.nxhip_set_pixel_map.argtypes = [vp, vp, u32]
+    L.nxhip_reset_frame_number.argtypes = [vp]
+    L.nxhip_set_frame_number.argtypes = [vp, u32]
+    L.nxhip_frame_number.argtypes = [vp]
+    L.nxhip_frame_number.restype = u32
+    L.nxhip_render_frame.argtypes = [vp]
+    L.nxhip_accumulate.argtypes = [vp]
+    L.nxhip_render.argtypes = [vp, u32]
+    L.nxhip_read_radiance.argtypes = [vp, vp]
+    L.nxhip_read_accumulation.argtypes = [vp, vp]
+    L.nxhip_read_rgba8.argtypes = [vp, vp]
+    L.nxhip_radiance_device_ptr.argtypes = [vp]
+    L.nxhip_radiance_device_ptr.restype = vp
+    L.nxhip_accumulation_device_ptr.argtypes = [vp]
+    L.nxhip_accumulation_device_ptr.restype = vp
+    L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32]
+    L.nxhip_read_queue_sizes.argtypes = [vp, C.POINTER(QueueSizes)]
+    L.nxhip_set_pixel_query.argtypes = [vp, u32, u32]
+    L.nxhip_get_selected_instance.argtypes = [vp, C.POINTER(i32)]
+    L.nxhip_trace_batch.argtypes = [vp, vp, u32, vp]
+    L.nxhip_trace_shadow_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.nxhip_enable_trace_stats.argtypes = [vp, C.c_int]
+    L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
+    L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.nxhip_read_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.c_int]
+    # host builders
+    L.nxh_bvh8_build.argtypes = [vp, u32, u32, C.POINTER(vp)]
+    L.nxh_tlas_build.argtypes = [vp, u32, C.POINTER(vp)]
+    L.nxh_bvh8_node_count.argtypes = [vp]
+    L.nxh_bvh8_node_count.restype = u32
+    L.nxh_bvh8_prim_count.argtypes = [vp]
+    L.nxh_bvh8_prim_count.restype = u32
+    L.nxh_bvh8_nodes.argtypes = [vp]
+    L.nxh_bvh8_nodes.restype = vp
+    L.nxh_bvh8_prim_indices.argtypes = [vp]
+    L.nxh_bvh8_prim_indices.restype = vp
+    L.nxh_bvh8_free.argtypes = [vp]
+    L.nxh_bvh8_free.restype = None
+    L.nxh_bvh2_build.argtypes = [vp, u32, u32, vp, vp]
+    L.nxh_mat4_from_trs.argtypes = [vp, vp, vp, vp]
+    L.nxh_mat4_from_trs.restype = None
+    L.nxh_mat4_invert.argtypes = [vp, vp]
+    L.nxh_mat4_invert.restype = None
+    L.nxh_instance_init.argtypes = [vp, u32, i32, vp, vp]
+    L.nxh_camera_init.argtypes = [vp, vp, vp, f32, u32, u32, f32, f32]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().nxhip_last_error()
+        raise NexusError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def _copy_out(addr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+# ---- host builders --------------------------------------------------------------------------------
+
+def bvh8_build(tris, threads=0):
+    """BVH8Builder(tris).Init().Build() -> (nodes NODE_DT[], triIdx u32[])."""
+    tris = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+    h = C.c_void_p()
+    rc = lib().nxh_bvh8_build(_ptr(tris), len(tris), threads, C.byref(h))
+    if rc != 0:
+        raise NexusError(f"nxh_bvh8_build failed ({rc})")
+    try:
+        nodes = _copy_out(lib().nxh_bvh8_nodes(h), lib().nxh_bvh8_node_count(h), pod.NODE_DT)
+        idx = _copy_out(lib().nxh_bvh8_prim_indices(h), lib().nxh_bvh8_prim_count(h), np.uint32)
+    finally:
+        lib().nxh_bvh8_free(h)
+    return nodes, idx
+
+
+def tlas_build(instances):
+    instances = np.ascontiguousarray(instances, dtype=pod.INST_DT)
+    h = C.c_void_p()
+    rc = lib().nxh_tlas_build(_ptr(instances), len(instances), C.byref(h))
+    if rc != 0:
+        raise NexusError(f"nxh_tlas_build failed ({rc})")
+    try:
+        nodes = _copy_out(lib().nxh_bvh8_nodes(h), lib().nxh_bvh8_node_count(h), pod.NODE_DT)
+        idx = _copy_out(lib().nxh_bvh8_prim_indices(h), lib().nxh_bvh8_prim_count(h), np.uint32)
+    finally:
+        lib().nxh_bvh8_free(h)
+    return nodes, idx
+
+
+BVH2_NODE_DT = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("leftFirst", "<u4"), ("triCount", "<u4")])
+
+
+def bvh2_build(tris, threads=0):
+    tris = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+    nodes = np.zeros(2 * len(tris) - 1, dtype=BVH2_NODE_DT)
+    idx = np.zeros(len(tris), dtype=np.uint32)
+    rc = lib().nxh_bvh2_build(_ptr(tris), len(tris), threads, _ptr(nodes), _ptr(idx))
+    if rc != 0:
+        raise NexusError(f"nxh_bvh2_build failed ({rc})")
+    return nodes, idx
+
+
+def mat4_from_trs(pos=(0, 0, 0), rot_deg=(0, 0, 0), scale=(1, 1, 1)):
+    out = np.zeros(16, np.float32)
+    p, r, s = (np.asarray(x, np.float32) for x in (pos, rot_deg, scale))
+    lib().nxh_mat4_from_trs(_ptr(p), _ptr(r), _ptr(s), _ptr(out))
+    return out
+
+
+def mat4_invert(m):
+    m = np.ascontiguousarray(m, np.float32)
+    out = np.zeros(16, np.float32)
+    lib().nxh_mat4_invert(_ptr(m), _ptr(out))
+    return out
+
+
+def instance_init(bvh_idx, material_id, transform, blas_root_node):
+    inst = np.zeros(1, dtype=pod.INST_DT)
+    t = np.ascontiguousarray(transform, np.float32)
+    root = np.ascontiguousarray(blas_root_node, dtype=pod.NODE_DT).reshape(1)
+    rc = lib().nxh_instance_init(_ptr(inst), int(bvh_idx), int(material_id), _ptr(t), _ptr(root))
+    if rc != 0:
+        raise NexusError(f"nxh_instance_init failed ({rc})")
+    return inst[0]
+
+
+def camera_init(position, forward, hfov_deg, width, height, focus_dist=5.0, defocus_deg=0.0):
+    cam = np.zeros(1, dtype=pod.CAM_DT)
+    p = np.asarray(position, np.float32)
+    f = np.asarray(forward, np.float32)
+    rc = lib().nxh_camera_init(_ptr(cam), _ptr(p), _ptr(f), hfov_deg, width, height, focus_dist, defocus_deg)
+    if rc != 0:
+        raise NexusError(f"nxh_camera_init failed ({rc})")
+    return cam[0]
+
+
+# ---- device context -------------------------------------------------------------------------------
+
+class Context:
+    """One ``nxhip_ctx`` (one GPU).  Thin 1:1 wrapper of the C-ABI; raises NexusError on any failure."""
+
+    def __init__(self, width, height, device=0, stream=None):
+        self.L = lib()
+        self.width, self.height = int(width), int(height)
+        h = C.c_void_p()
+        check(self.L.nxhip_create(device, self.width, self.height, C.c_void_p(stream) if stream else None, C.byref(h)), "nxhip_create")
+        self.h = h
+        self.local_count = self.width * self.height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nxhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # scene
+    def upload_blas(self, nodes, tris, tri_idx):
+        nodes = np.ascontiguousarray(nodes, dtype=pod.NODE_DT)
+        tris = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+        tri_idx = np.ascontiguousarray(tri_idx, dtype=np.uint32)
+        bid = C.c_int32(-1)
+        check(self.L.nxhip_upload_blas(self.h, _ptr(nodes), len(nodes), _ptr(tris), len(tris), _ptr(tri_idx), C.byref(bid)), "nxhip_upload_blas")
+        return bid.value
+
+    def clear_blas(self):
+        check(self.L.nxhip_clear_blas(self.h), "nxhip_clear_blas")
+
+    def set_tlas(self, nodes, inst_idx, instances):
+        nodes = np.ascontiguousarray(nodes, dtype=pod.NODE_DT)
+        inst_idx = np.ascontiguousarray(inst_idx, dtype=np.uint32)
+        instances = np.ascontiguousarray(instances, dtype=pod.INST_DT)
+        check(self.L.nxhip_set_tlas(self.h, _ptr(nodes), len(nodes), _ptr(inst_idx), _ptr(instances), len(instances)), "nxhip_set_tlas")
+
+    def set_materials(self, materials):
+        materials = np.ascontiguousarray(materials, dtype=pod.MAT_DT)
+        check(self.L.nxhip_set_materials(self.h, _ptr(materials), len(materials)), "nxhip_set_materials")
+
+    def set_lights(self, lights):
+        lights = np.ascontiguousarray(lights, dtype=pod.LIGHT_DT)
+        check(self.L.nxhip_set_lights(self.h, _ptr(lights) if len(lights) else None, len(lights)), "nxhip_set_lights")
+
+    def upload_texture(self, kind, rgba8):
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert img.ndim == 3 and img.shape[2] == 4
+        tid = C.c_int32(-1)
+        check(self.L.nxhip_upload_texture(self.h, {"diffuse": 0, "emissive": 1, "hdr": 2}[kind], _ptr(img), img.shape[1], img.shape[0], C.byref(tid)),
+              "nxhip_upload_texture")
+        return tid.value
+
+    def clear_textures(self):
+        check(self.L.nxhip_clear_textures(self.h), "nxhip_clear_textures")
+
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(cam, dtype=pod.CAM_DT).reshape(1)
+        check(self.L.nxhip_set_camera(self.h, _ptr(cam)), "nxhip_set_camera")
+
+    def set_render_settings(self, st):
+        st = np.ascontiguousarray(st, dtype=pod.SETTINGS_DT).reshape(1)
+        check(self.L.nxhip_set_render_settings(self.h, _ptr(st)), "nxhip_set_render_settings")
+
+    def set_modes(self, rng_mode=pod.RNG_REFERENCE_SLOT, compact_mode=pod.COMPACT_FAST, conductor_mode=pod.CONDUCTOR_REFERENCE):
+        check(self.L.nxhip_set_modes(self.h, rng_mode, compact_mode, conductor_mode), "nxhip_set_modes")
+
+    def set_pixel_map(self, pixel_map):
+        if pixel_map is None:
+            check(self.L.nxhip_set_pixel_map(self.h, None, 0), "nxhip_set_pixel_map")
+            self.local_count = self.width * self.height
+        else:
+            pm = np.ascontiguousarray(pixel_map, dtype=np.uint32)
+            check(self.L.nxhip_set_pixel_map(self.h, _ptr(pm), len(pm)), "nxhip_set_pixel_map")
+            self.local_count = len(pm)
+
+    def resize(self, width, height):
+        check(self.L.nxhip_resize(self.h, width, height), "nxhip_resize")
+        self.width, self.height = int(width), int(height)
+        self.local_count = self.width * self.height
+
+    # rendering
+    def reset_frame_number(self):
+        check(self.L.nxhip_reset_frame_number(self.h), "nxhip_reset_frame_number")
+
+    def set_frame_number(self, f):
+        check(self.L.nxhip_set_frame_number(self.h, f), "nxhip_set_frame_number")
+
+    def frame_number(self):
+        return int(self.L.nxhip_frame_number(self.h))
+
+    def render_frame(self):
+        check(self.L.nxhip_render_frame(self.h), "nxhip_render_frame")
+
+    def accumulate(self):
+        check(self.L.nxhip_accumulate(self.h), "nxhip_accumulate")
+
+    def accumulate_external(self, dev_ptr, count, frame_number):
+        check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, frame_number), "nxhip_accumulate_external")
+
+    def render(self, frames):
+        check(self.L.nxhip_render(self.h, frames), "nxhip_render")
+
+    def sync(self):
+        check(self.L.nxhip_sync(self.h), "nxhip_sync")
+
+    def read_radiance(self):
+        out = np.zeros((self.local_count, 3), np.float32)
+        check(self.L.nxhip_read_radiance(self.h, _ptr(out)), "nxhip_read_radiance")
+        return out
+
+    def read_accumulation(self):
+        out = np.zeros((self.local_count, 3), np.float32)
+        check(self.L.nxhip_read_accumulation(self.h, _ptr(out)), "nxhip_read_accumulation")
+        return out
+
+    def read_rgba8(self):
+        out = np.zeros(self.local_count, np.uint32)
+        check(self.L.nxhip_read_rgba8(self.h, _ptr(out)), "nxhip_read_rgba8")
+        return out
+
+    def radiance_device_ptr(self):
+        return self.L.nxhip_radiance_device_ptr(self.h)
+
+    def accumulation_device_ptr(self):
+        return self.L.nxhip_accumulation_device_ptr(self.h)
+
+    def read_queue_sizes(self):
+        q = QueueSizes()
+        check(self.L.nxhip_read_queue_sizes(self.h, C.byref(q)), "nxhip_read_queue_sizes")
+        return {n: np.array(getattr(q, n)[:], dtype=np.int32) for n, _ in QueueSizes._fields_}
+
+    def set_pixel_query(self, x, y):
+        check(self.L.nxhip_set_pixel_query(self.h, x, y), "nxhip_set_pixel_query")
+
+    def get_selected_instance(self):
+        v = C.c_int32(0)
+        check(self.L.nxhip_get_selected_instance(self.h, C.byref(v)), "nxhip_get_selected_instance")
+        return v.value
+
+    # hooks
+    def trace_batch(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=pod.RAY_DT)
+        hits = np.zeros(len(rays), dtype=pod.HIT_DT)
+        check(self.L.nxhip_trace_batch(self.h, _ptr(rays), len(rays), _ptr(hits)), "nxhip_trace_batch")
+        return hits
+
+    def trace_shadow_batch(self, rays, tmax):
+        rays = np.ascontiguousarray(rays, dtype=pod.RAY_DT)
+        tmax = np.ascontiguousarray(tmax, dtype=np.float32)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        check(self.L.nxhip_trace_shadow_batch(self.h, _ptr(rays), _ptr(tmax), len(rays), _ptr(occ)), "nxhip_trace_shadow_batch")
+        return occ
+
+    def enable_trace_stats(self, on=True):
+        check(self.L.nxhip_enable_trace_stats(self.h, 1 if on else 0), "nxhip_enable_trace_stats")
+
+    def read_trace_stats(self, reset=False):
+        a, b = TraceStats(), TraceStats()
+        check(self.L.nxhip_read_trace_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0), "nxhip_read_trace_stats")
+        return a.as_dict(), b.as_dict()
+
+    def enable_kernel_timing(self, on=True):
+        check(self.L.nxhip_enable_kernel_timing(self.h, 1 if on else 0), "nxhip_enable_kernel_timing")
+
+    def read_kernel_times(self, reset=False):
+        t = KernelTimes()
+        check(self.L.nxhip_read_kernel_times(self.h, C.byref(t), 1 if reset else 0), "nxhip_read_kernel_times")
+        return {k: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, k in enumerate(KERNEL_CLASSES)}
+
+
+def device_count():
+    return int(lib().nxhip_device_count())

@@ -1,0 +1,105 @@
+// nx_context.h — host-side bookkeeping of one device context (internal to the device layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "nexus_hip.h"
+#include "nx_device.h"
+
+namespace nxd {
+
+void set_error(const std::string& msg);
+bool hip_ok(hipError_t e, const char* what, const char* file, int line);
+
+#define NX_HIP(call)                                                              \
+    do {                                                                          \
+        if (!::nxd::hip_ok((call), #call, __FILE__, __LINE__)) return NXHIP_ERR_HIP; \
+    } while (0)
+
+// Owning device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // (Re)allocate; contents undefined.  Returns false on failure (error string set).
+    bool alloc(size_t n);
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct BlasHost {
+    DevBuf nodes, isect, tris, triIdx;
+    uint32_t nodeCount = 0, triCount = 0;
+};
+
+struct TextureHost {
+    DevBuf texels;
+    uint32_t width = 0, height = 0;
+};
+
+struct KernelTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+}  // namespace nxd
+
+struct nxhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    hipStream_t stream2 = nullptr;  // second branch of the per-bounce fork (shadow trace)
+    int numCUs = 0;
+
+    uint32_t width = 0, height = 0, localCount = 0;
+
+    nxd::DeviceState h{};  // host mirror, uploaded to dState when dirty
+    nxd::DevBuf dState;
+    bool stateDirty = true;
+
+    // scene
+    std::vector<nxd::BlasHost> blas;
+    nxd::DevBuf blasTable;
+    nxd::DevBuf tlasNodes, tlasInstIdx, instTrav, instances;
+    std::vector<nx_bvh_instance> hostInstances;
+    nxd::DevBuf materials, lights;
+    std::vector<nxd::TextureHost> diffuseMaps, emissiveMaps;
+    nxd::TextureHost hdrMap;
+    nxd::DevBuf diffuseTable, emissiveTable, srgbLut;
+    // paths / queues
+    nxd::DevBuf pixelMap, throughputPdf, radiance, rayOrigin, accumulation, rgba8;
+    nxd::DevBuf trRayO, trRayD, trHit, trHitInst;
+    nxd::DevBuf shRayO, shRayD, shRadiance;
+    nxd::DevBuf mqHit[4], mqDirInst[4], mqPixel[4];
+    nxd::DevBuf counters, frame, traceStats;
+
+    uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
+    bool statsEnabled = false;
+    bool timingEnabled = false;
+    nxhip_kernel_times times{};
+    std::vector<nxd::KernelTimer> timerPool;
+    std::vector<int> timerClass;  // kernel class of timerPool[i]
+
+    // frame graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graphExec = nullptr;
+    bool graphValid = false;
+
+    int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;
+};

@@ -1,0 +1,130 @@
+// nx_device.h — device-resident state of one context: scene tables, ray queues, counters.
+//
+// Layout in HBM (all 16-byte aligned, float4-packed so every lane moves 16 B per access):
+//   BLAS k   : nodes   uint4[5*nodeCount]   the 80-byte CWBVH nodes as uploaded (reference D_BVH8Node)
+//              isect   float4[3*triCount]   leaf-ordered intersection stream {p0,origTriIdx},{e0,0},{e1,0}:
+//                                           built at upload so the trace kernel needs no triangleIdx
+//                                           indirection and reads 48 B instead of 4 + 96
+//              tris    nx_triangle[triCount] original 96-byte triangles (shading only)
+//   TLAS     : nodes, instIdx u32[], instTrav InstTrav[instanceCount] (64 B: inverse transform rows + the
+//              BLAS pointers, replaces the reference's 160-B instance + 32-B D_BVH8 double fetch),
+//              instances nx_bvh_instance[] (shading only)
+//   queues   : trace   rayO float4 (origin, -), rayD float4 (direction, pixelIdx), hit float4 (t,u,v,triIdx),
+//                      hitInst u32            — reference D_TraceRequestSOA, Cuda/PathTracer/PathTracer.cuh:32-37
+//              shadow  rayO float4 (origin, tmax), rayD float4 (direction, pixelIdx), rad float4
+//                                             — D_ShadowTraceRequestSOA, PathTracer.cuh:39-45
+//              material[4] hit float4, dirInst float4 (direction, instanceIdx), pixel u32
+//                                             — D_MaterialRequestSOA, PathTracer.cuh:47-52
+//              path    throughput float4 (rgb, lastPdf), radiance float4, rayOrigin float4
+//                                             — D_PathStateSOA, PathTracer.cuh:19-30
+//   counters : per bounce queue sizes (reference D_QueueSize) + 8 per-XCD fetch heads per trace launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nexus_pod.h"
+
+namespace nxd {
+
+constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with its own L2
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;
+
+struct BlasDev {
+    const uint4* nodes;
+    const float4* isect;
+    const nx_triangle* tris;
+    const uint32_t* triIdx;
+    uint32_t nodeCount, triCount;
+    uint32_t pad_[2];
+};
+static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
+
+struct __attribute__((aligned(16))) InstTrav {
+    float4 r0, r1, r2;  // rows 0..2 of invTransform
+    const uint4* nodes;
+    const float4* isect;
+};
+static_assert(sizeof(InstTrav) == 64, "InstTrav layout");
+
+struct TextureDev {
+    const uint32_t* texels;  // RGBA8, row 0 first
+    uint32_t width, height;
+};
+
+struct TraceQueue {
+    float4* rayO;
+    float4* rayD;
+    float4* hit;
+    uint32_t* hitInst;
+};
+struct ShadowQueue {
+    float4* rayO;
+    float4* rayD;
+    float4* radiance;
+};
+struct MaterialQueue {
+    float4* hit;
+    float4* dirInst;
+    uint32_t* pixel;
+};
+
+// Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize
+// (PathTracer.cuh:61-73) with traceCount/traceShadowCount widened to one fetch head per XCD.
+struct Counters {
+    int32_t traceSize[kMaxBounceSlots];
+    int32_t traceShadowSize[kMaxBounceSlots];
+    int32_t materialSize[4][kMaxBounceSlots];  // enum order DIFFUSE, DIELECTRIC, PLASTIC, CONDUCTOR
+    int32_t traceHead[kMaxBounceSlots][kXcds];
+    int32_t shadowHead[kMaxBounceSlots][kXcds];
+    // ordered-compaction running bases (single-workgroup mode)
+    int32_t orderedBase[8];
+};
+
+struct FrameState {
+    uint32_t frameNumber;
+    int32_t pixelQueryPixel;     // -1: none (D_PixelQuery, PathTracer.cuh:54-58)
+    int32_t pixelQueryInstance;
+    uint32_t pad_;
+};
+
+struct TraceStatsDev {
+    unsigned long long rays, nodes, tris, instances;
+};
+
+struct DeviceState {
+    // scene
+    const uint4* tlasNodes;
+    const uint32_t* tlasInstIdx;
+    const InstTrav* instTrav;
+    const nx_bvh_instance* instances;
+    const BlasDev* blas;
+    const nx_material* materials;
+    const nx_light* lights;
+    const TextureDev* diffuseMaps;
+    const TextureDev* emissiveMaps;
+    const float* srgbLut;  // 256 floats
+    TextureDev hdrMap;     // texels == nullptr: flat background
+    uint32_t lightCount;
+    uint32_t instanceCount;
+    nx_camera camera;
+    nx_render_settings settings;
+    int32_t rngMode, compactMode, conductorMode;
+    // paths
+    uint32_t localCount;       // paths rendered by this context
+    const uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
+    float4* throughputPdf;     // rgb throughput, w = lastPdf
+    float4* radiance;
+    float4* rayOrigin;
+    float4* accumulation;
+    uint32_t* rgba8;
+    TraceQueue trace;
+    ShadowQueue shadow;
+    MaterialQueue material[4];
+    Counters* counters;
+    FrameState* frame;
+    TraceStatsDev* traceStats;  // [0] closest, [1] shadow
+};
+
+}  // namespace nxd

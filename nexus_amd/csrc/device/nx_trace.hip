@@ -1,0 +1,308 @@
+// nx_trace.hip — closest-hit and any-hit traversal of the two-level compressed BVH8 (gfx950 / CDNA4).
+//
+// What it computes is the reference's TraceKernel / TraceShadowKernel
+// (/root/reference/Nexus/src/Cuda/PathTracer/PathTracer.cu:125-133 ->
+//  Cuda/BVH/BVH8Traversal.cuh:55-146 ChildTrace, :148-322 BVH8Trace, :326-518 BVH8TraceShadow,
+//  Cuda/Geometry/Triangle.cuh:53-118 Moeller-Trumbore): per ray the same nodes are visited in the same
+// order and the same hit record results.  How it is organised is CDNA4-first:
+//   * one ray per lane of a 64-wide wave; persistent workgroups; rays are fetched a wave at a time with
+//     ONE atomic per refill (ballot + popcount ranks) instead of one atomic per lane;
+//   * the ray queue is cut into 8 contiguous shards, one fetch head per XCD group (blockIdx % 8 share an
+//     XCD and its private 4 MiB L2): waves of one XCD walk one band of the image / queue so the BVH
+//     subtrees they touch stay in that XCD's L2, and the head word is not hammered by 256 CUs; a wave
+//     whose shard runs dry steals from the next one;
+//   * every lane's loop iteration is "pop -> one node test -> one triangle test" so that the 64 lanes
+//     reconverge at the node test and at the triangle test in every iteration (the reference's
+//     `while (triangleEntry.y)` inner loop serialises lanes with long triangle lists on a 64-wide wave);
+//   * an 80-byte node is five 16-byte loads; quantised bounds are converted with v_cvt_f32_ubyteN and the
+//     slab test is 6 v_fma per child + integer max3/min3 on the float bit patterns (identical ordering to
+//     the reference's vmax.s32/vmin.s32 PTX, including its NaN behaviour);
+//   * triangles come from a leaf-ordered 48-byte stream (p0|id, e0, e1) built at upload: three 16-byte
+//     loads and no triangleIdx indirection; instances from a 64-byte traversal record;
+//   * the traversal stack lives in LDS, entry-major ([depth][lane]) so ds_read/write_b64 are
+//     conflict-free, with a scratch overflow; the world-space ray is re-read from the queue when an
+//     instance is left instead of being kept in 6 VGPRs.
+// No MFMA: this is pointer chasing, bounded by memory latency / bandwidth.
+#include "nx_device.h"
+#include "nx_math.h"
+
+namespace nxd {
+
+constexpr int kTraceBlock = 256;  // 4 waves
+constexpr int kLdsDepth = 12;     // stack entries per lane held in LDS (24 KiB per workgroup)
+constexpr int kSpillDepth = 20;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
+constexpr int kRefillBelow = 40;  // refill idle lanes when fewer than this many of the 64 are still traversing
+
+struct Stack {
+    uint2* lds;  // &ldsStack[tid]
+    uint2 spill[kSpillDepth];
+    int sp;
+    NXD void push(uint2 e)
+    {
+        if (sp < kLdsDepth) lds[sp * kTraceBlock] = e;
+        else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = e;
+        sp++;
+    }
+    NXD uint2 pop()
+    {
+        sp--;
+        if (sp < kLdsDepth) return lds[sp * kTraceBlock];
+        if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
+        return make_uint2(0u, 0u);
+    }
+};
+
+NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
+NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
+NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
+
+// ChildTrace — BVH8Traversal.cuh:55-146
+NXD void child_trace(const uint4* __restrict__ nodes, uint32_t nodeIdx, f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
+{
+    const uint4* n = nodes + (size_t)nodeIdx * 5u;
+    const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3], n4 = n[4];
+
+    const f3 p = mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const f3 tdir = mk3(__uint_as_float((e_imask & 0xffu) << 23) * idir.x, __uint_as_float((e_imask << 15) & 0x7f800000u) * idir.y,
+                        __uint_as_float((e_imask << 7) & 0x7f800000u) * idir.z);
+    const f3 torg = (p - org) * idir;
+    const bool nx = dir.x < 0.0f, ny = dir.y < 0.0f, nz = dir.z < 0.0f;
+
+    uint32_t hitMask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t meta4 = i ? n1.w : n1.z;
+        const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;  // per byte 0xff where inner (reference: prmt sign extension)
+        const uint32_t bitIndex4 = (meta4 ^ (invOct4 & innerMask4)) & 0x1f1f1f1fu;
+        const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
+
+        const uint32_t qlox = i ? n2.y : n2.x, qloy = i ? n2.w : n2.z, qloz = i ? n3.y : n3.x;
+        const uint32_t qhix = i ? n3.w : n3.z, qhiy = i ? n4.y : n4.x, qhiz = i ? n4.w : n4.z;
+        const uint32_t xMin = nx ? qhix : qlox, xMax = nx ? qlox : qhix;
+        const uint32_t yMin = ny ? qhiy : qloy, yMax = ny ? qloy : qhiy;
+        const uint32_t zMin = nz ? qhiz : qloz, zMax = nz ? qloz : qhiz;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float tminx = fmaf(ubyte_f(xMin, j), tdir.x, torg.x);
+            const float tminy = fmaf(ubyte_f(yMin, j), tdir.y, torg.y);
+            const float tminz = fmaf(ubyte_f(zMin, j), tdir.z, torg.z);
+            const float tmaxx = fmaf(ubyte_f(xMax, j), tdir.x, torg.x);
+            const float tmaxy = fmaf(ubyte_f(yMax, j), tdir.y, torg.y);
+            const float tmaxz = fmaf(ubyte_f(zMax, j), tdir.z, torg.z);
+            const float tmin = __int_as_float(imax3(__float_as_int(tminx), __float_as_int(tminy), __float_as_int(fmaxf(tminz, 0.0f))));
+            const float tmax = __int_as_float(imin3(__float_as_int(tmaxx), __float_as_int(tmaxy), __float_as_int(fminf(tmaxz, tmaxRay))));
+            const uint32_t childBits = (childBits4 >> (8 * j)) & 0xffu;
+            const uint32_t bitIndex = (bitIndex4 >> (8 * j)) & 0xffu;
+            hitMask |= (tmin <= tmax) ? (childBits << bitIndex) : 0u;
+        }
+    }
+    ng = make_uint2(n1.x, (hitMask & 0xff000000u) | (e_imask >> 24));
+    tg = make_uint2(n1.y, hitMask & 0x00ffffffu);
+}
+
+template <bool ANY_HIT, bool STATS>
+__global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
+{
+    __shared__ uint2 ldsStack[kLdsDepth * kTraceBlock];
+
+    Counters* __restrict__ C = S->counters;
+    const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
+    if (size <= 0) return;
+    int* heads = ANY_HIT ? C->shadowHead[bounce] : C->traceHead[bounce];
+    const float4* __restrict__ rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
+    const float4* __restrict__ rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
+    const uint4* __restrict__ tlasNodes = S->tlasNodes;
+    const uint32_t* __restrict__ tlasInstIdx = S->tlasInstIdx;
+    const InstTrav* __restrict__ instTrav = S->instTrav;
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+    // shard geometry: 8 contiguous, 64-aligned pieces of the queue
+    const int chunk = ((size + kXcds * kWave - 1) / (kXcds * kWave)) * kWave;
+    int shard = blockIdx.x & (kXcds - 1);
+    int shardsTried = 0;
+    bool exhausted = false;
+
+    Stack st;
+    st.lds = &ldsStack[threadIdx.x];
+    st.sp = 0;
+
+    bool active = false;
+    f3 org = mk3(0.0f), dir = mk3(0.0f), idir = mk3(0.0f);
+    float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
+    uint32_t hitTri = 0xffffffffu, hitInst = 0xffffffffu;
+    uint32_t rayIdx = 0, pixelBits = 0, instIdx = 0, invOct4 = 0;
+    int instSp = -1;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    const uint4* nodes = tlasNodes;
+    const float4* isect = nullptr;
+    unsigned long long nNodes = 0, nTris = 0, nInst = 0, nRays = 0;
+
+    for (;;) {
+        // ---- refill idle lanes: one atomic per wave and shard
+        if (!exhausted) {
+            bool need = !active;
+            while (!exhausted) {
+                const unsigned long long needMask = __ballot(need);
+                if (needMask == 0ull) break;
+                const int n = __popcll(needMask);
+                const int leader = __ffsll((long long)needMask) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&heads[shard], n);
+                base = __shfl(base, leader);
+                const int shardBegin = shard * chunk;
+                const int shardEnd = min(size, shardBegin + chunk);
+                const int idx = shardBegin + base + __popcll(needMask & laneLt);
+                if (need && idx < shardEnd) {
+                    need = false;
+                    active = true;
+                    rayIdx = (uint32_t)idx;
+                    const float4 o = rayO[idx], d = rayD[idx];
+                    org = mk3(o.x, o.y, o.z);
+                    dir = mk3(d.x, d.y, d.z);
+                    pixelBits = __float_as_uint(d.w);
+                    idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                    hitT = ANY_HIT ? o.w : 1e30f;
+                    hitU = 0.0f; hitV = 0.0f; hitTri = 0xffffffffu; hitInst = 0xffffffffu;
+                    const uint32_t oct = ((dir.x < 0.0f ? 1u : 0u) << 2) | ((dir.y < 0.0f ? 1u : 0u) << 1) | (dir.z < 0.0f ? 1u : 0u);
+                    invOct4 = (7u - oct) * 0x01010101u;
+                    ng = make_uint2(0u, 0x80000000u);
+                    tg = make_uint2(0u, 0u);
+                    st.sp = 0;
+                    instSp = -1;
+                    nodes = tlasNodes;
+                    if (STATS) nRays++;
+                }
+                if (shardBegin + base + n >= shardEnd) {  // this shard is dry: steal from the next XCD's
+                    shard = (shard + 1) & (kXcds - 1);
+                    if (++shardsTried == kXcds) exhausted = true;
+                }
+            }
+        }
+        unsigned long long activeMask = __ballot(active);
+        if (activeMask == 0ull) break;
+
+        // ---- traverse until too many lanes have run out of work
+        do {
+            // A: acquire work from the stack, or retire the ray
+            if (active && tg.y == 0u && (ng.y & 0xff000000u) == 0u) {
+                if (st.sp == 0) {
+                    active = false;
+                    if (ANY_HIT) {
+                        // unoccluded: pathRadiance[pixelIdx] += radiance (BVH8Traversal.cuh:515-516);
+                        // at most one shadow ray per pixel and bounce, so no atomic is needed
+                        const float4 r = S->shadow.radiance[rayIdx];
+                        float4* dst = &S->radiance[pixelBits];
+                        float4 cur = *dst;
+                        cur.x += r.x; cur.y += r.y; cur.z += r.z;
+                        *dst = cur;
+                    } else {
+                        S->trace.hit[rayIdx] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
+                        S->trace.hitInst[rayIdx] = hitInst;
+                    }
+                } else {
+                    if (st.sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
+                        const float4 o = rayO[rayIdx], d = rayD[rayIdx];
+                        org = mk3(o.x, o.y, o.z);
+                        dir = mk3(d.x, d.y, d.z);
+                        idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                        nodes = tlasNodes;
+                        instSp = -1;
+                    }
+                    const uint2 e = st.pop();
+                    if (e.y & 0xff000000u) ng = e;
+                    else { tg = e; ng = make_uint2(0u, 0u); }
+                }
+            }
+            // B: one node test
+            if (active && tg.y == 0u && (ng.y & 0xff000000u) != 0u) {
+                const int nodeOffset = 31 - __clz((int)ng.y);
+                ng.y &= ~(1u << nodeOffset);
+                if (ng.y & 0xff000000u) st.push(ng);
+                const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
+                const int rel = __popc(ng.y & ~(0xffffffffu << slot));
+                child_trace(nodes, ng.x + (uint32_t)rel, org, dir, idir, invOct4, hitT, ng, tg);
+                if (STATS) nNodes++;
+            }
+            // C: one leaf primitive: an instance (TLAS) or a triangle (BLAS)
+            if (active && tg.y != 0u) {
+                const int off = 31 - __clz((int)tg.y);
+                tg.y &= ~(1u << off);
+                if (instSp < 0) {
+                    instIdx = tlasInstIdx[tg.x + (uint32_t)off];
+                    if (tg.y) st.push(tg);
+                    if (ng.y & 0xff000000u) st.push(ng);
+                    instSp = st.sp;
+                    const InstTrav* it = &instTrav[instIdx];
+                    const float4 r0 = it->r0, r1 = it->r1, r2 = it->r2;
+                    nodes = it->nodes;
+                    isect = it->isect;
+                    ng = make_uint2(0u, 0x80000000u);
+                    tg = make_uint2(0u, 0u);
+                    // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264)
+                    org = mat_point(r0, r1, r2, org);
+                    dir = mat_vec(r0, r1, r2, dir);
+                    idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                    if (STATS) nInst++;
+                } else {
+                    // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
+                    const float4* tp = isect + (size_t)(tg.x + (uint32_t)off) * 3u;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    const f3 p0 = mk3(a.x, a.y, a.z), edge0 = mk3(b.x, b.y, b.z), edge1 = mk3(c.x, c.y, c.z);
+                    const f3 rayCrossEdge1 = cross3(dir, edge1);
+                    const float det = dot3(edge0, rayCrossEdge1);
+                    const float invDet = 1.0f / det;
+                    const f3 s = org - p0;
+                    const float u = invDet * dot3(s, rayCrossEdge1);
+                    const f3 sCrossEdge0 = cross3(s, edge0);
+                    const float v = invDet * dot3(dir, sCrossEdge0);
+                    const float t = invDet * dot3(edge1, sCrossEdge0);
+                    const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0f && t < hitT);
+                    if (STATS) nTris++;
+                    if (hit) {
+                        if (ANY_HIT) {
+                            active = false;  // occluded: nothing to add
+                        } else {
+                            hitT = t; hitU = u; hitV = v;
+                            hitTri = __float_as_uint(a.w);
+                            hitInst = instIdx;
+                        }
+                    }
+                }
+            }
+            activeMask = __ballot(active);
+        } while (activeMask != 0ull && (exhausted || __popcll(activeMask) >= kRefillBelow));
+    }
+
+    if (STATS) {
+        // wave-level reduction, one atomic per wave and counter
+        for (int o = 32; o > 0; o >>= 1) {
+            nRays += __shfl_down(nRays, o);
+            nNodes += __shfl_down(nNodes, o);
+            nTris += __shfl_down(nTris, o);
+            nInst += __shfl_down(nInst, o);
+        }
+        if (lane == 0) {
+            TraceStatsDev* ts = &S->traceStats[ANY_HIT ? 1 : 0];
+            atomicAdd(&ts->rays, nRays);
+            atomicAdd(&ts->nodes, nNodes);
+            atomicAdd(&ts->tris, nTris);
+            atomicAdd(&ts->instances, nInst);
+        }
+    }
+}
+
+template __global__ void trace_kernel<false, false>(const DeviceState*, int);
+template __global__ void trace_kernel<false, true>(const DeviceState*, int);
+template __global__ void trace_kernel<true, false>(const DeviceState*, int);
+template __global__ void trace_kernel<true, true>(const DeviceState*, int);
+
+const void* trace_kernel_ptr(bool anyHit, bool stats)
+{
+    if (anyHit) return stats ? (const void*)trace_kernel<true, true> : (const void*)trace_kernel<true, false>;
+    return stats ? (const void*)trace_kernel<false, true> : (const void*)trace_kernel<false, false>;
+}
+
+}  // namespace nxd

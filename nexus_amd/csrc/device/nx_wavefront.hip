@@ -1,0 +1,494 @@
+// nx_wavefront.hip — the wide wavefront kernels: begin-frame, generate, logic, shade (+NEE), accumulate.
+//
+// What they compute is the reference's GenerateKernel, LogicKernel, Shade<BSDF> + NextEventEstimation<BSDF> and
+// AccumulateKernel (/root/reference/Nexus/src/Cuda/PathTracer/PathTracer.cu:85-122, 136-210, 213-458, 480-496).
+// How they run is MI355X-first:
+//   * persistent grid-stride launches (<= 2048 workgroups of 256) instead of N/64+1 blocks that mostly exit:
+//     late bounces with few live paths cost a launch, not tens of thousands of empty workgroups;
+//   * float4-packed SoA queues: every lane moves 16 B per access, fully coalesced;
+//   * queue slots are handed out once per wave (ballot + popcount rank + one atomic) — NX_COMPACT_FAST — or by an
+//     ordered block-wide scan in a single 1024-thread workgroup — NX_COMPACT_ORDERED, which reproduces the
+//     reference's serial slot order exactly (ascending thread index, material kernels in graph order) and is
+//     what the parity tests use; the shading math is the same code in both modes;
+//   * a path's shadow-ray and continuation-ray payloads are built in registers and written after the slot
+//     allocation, outside divergent control flow;
+//   * the frame number lives on the device and is advanced by begin_frame_kernel, so a frame is one
+//     hipGraph replay with no host-side writes in between.
+#include "nx_bsdf.h"
+#include "nx_device.h"
+#include "nx_math.h"
+#include "nx_texture.h"
+
+namespace nxd {
+
+constexpr int kWideBlock = 256;
+constexpr int kOrderedBlock = 1024;
+
+// ------------------------------------------------------------------------------------------------------
+// slot allocation
+
+template <bool ORDERED> struct SlotAllocator;
+
+// FAST: one atomic per wave.
+template <> struct SlotAllocator<false> {
+    NXD void init(const DeviceState*, int) {}
+    NXD void finish(const DeviceState*, int) {}
+    NXD int alloc(bool want, int* counter, int /*which*/)
+    {
+        const unsigned long long mask = __ballot(want);
+        if (mask == 0ull) return -1;
+        const int lane = threadIdx.x & (kWave - 1);
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+        base = __shfl(base, leader);
+        return base + __popcll(mask & ((1ull << lane) - 1ull));
+    }
+};
+
+// ORDERED: single workgroup; running bases live in LDS, slots follow ascending thread index.
+// which: 0 trace, 1 shadow, 2..5 material queues.
+template <> struct SlotAllocator<true> {
+    int* sBase;   // [6]
+    int* sWave;   // [kOrderedBlock / 64]
+    NXD void init(const DeviceState* S, int bounce)
+    {
+        __shared__ int base[6];
+        __shared__ int wave[kOrderedBlock / kWave];
+        sBase = base;
+        sWave = wave;
+        if (threadIdx.x == 0) {
+            Counters* C = S->counters;
+            base[0] = C->traceSize[bounce];
+            base[1] = C->traceShadowSize[bounce];
+            for (int m = 0; m < 4; m++) base[2 + m] = C->materialSize[m][bounce];
+        }
+        __syncthreads();
+    }
+    NXD void finish(const DeviceState* S, int bounce)
+    {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Counters* C = S->counters;
+            C->traceSize[bounce] = sBase[0];
+            C->traceShadowSize[bounce] = sBase[1];
+            for (int m = 0; m < 4; m++) C->materialSize[m][bounce] = sBase[2 + m];
+        }
+    }
+    // must be called by every thread of the workgroup
+    NXD int alloc(bool want, int* /*counter*/, int which)
+    {
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        const unsigned long long mask = __ballot(want);
+        if (lane == 0) sWave[wave] = __popcll(mask);
+        __syncthreads();
+        const int nWaves = blockDim.x / kWave;
+        int prefix = 0, total = 0;
+        for (int w = 0; w < nWaves; w++) {
+            const int c = sWave[w];
+            prefix += (w < wave) ? c : 0;
+            total += c;
+        }
+        const int base = sBase[which];
+        __syncthreads();
+        if (threadIdx.x == 0) sBase[which] = base + total;
+        __syncthreads();
+        return want ? base + prefix + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+    }
+};
+
+NXD uint32_t global_pixel(const DeviceState* S, uint32_t local) { return S->pixelMap ? S->pixelMap[local] : local; }
+
+NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pixelIdx, uint32_t bounce, uint32_t stage, uint32_t frame)
+{
+    if (S->rngMode == NX_RNG_PIXEL_KEYED) return rng_init_keyed(global_pixel(S, pixelIdx), bounce, frame, stage);
+    return rng_init_index(slot, S->camera.resolution[0], frame);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// begin frame: frameNumber++, zero every counter, traceSize[0] = localCount (GenerateKernel's thread 0 in
+// the reference, PathTracer.cu:112-113; the memset of PathTracer.cpp:263)
+
+__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(const DeviceState* __restrict__ S)
+{
+    int* c = reinterpret_cast<int*>(S->counters);
+    constexpr int n = (int)(sizeof(Counters) / sizeof(int));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->counters->traceSize[0] = (int)S->localCount;
+        S->frame->frameNumber += 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// GenerateKernel — PathTracer.cu:85-122
+
+__global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState* __restrict__ S)
+{
+    const uint32_t n = S->localCount;
+    const uint32_t frame = S->frame->frameNumber;
+    const uint32_t resX = S->camera.resolution[0], resY = S->camera.resolution[1];
+    const f3 camPos = ld3(S->camera.position), camRight = ld3(S->camera.right), camUp = ld3(S->camera.up);
+    const f3 llc = ld3(S->camera.lowerLeftCorner), vpX = ld3(S->camera.viewportX), vpY = ld3(S->camera.viewportY);
+    const float lensRadius = S->camera.lensRadius;
+    for (uint32_t index = blockIdx.x * blockDim.x + threadIdx.x; index < n; index += gridDim.x * blockDim.x) {
+        const uint32_t g = global_pixel(S, index);
+        const uint32_t j = g / resX;
+        const uint32_t i = g - j * resX;
+        uint32_t rng = rng_init_pixel(i, j, resX, frame);
+        const float x = ((float)i + rng_next(rng)) / (float)resX;
+        const float y = ((float)j + rng_next(rng)) / (float)resY;
+        const f2 disk = unit_disk(rng);
+        const float rdx = lensRadius * disk.x, rdy = lensRadius * disk.y;
+        const f3 offset = camRight * rdx + camUp * rdy;
+        const f3 origin = camPos + offset;
+        const f3 direction = normalize3((((llc + vpX * x) + vpY * y) - camPos) - offset);
+        S->rayOrigin[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+        S->throughputPdf[index] = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);
+        S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+        S->trace.rayD[index] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SampleBackground — PathTracer.cu:65-83
+
+NXD f3 sample_background(const DeviceState* S, f3 d)
+{
+    if (S->hdrMap.texels) {
+        const float theta = atan2f(d.z, d.x);
+        const float phi = asinf(d.y);
+        const float u = (float)((theta + kPiD) * kInvPi * 0.5);
+        const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
+        const float4 c = tex2d(S->hdrMap, S->srgbLut, u, v);
+        return mk3(c.x, c.y, c.z);
+    }
+    return ld3(S->settings.backgroundColor) * S->settings.backgroundIntensity;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LogicKernel — PathTracer.cu:136-210
+
+template <bool ORDERED>
+__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
+{
+    Counters* C = S->counters;
+    const int size = C->traceSize[bounce - 1];
+    const uint32_t frame = S->frame->frameNumber;
+    SlotAllocator<ORDERED> slots;
+    slots.init(S, bounce);
+    const int stride = gridDim.x * blockDim.x;
+    for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
+        const int index = tile + (int)threadIdx.x;
+        int type = -1;
+        float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0);
+        uint32_t inst = 0, pixelIdx = 0;
+        if (index < size) {
+            hit = S->trace.hit[index];
+            dirPix = S->trace.rayD[index];
+            pixelIdx = __float_as_uint(dirPix.w);
+            const f3 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
+            const float4 tp = S->throughputPdf[pixelIdx];
+            const f3 throughput = bounce == 1 ? mk3(1.0f) : mk3(tp.x, tp.y, tp.z);
+            if (hit.x == 1e30f) {
+                const f3 bg = throughput * sample_background(S, dir);
+                float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
+                r.x += bg.x; r.y += bg.y; r.z += bg.z;
+                if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
+                S->radiance[pixelIdx] = r;
+                if (bounce == 1 && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
+            } else {
+                uint32_t rng = seed_for(S, (uint32_t)index, pixelIdx, (uint32_t)bounce, 0u, frame);
+                const float probability = maxcomp3(throughput);
+                if (rng_next(rng) < probability) {
+                    const f3 t = throughput / probability;
+                    S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
+                    inst = S->trace.hitInst[index];
+                    const int materialId = S->instances[inst].materialId;
+                    type = S->materials[materialId].type;
+                    if (type < 0 || type > 3) type = -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const bool want = type == m;
+            const int slot = slots.alloc(want, &C->materialSize[m][bounce], 2 + m);
+            if (want) {
+                S->material[m].hit[slot] = hit;
+                S->material[m].dirInst[slot] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
+                S->material[m].pixel[slot] = pixelIdx;
+            }
+        }
+    }
+    slots.finish(S, bounce);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Shade<BSDF> + NextEventEstimation<BSDF> — PathTracer.cu:311-458, 213-308
+
+NXD MatParams load_params(const nx_material& m)
+{
+    MatParams p;
+    p.albedo = ld3(m.diffuse.albedo);
+    p.roughness = (m.type == NX_MAT_CONDUCTOR) ? m.conductor.roughness : m.plastic.roughness;
+    p.ior = m.plastic.ior;
+    p.cIor = ld3(m.conductor.ior);
+    p.cK = ld3(m.conductor.k);
+    return p;
+}
+
+NXD float tri_area(f3 p0, f3 p1, f3 p2) { return 0.5f * length3(cross3(p1 - p0, p2 - p0)); }
+
+struct ShadowPayload {
+    f3 origin, direction, radiance;
+    float distance;
+};
+
+template <int TYPE>
+NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp, f3 hitPoint, f3 normal, f3 hitGNormal, f3 throughput,
+                               uint32_t& rng, ShadowPayload& out)
+{
+    const nx_light light = S->lights[uniform_index(S->lightCount, rng)];
+    if (light.type != NX_LIGHT_MESH) return false;
+    const nx_bvh_instance* inst = &S->instances[light.mesh.meshId];
+    const BlasDev* bvh = &S->blas[inst->bvhIdx];
+    const uint32_t triangleIdx = uniform_index(bvh->triCount, rng);
+    const f2 uv = uniform_triangle(rng);
+    const nx_triangle* tri = &bvh->tris[triangleIdx];
+    const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
+    const float* T = inst->transform.cell;
+    const float* IT = inst->invTransform.cell;
+
+    f3 p = mat_point(T, bary3(tp0, tp1, tp2, uv.x, uv.y));
+    const f3 lightGNormal = normalize3(mat_vec_transposed(IT, cross3(tp1 - tp0, tp2 - tp0)));
+    const f3 lightNormal = normalize3(mat_vec_transposed(IT, bary3(ld3(tri->normal0), ld3(tri->normal1), ld3(tri->normal2), uv.x, uv.y)));
+
+    f3 toLight = p - hitPoint;
+    float offsetDirection = sgnE(dot3(toLight, normal));
+    out.origin = offset_ray(hitPoint, hitGNormal * offsetDirection);
+    offsetDirection = sgnE(dot3(-toLight, lightNormal));
+    p = offset_ray(p, lightGNormal * offsetDirection);
+
+    toLight = p - out.origin;
+    out.distance = length3(toLight);
+    out.direction = toLight / out.distance;
+
+    const float4 q = rotation_to_z(normal);
+    const f3 wo = rotate_point(q, out.direction);
+    const float cosThetaO = fabsf(dot3(lightNormal, out.direction));
+    const float dSquared = dot3(toLight, toLight);
+    const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
+    float lightPdf = 1.0f / ((float)(S->lightCount * bvh->triCount) * area);
+    lightPdf *= dSquared / cosThetaO;
+    if (!pdf_valid(lightPdf)) return false;
+
+    const nx_material* lightMaterial = &S->materials[inst->materialId];
+    f3 sampleThroughput;
+    float bsdfPdf;
+    if (!Bsdf<TYPE>::eval(mp, wi, wo, sampleThroughput, bsdfPdf)) return false;
+    const float weight = power_heuristic(lightPdf, bsdfPdf);
+
+    f3 emissive;
+    if (lightMaterial->emissiveMapId != -1) {
+        const f2 t = bary2(tri->texCoord0, tri->texCoord1, tri->texCoord2, uv.x, uv.y);
+        const float4 c = tex2d(S->emissiveMaps[lightMaterial->emissiveMapId], S->srgbLut, t.x, t.y);
+        emissive = mk3(c.x, c.y, c.z);
+    } else {
+        emissive = ld3(lightMaterial->emissive);
+    }
+    out.radiance = ((((throughput * weight) * sampleThroughput) * emissive) * lightMaterial->intensity) / lightPdf;
+    return true;
+}
+
+template <int TYPE, bool ORDERED>
+__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+{
+    Counters* C = S->counters;
+    const int size = C->materialSize[TYPE][bounce];
+    const uint32_t frame = S->frame->frameNumber;
+    const MaterialQueue mq = S->material[TYPE];
+    SlotAllocator<ORDERED> slots;
+    slots.init(S, bounce);
+    const int stride = gridDim.x * blockDim.x;
+    for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
+        const int requestIdx = tile + (int)threadIdx.x;
+        bool wantShadow = false, wantTrace = false, updatePath = false;
+        ShadowPayload sh;
+        f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
+        float nextPdf = 0.0f;
+        uint32_t pixelIdx = 0;
+
+        if (requestIdx < size) {
+            const float4 hit = mq.hit[requestIdx];
+            const float4 dirInst = mq.dirInst[requestIdx];
+            pixelIdx = mq.pixel[requestIdx];
+            const f3 rayDirection = mk3(dirInst.x, dirInst.y, dirInst.z);
+            const uint32_t instanceIdx = __float_as_uint(dirInst.w), triIdx = __float_as_uint(hit.w);
+            const float hu = hit.y, hv = hit.z;
+
+            const float4 tpdf = S->throughputPdf[pixelIdx];
+            f3 throughput = bounce == 1 ? mk3(1.0f) : mk3(tpdf.x, tpdf.y, tpdf.z);
+            uint32_t rng = seed_for(S, (uint32_t)requestIdx, pixelIdx, (uint32_t)bounce, 1u, frame);
+
+            const nx_bvh_instance* inst = &S->instances[instanceIdx];
+            const BlasDev* bvh = &S->blas[inst->bvhIdx];
+            const nx_triangle* tri = &bvh->tris[triIdx];
+            const nx_material material = S->materials[inst->materialId];
+            MatParams mp = load_params(material);
+            const float* T = inst->transform.cell;
+            const float* IT = inst->invTransform.cell;
+            const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
+
+            const f3 p = mat_point(T, bary3(tp0, tp1, tp2, hu, hv));
+            f3 normal = bary3(ld3(tri->normal0), ld3(tri->normal1), ld3(tri->normal2), hu, hv);
+            const f2 texUv = bary2(tri->texCoord0, tri->texCoord1, tri->texCoord2, hu, hv);
+            normal = normalize3(mat_vec_transposed(IT, normal));
+            f3 gNormal = normalize3(mat_vec_transposed(IT, cross3(tp1 - tp0, tp2 - tp0)));
+
+            f3 emissive = ld3(material.emissive);
+            if (material.emissiveMapId != -1) {
+                const float4 c = tex2d(S->emissiveMaps[material.emissiveMapId], S->srgbLut, texUv.x, texUv.y);
+                emissive = mk3(c.x, c.y, c.z);
+            }
+            const bool useMIS = S->settings.useMIS != 0;
+            const bool allowMIS = bounce > 1 && useMIS;
+            f3 radiance = mk3(0.0f);
+            if (maxcomp3(emissive * material.intensity) > 0.0f) {
+                float weight = 1.0f;
+                if (allowMIS) {
+                    const float lastPdf = tpdf.w;
+                    const float cosThetaO = fabsf(dot3(normal, rayDirection));
+                    const float4 ro = S->rayOrigin[pixelIdx];
+                    const float dSquared = squaref(length3(p - mk3(ro.x, ro.y, ro.z)));
+                    const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
+                    float lightPdf = 1.0f / ((float)(S->lightCount * bvh->triCount) * area);
+                    lightPdf *= dSquared / cosThetaO;
+                    if (!pdf_valid(lightPdf)) weight = 0.0f;
+                    else weight = power_heuristic(lastPdf, lightPdf);
+                }
+                radiance = ((emissive * weight) * material.intensity) * throughput;
+            }
+            {
+                float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
+                if (bounce == 1) r = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                else { r.x += radiance.x; r.y += radiance.y; r.z += radiance.z; }
+                S->radiance[pixelIdx] = r;
+            }
+
+            if (bounce != (int)S->settings.pathLength) {
+                if (bounce == 1 && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = (int)instanceIdx;
+
+                float4 color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                if (material.diffuseMapId != -1) {
+                    color = tex2d(S->diffuseMaps[material.diffuseMapId], S->srgbLut, texUv.x, texUv.y);
+                    mp.albedo = mk3(color.x, color.y, color.z);
+                }
+                if (dot3(gNormal, rayDirection) > 0.0f && TYPE != NX_MAT_DIELECTRIC) { normal = -normal; gNormal = -gNormal; }
+
+                const float4 q = rotation_to_z(normal);
+                const f3 wi = rotate_point(q, -rayDirection);
+                f3 wo;
+                if (rng_next(rng) > material.opacity || (material.diffuseMapId != -1 && rng_next(rng) > color.w)) {
+                    // texture / opacity pass-through: continue straight, path state untouched
+                    wo = normalize3(rotate_point(invert_rotation(q), -wi));
+                    const float od = sgnE(dot3(wo, normal));
+                    nextOrigin = offset_ray(p, gNormal * od);
+                    nextDir = wo;
+                    wantTrace = true;
+                } else {
+                    if (useMIS) wantShadow = next_event_estimation<TYPE>(S, wi, mp, p, normal, gNormal, throughput, rng, sh);
+                    float pdf;
+                    f3 sampleThroughput;
+                    if (Bsdf<TYPE>::sample(mp, wi, rng, wo, sampleThroughput, pdf)) {
+                        wo = normalize3(rotate_point(invert_rotation(q), wo));
+                        const float od = sgnE(dot3(wo, normal));
+                        nextOrigin = offset_ray(p, gNormal * od);
+                        nextDir = wo;
+                        nextThroughput = throughput * sampleThroughput;
+                        nextPdf = pdf;
+                        wantTrace = true;
+                        updatePath = true;
+                    }
+                }
+            }
+        }
+        // slot order within a thread: shadow request first, then the continuation ray (PathTracer.cu:303, 448)
+        const int shadowSlot = slots.alloc(wantShadow, &C->traceShadowSize[bounce], 1);
+        if (wantShadow) {
+            S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
+            S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
+            S->shadow.radiance[shadowSlot] = make_float4(sh.radiance.x, sh.radiance.y, sh.radiance.z, 0.0f);
+        }
+        const int traceSlot = slots.alloc(wantTrace, &C->traceSize[bounce], 0);
+        if (wantTrace) {
+            S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
+            S->trace.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
+            if (updatePath) {
+                S->rayOrigin[pixelIdx] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
+                S->throughputPdf[pixelIdx] = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
+            }
+        }
+    }
+    slots.finish(S, bounce);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// AccumulateKernel, Tonemap, LinearToGamma, ToColorUInt — PathTracer.cu:37-62, 480-496; Utils/Utils.h:51-54
+
+NXD uint32_t tonemap_rgba8(f3 c)
+{
+    const float v[3] = {c.x, c.y, c.z};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float x = v[k] * 0.6f;
+        x = clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
+        x = (float)pow((double)x, 0.45454545454);
+        x = clampf(x, 0.0f, 1.0f);
+        out |= (uint32_t)(uint8_t)(x * 255.0f) << (8 * k);
+    }
+    return out | (255u << 24);
+}
+
+// src == nullptr: accumulate this context's own radiance with the device frame number.
+__global__ void __launch_bounds__(kWideBlock) accumulate_kernel(const DeviceState* __restrict__ S, const float4* __restrict__ src, const uint32_t count,
+                                                                 const uint32_t frameOverride)
+{
+    const uint32_t frame = frameOverride ? frameOverride : S->frame->frameNumber;
+    const float4* in = src ? src : S->radiance;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float4 r = in[i];
+        float4 a;
+        if (frame == 1u) a = make_float4(r.x, r.y, r.z, 0.0f);
+        else {
+            a = S->accumulation[i];
+            const float f = (float)frame;
+            a.x += (r.x - a.x) / f;
+            a.y += (r.y - a.y) / f;
+            a.z += (r.z - a.z) / f;
+        }
+        S->accumulation[i] = a;
+        S->rgba8[i] = tonemap_rgba8(mk3(a.x, a.y, a.z));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+
+const void* logic_kernel_ptr(bool ordered) { return ordered ? (const void*)logic_kernel<true> : (const void*)logic_kernel<false>; }
+
+const void* shade_kernel_ptr(int type, bool ordered)
+{
+    switch (type) {
+    case NX_MAT_DIFFUSE: return ordered ? (const void*)shade_kernel<NX_MAT_DIFFUSE, true> : (const void*)shade_kernel<NX_MAT_DIFFUSE, false>;
+    case NX_MAT_DIELECTRIC: return ordered ? (const void*)shade_kernel<NX_MAT_DIELECTRIC, true> : (const void*)shade_kernel<NX_MAT_DIELECTRIC, false>;
+    case NX_MAT_PLASTIC: return ordered ? (const void*)shade_kernel<NX_MAT_PLASTIC, true> : (const void*)shade_kernel<NX_MAT_PLASTIC, false>;
+    default: return ordered ? (const void*)shade_kernel<NX_MAT_CONDUCTOR, true> : (const void*)shade_kernel<NX_MAT_CONDUCTOR, false>;
+    }
+}
+const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
+const void* generate_kernel_ptr() { return (const void*)generate_kernel; }
+const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }
+
+}  // namespace nxd

@@ -1,0 +1,990 @@
+// nxhip_api.hip — implementation of the C-ABI device layer declared in include/nexus_hip.h.
+// Each entry point cites, in the header, the reference interface it replaces; this file is the HIP runtime
+// plumbing behind it: allocation, uploads, the per-frame hipGraph and the kernel-level test hooks.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nx_context.h"
+
+namespace nxd {
+
+const void* trace_kernel_ptr(bool anyHit, bool stats);
+const void* logic_kernel_ptr(bool ordered);
+const void* shade_kernel_ptr(int type, bool ordered);
+const void* begin_frame_kernel_ptr();
+const void* generate_kernel_ptr();
+const void* accumulate_kernel_ptr();
+
+static thread_local std::string g_lastError;
+
+void set_error(const std::string& msg) { g_lastError = msg; }
+
+bool hip_ok(hipError_t e, const char* what, const char* file, int line)
+{
+    if (e == hipSuccess) return true;
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "HIP error %d (%s) in '%s' at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    set_error(buf);
+    return false;
+}
+
+bool DevBuf::alloc(size_t n)
+{
+    release();
+    if (n == 0) n = 16;
+    void* q = nullptr;
+    if (!hip_ok(hipMalloc(&q, n), "hipMalloc", __FILE__, __LINE__)) return false;
+    p = q;
+    bytes = n;
+    return true;
+}
+
+constexpr int kTraceBlockThreads = 256;
+constexpr int kWideBlockThreads = 256;
+constexpr int kOrderedBlockThreads = 1024;
+constexpr int kHookBounceSlot = NX_PATH_MAX_LENGTH - 1;  // queue-size slot used by the batch test hooks
+
+}  // namespace nxd
+
+using namespace nxd;
+
+#define NX_CHECK_CTX(ctx)                      \
+    do {                                       \
+        if (!(ctx)) {                          \
+            set_error("null context");         \
+            return NXHIP_ERR_INVALID;          \
+        }                                      \
+    } while (0)
+
+#define NX_ALLOC(buf, n)                                  \
+    do {                                                  \
+        if (!(buf).alloc(n)) return NXHIP_ERR_HIP;        \
+    } while (0)
+
+static int fail_invalid(const char* msg)
+{
+    set_error(msg);
+    return NXHIP_ERR_INVALID;
+}
+
+static void invalidate_graph(nxhip_ctx* c)
+{
+    if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graphExec = nullptr;
+    c->graph = nullptr;
+    c->graphValid = false;
+}
+
+static int upload_state(nxhip_ctx* c)
+{
+    if (!c->stateDirty) return NXHIP_OK;
+    NX_HIP(hipMemcpyAsync(c->dState.p, &c->h, sizeof(DeviceState), hipMemcpyHostToDevice, c->stream));
+    // the host struct may be modified right after this call returns
+    NX_HIP(hipStreamSynchronize(c->stream));
+    c->stateDirty = false;
+    return NXHIP_OK;
+}
+
+static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
+{
+    const size_t n = std::max<uint32_t>(localCount, 1u);
+    const size_t full = std::max<size_t>((size_t)c->width * c->height, n);
+    NX_ALLOC(c->throughputPdf, n * 16);
+    NX_ALLOC(c->radiance, n * 16);
+    NX_ALLOC(c->rayOrigin, n * 16);
+    NX_ALLOC(c->accumulation, full * 16);
+    NX_ALLOC(c->rgba8, full * 4);
+    NX_ALLOC(c->trRayO, n * 16);
+    NX_ALLOC(c->trRayD, n * 16);
+    NX_ALLOC(c->trHit, n * 16);
+    NX_ALLOC(c->trHitInst, n * 4);
+    NX_ALLOC(c->shRayO, n * 16);
+    NX_ALLOC(c->shRayD, n * 16);
+    NX_ALLOC(c->shRadiance, n * 16);
+    for (int m = 0; m < 4; m++) {
+        NX_ALLOC(c->mqHit[m], n * 16);
+        NX_ALLOC(c->mqDirInst[m], n * 16);
+        NX_ALLOC(c->mqPixel[m], n * 4);
+    }
+    NX_HIP(hipMemsetAsync(c->accumulation.p, 0, full * 16, c->stream));
+    NX_HIP(hipMemsetAsync(c->rgba8.p, 0, full * 4, c->stream));
+    NX_HIP(hipMemsetAsync(c->radiance.p, 0, n * 16, c->stream));
+    c->localCount = localCount;
+    DeviceState& h = c->h;
+    h.localCount = localCount;
+    h.throughputPdf = c->throughputPdf.as<float4>();
+    h.radiance = c->radiance.as<float4>();
+    h.rayOrigin = c->rayOrigin.as<float4>();
+    h.accumulation = c->accumulation.as<float4>();
+    h.rgba8 = c->rgba8.as<uint32_t>();
+    h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
+    h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
+    for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
+    c->stateDirty = true;
+    invalidate_graph(c);
+    return NXHIP_OK;
+}
+
+static int set_frame_number_device(nxhip_ctx* c, uint32_t f)
+{
+    c->frameNumber = f;
+    NX_HIP(hipMemcpyAsync(&c->frame.as<FrameState>()->frameNumber, &c->frameNumber, 4, hipMemcpyHostToDevice, c->stream));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    return NXHIP_OK;
+}
+
+extern "C" {
+
+const char* nxhip_last_error(void) { return g_lastError.c_str(); }
+
+int nxhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nxhip_has_gfx950_code(void)
+{
+#ifdef NX_BUILT_FOR_GFX950
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhip_ctx** out)
+{
+    if (!out) return fail_invalid("nxhip_create: out is null");
+    *out = nullptr;
+    if (width == 0 || height == 0) return fail_invalid("nxhip_create: zero-sized viewport");
+    if (nxhip_device_count() <= device || device < 0) {
+        set_error("nxhip_create: no such HIP device");
+        return NXHIP_ERR_NO_DEVICE;
+    }
+    NX_HIP(hipSetDevice(device));
+    nxhip_ctx* c = new (std::nothrow) nxhip_ctx();
+    if (!c) return fail_invalid("nxhip_create: out of host memory");
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    int rc = NXHIP_OK;
+    do {
+        if (stream) c->stream = (hipStream_t)stream;
+        else {
+            if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate", __FILE__, __LINE__)) { rc = NXHIP_ERR_HIP; break; }
+            c->ownsStream = true;
+        }
+        hipDeviceProp_t prop;
+        if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties", __FILE__, __LINE__)) { rc = NXHIP_ERR_HIP; break; }
+        c->numCUs = prop.multiProcessorCount;
+
+        if (!c->dState.alloc(sizeof(DeviceState)) || !c->counters.alloc(sizeof(Counters)) || !c->frame.alloc(sizeof(FrameState)) ||
+            !c->traceStats.alloc(2 * sizeof(TraceStatsDev)) || !c->srgbLut.alloc(256 * sizeof(float))) { rc = NXHIP_ERR_HIP; break; }
+        (void)hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream);
+        (void)hipMemsetAsync(c->traceStats.p, 0, 2 * sizeof(TraceStatsDev), c->stream);
+        FrameState fs{0u, -1, -1, 0u};
+        (void)hipMemcpyAsync(c->frame.p, &fs, sizeof fs, hipMemcpyHostToDevice, c->stream);
+        float lut[256];
+        for (int i = 0; i < 256; i++) {
+            const float x = (float)i / 255.0f;
+            lut[i] = x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
+        }
+        (void)hipMemcpyAsync(c->srgbLut.p, lut, sizeof lut, hipMemcpyHostToDevice, c->stream);
+        if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize", __FILE__, __LINE__)) { rc = NXHIP_ERR_HIP; break; }
+
+        DeviceState& h = c->h;
+        std::memset(&h, 0, sizeof h);
+        h.counters = c->counters.as<Counters>();
+        h.frame = c->frame.as<FrameState>();
+        h.traceStats = c->traceStats.as<TraceStatsDev>();
+        h.srgbLut = c->srgbLut.as<float>();
+        h.settings.useMIS = 1;  // Renderer/RenderSettings.h:4-10 defaults
+        h.settings.pathLength = 10;
+        h.settings.backgroundColor[0] = h.settings.backgroundColor[1] = h.settings.backgroundColor[2] = 1.0f;
+        h.settings.backgroundIntensity = 0.0f;
+        h.camera.resolution[0] = width;
+        h.camera.resolution[1] = height;
+        h.rngMode = NX_RNG_REFERENCE_SLOT;
+        h.compactMode = NX_COMPACT_FAST;
+        h.conductorMode = NX_CONDUCTOR_REFERENCE;
+        rc = alloc_paths(c, width * height);
+        if (rc != NXHIP_OK) break;
+
+        // persistent launch geometry from the occupancy the kernels actually get
+        int perCU = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel_ptr(false, false), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
+        c->traceBlocks = std::max(1, perCU) * c->numCUs;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel_ptr(true, false), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
+        c->shadowBlocks = std::max(1, perCU) * c->numCUs;
+        c->wideBlocks = 8 * c->numCUs;
+    } while (false);
+    if (rc != NXHIP_OK) {
+        nxhip_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return NXHIP_OK;
+}
+
+void nxhip_destroy(nxhip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    invalidate_graph(c);
+    for (auto& t : c->timerPool) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int nxhip_sync(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipStreamSynchronize(c->stream));
+    return NXHIP_OK;
+}
+
+int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
+{
+    NX_CHECK_CTX(c);
+    if (width == 0 || height == 0) return fail_invalid("nxhip_resize: zero-sized viewport");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    c->width = width;
+    c->height = height;
+    c->h.camera.resolution[0] = width;
+    c->h.camera.resolution[1] = height;
+    c->pixelMap.release();
+    c->h.pixelMap = nullptr;
+    const int rc = alloc_paths(c, width * height);
+    if (rc != NXHIP_OK) return rc;
+    return set_frame_number_device(c, 0);
+}
+
+// ---- scene upload -----------------------------------------------------------------------------------
+
+static int refresh_blas_table(nxhip_ctx* c)
+{
+    std::vector<BlasDev> table(std::max<size_t>(1, c->blas.size()));
+    std::memset(table.data(), 0, table.size() * sizeof(BlasDev));
+    for (size_t i = 0; i < c->blas.size(); i++) {
+        const BlasHost& b = c->blas[i];
+        table[i].nodes = b.nodes.as<uint4>();
+        table[i].isect = b.isect.as<float4>();
+        table[i].tris = b.tris.as<nx_triangle>();
+        table[i].triIdx = b.triIdx.as<uint32_t>();
+        table[i].nodeCount = b.nodeCount;
+        table[i].triCount = b.triCount;
+    }
+    NX_HIP(hipStreamSynchronize(c->stream));  // nothing may still read the old table
+    NX_ALLOC(c->blasTable, table.size() * sizeof(BlasDev));
+    NX_HIP(hipMemcpy(c->blasTable.p, table.data(), table.size() * sizeof(BlasDev), hipMemcpyHostToDevice));
+    c->h.blas = c->blasTable.as<BlasDev>();
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+static int refresh_inst_trav(nxhip_ctx* c)
+{
+    const size_t n = c->hostInstances.size();
+    std::vector<InstTrav> trav(std::max<size_t>(1, n));
+    std::memset(trav.data(), 0, trav.size() * sizeof(InstTrav));
+    for (size_t i = 0; i < n; i++) {
+        const nx_bvh_instance& inst = c->hostInstances[i];
+        if (inst.bvhIdx >= c->blas.size()) return fail_invalid("instance refers to a BLAS id that has not been uploaded");
+        const float* m = inst.invTransform.cell;
+        trav[i].r0 = make_float4(m[0], m[1], m[2], m[3]);
+        trav[i].r1 = make_float4(m[4], m[5], m[6], m[7]);
+        trav[i].r2 = make_float4(m[8], m[9], m[10], m[11]);
+        trav[i].nodes = c->blas[inst.bvhIdx].nodes.as<uint4>();
+        trav[i].isect = c->blas[inst.bvhIdx].isect.as<float4>();
+    }
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_ALLOC(c->instTrav, trav.size() * sizeof(InstTrav));
+    NX_HIP(hipMemcpy(c->instTrav.p, trav.data(), trav.size() * sizeof(InstTrav), hipMemcpyHostToDevice));
+    c->h.instTrav = c->instTrav.as<InstTrav>();
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_upload_blas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, const nx_triangle* tris, uint32_t triCount,
+                      const uint32_t* triIdx, int32_t* blasId)
+{
+    NX_CHECK_CTX(c);
+    if (!nodes || !tris || !triIdx || nodeCount == 0 || triCount == 0) return fail_invalid("nxhip_upload_blas: empty input");
+    NX_HIP(hipSetDevice(c->device));
+    // validate what the kernels assume before anything reaches the GPU: indices in range
+    for (uint32_t i = 0; i < triCount; i++)
+        if (triIdx[i] >= triCount) return fail_invalid("nxhip_upload_blas: triangle index out of range");
+    for (uint32_t i = 0; i < nodeCount; i++) {
+        const nx_bvh8_node& n = nodes[i];
+        int inner = 0, prims = 0;
+        for (int s = 0; s < 8; s++) {
+            if (n.imask & (1u << s)) inner++;
+            else if (n.meta[s]) {
+                const int cnt = __builtin_popcount(n.meta[s] >> 5);
+                prims = std::max(prims, (n.meta[s] & 0x1f) + cnt);
+            }
+        }
+        if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_upload_blas: child index out of range");
+        if (prims && (uint64_t)n.triangleBaseIdx + prims > triCount) return fail_invalid("nxhip_upload_blas: leaf range out of range");
+    }
+    BlasHost b;
+    b.nodeCount = nodeCount;
+    b.triCount = triCount;
+    // leaf-ordered intersection stream: {p0 | original index}, {edge0}, {edge1}; the edges are the same float
+    // subtractions the reference performs per test (Triangle.cuh:55-56), done once here
+    std::vector<float4> isect((size_t)triCount * 3);
+    for (uint32_t k = 0; k < triCount; k++) {
+        const uint32_t t = triIdx[k];
+        const nx_triangle& tr = tris[t];
+        float idBits;
+        std::memcpy(&idBits, &t, 4);
+        isect[3 * (size_t)k + 0] = make_float4(tr.pos0[0], tr.pos0[1], tr.pos0[2], idBits);
+        isect[3 * (size_t)k + 1] = make_float4(tr.pos1[0] - tr.pos0[0], tr.pos1[1] - tr.pos0[1], tr.pos1[2] - tr.pos0[2], 0.0f);
+        isect[3 * (size_t)k + 2] = make_float4(tr.pos2[0] - tr.pos0[0], tr.pos2[1] - tr.pos0[1], tr.pos2[2] - tr.pos0[2], 0.0f);
+    }
+    NX_ALLOC(b.nodes, (size_t)nodeCount * sizeof(nx_bvh8_node));
+    NX_ALLOC(b.isect, isect.size() * sizeof(float4));
+    NX_ALLOC(b.tris, (size_t)triCount * sizeof(nx_triangle));
+    NX_ALLOC(b.triIdx, (size_t)triCount * 4);
+    NX_HIP(hipMemcpy(b.nodes.p, nodes, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(b.isect.p, isect.data(), isect.size() * sizeof(float4), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(b.tris.p, tris, (size_t)triCount * sizeof(nx_triangle), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(b.triIdx.p, triIdx, (size_t)triCount * 4, hipMemcpyHostToDevice));
+    c->blas.push_back(std::move(b));
+    if (blasId) *blasId = (int32_t)c->blas.size() - 1;
+    return refresh_blas_table(c);
+}
+
+int nxhip_clear_blas(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    c->blas.clear();
+    c->hostInstances.clear();
+    c->h.tlasNodes = nullptr;
+    c->h.instanceCount = 0;
+    return refresh_blas_table(c);
+}
+
+int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, const uint32_t* instanceIdx, const nx_bvh_instance* instances,
+                   uint32_t instanceCount)
+{
+    NX_CHECK_CTX(c);
+    if (!nodes || !instanceIdx || !instances || nodeCount == 0 || instanceCount == 0) return fail_invalid("nxhip_set_tlas: empty input");
+    NX_HIP(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < instanceCount; i++) {
+        if (instanceIdx[i] >= instanceCount) return fail_invalid("nxhip_set_tlas: instance index out of range");
+        if (instances[i].bvhIdx >= c->blas.size()) return fail_invalid("nxhip_set_tlas: instance refers to a BLAS id that has not been uploaded");
+    }
+    for (uint32_t i = 0; i < nodeCount; i++) {
+        const nx_bvh8_node& n = nodes[i];
+        int inner = 0, prims = 0;
+        for (int s = 0; s < 8; s++) {
+            if (n.imask & (1u << s)) inner++;
+            else if (n.meta[s]) prims = std::max(prims, (n.meta[s] & 0x1f) + __builtin_popcount(n.meta[s] >> 5));
+        }
+        if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_set_tlas: child index out of range");
+        if (prims && (uint64_t)n.triangleBaseIdx + prims > instanceCount) return fail_invalid("nxhip_set_tlas: leaf range out of range");
+    }
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_ALLOC(c->tlasNodes, (size_t)nodeCount * sizeof(nx_bvh8_node));
+    NX_ALLOC(c->tlasInstIdx, (size_t)instanceCount * 4);
+    NX_ALLOC(c->instances, (size_t)instanceCount * sizeof(nx_bvh_instance));
+    NX_HIP(hipMemcpy(c->tlasNodes.p, nodes, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->tlasInstIdx.p, instanceIdx, (size_t)instanceCount * 4, hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->instances.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
+    c->hostInstances.assign(instances, instances + instanceCount);
+    c->h.tlasNodes = c->tlasNodes.as<uint4>();
+    c->h.tlasInstIdx = c->tlasInstIdx.as<uint32_t>();
+    c->h.instances = c->instances.as<nx_bvh_instance>();
+    c->h.instanceCount = instanceCount;
+    c->stateDirty = true;
+    return refresh_inst_trav(c);
+}
+
+int nxhip_set_materials(nxhip_ctx* c, const nx_material* materials, uint32_t count)
+{
+    NX_CHECK_CTX(c);
+    if (!materials || count == 0) return fail_invalid("nxhip_set_materials: empty input");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_ALLOC(c->materials, (size_t)count * sizeof(nx_material));
+    NX_HIP(hipMemcpy(c->materials.p, materials, (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
+    c->h.materials = c->materials.as<nx_material>();
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_set_lights(nxhip_ctx* c, const nx_light* lights, uint32_t count)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_ALLOC(c->lights, std::max<size_t>(1, count) * sizeof(nx_light));
+    if (count) NX_HIP(hipMemcpy(c->lights.p, lights, (size_t)count * sizeof(nx_light), hipMemcpyHostToDevice));
+    c->h.lights = c->lights.as<nx_light>();
+    c->h.lightCount = count;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+static int refresh_texture_tables(nxhip_ctx* c)
+{
+    auto build = [&](std::vector<TextureHost>& v, DevBuf& table, const TextureDev*& dst) -> int {
+        std::vector<TextureDev> t(std::max<size_t>(1, v.size()));
+        std::memset(t.data(), 0, t.size() * sizeof(TextureDev));
+        for (size_t i = 0; i < v.size(); i++) t[i] = TextureDev{v[i].texels.as<uint32_t>(), v[i].width, v[i].height};
+        NX_ALLOC(table, t.size() * sizeof(TextureDev));
+        NX_HIP(hipMemcpy(table.p, t.data(), t.size() * sizeof(TextureDev), hipMemcpyHostToDevice));
+        dst = table.as<TextureDev>();
+        return NXHIP_OK;
+    };
+    NX_HIP(hipStreamSynchronize(c->stream));
+    int rc = build(c->diffuseMaps, c->diffuseTable, c->h.diffuseMaps);
+    if (rc != NXHIP_OK) return rc;
+    rc = build(c->emissiveMaps, c->emissiveTable, c->h.emissiveMaps);
+    if (rc != NXHIP_OK) return rc;
+    c->h.hdrMap = TextureDev{c->hdrMap.texels.as<uint32_t>(), c->hdrMap.width, c->hdrMap.height};
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_upload_texture(nxhip_ctx* c, int kind, const uint8_t* rgba8, uint32_t width, uint32_t height, int32_t* texId)
+{
+    NX_CHECK_CTX(c);
+    if (!rgba8 || width == 0 || height == 0 || kind < 0 || kind > 2) return fail_invalid("nxhip_upload_texture: bad arguments");
+    NX_HIP(hipSetDevice(c->device));
+    TextureHost t;
+    t.width = width;
+    t.height = height;
+    NX_ALLOC(t.texels, (size_t)width * height * 4);
+    NX_HIP(hipMemcpy(t.texels.p, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice));
+    int32_t id = 0;
+    if (kind == 0) { c->diffuseMaps.push_back(std::move(t)); id = (int32_t)c->diffuseMaps.size() - 1; }
+    else if (kind == 1) { c->emissiveMaps.push_back(std::move(t)); id = (int32_t)c->emissiveMaps.size() - 1; }
+    else { NX_HIP(hipStreamSynchronize(c->stream)); c->hdrMap = std::move(t); }
+    if (texId) *texId = id;
+    return refresh_texture_tables(c);
+}
+
+int nxhip_clear_textures(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    c->diffuseMaps.clear();
+    c->emissiveMaps.clear();
+    c->hdrMap = TextureHost();
+    return refresh_texture_tables(c);
+}
+
+int nxhip_set_camera(nxhip_ctx* c, const nx_camera* camera)
+{
+    NX_CHECK_CTX(c);
+    if (!camera) return fail_invalid("nxhip_set_camera: null camera");
+    if (camera->resolution[0] != c->width || camera->resolution[1] != c->height)
+        return fail_invalid("nxhip_set_camera: camera resolution differs from the context viewport (call nxhip_resize first)");
+    c->h.camera = *camera;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_set_render_settings(nxhip_ctx* c, const nx_render_settings* s)
+{
+    NX_CHECK_CTX(c);
+    if (!s) return fail_invalid("nxhip_set_render_settings: null settings");
+    if (s->pathLength < 1 || s->pathLength > NX_PATH_MAX_LENGTH - 2) return fail_invalid("nxhip_set_render_settings: pathLength must be in [1, 98]");
+    if (s->pathLength != c->h.settings.pathLength) invalidate_graph(c);
+    c->h.settings = *s;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_set_modes(nxhip_ctx* c, int rngMode, int compactMode, int conductorMode)
+{
+    NX_CHECK_CTX(c);
+    if (rngMode < 0 || rngMode > 1 || compactMode < 0 || compactMode > 1 || conductorMode < 0 || conductorMode > 1)
+        return fail_invalid("nxhip_set_modes: unknown mode");
+    if (compactMode != c->h.compactMode || conductorMode != c->h.conductorMode) invalidate_graph(c);
+    c->h.rngMode = rngMode;
+    c->h.compactMode = compactMode;
+    c->h.conductorMode = conductorMode;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_set_pixel_map(nxhip_ctx* c, const uint32_t* pixelMap, uint32_t localCount)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t full = c->width * c->height;
+    if (!pixelMap) {
+        c->pixelMap.release();
+        c->h.pixelMap = nullptr;
+        const int rc = alloc_paths(c, full);
+        if (rc != NXHIP_OK) return rc;
+        return set_frame_number_device(c, 0);
+    }
+    if (localCount == 0 || localCount > full) return fail_invalid("nxhip_set_pixel_map: localCount out of range");
+    for (uint32_t i = 0; i < localCount; i++)
+        if (pixelMap[i] >= full) return fail_invalid("nxhip_set_pixel_map: pixel index out of range");
+    NX_ALLOC(c->pixelMap, (size_t)localCount * 4);
+    NX_HIP(hipMemcpy(c->pixelMap.p, pixelMap, (size_t)localCount * 4, hipMemcpyHostToDevice));
+    c->h.pixelMap = c->pixelMap.as<uint32_t>();
+    const int rc = alloc_paths(c, localCount);
+    if (rc != NXHIP_OK) return rc;
+    return set_frame_number_device(c, 0);
+}
+
+// ---- rendering --------------------------------------------------------------------------------------
+
+int nxhip_reset_frame_number(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    return set_frame_number_device(c, 0);
+}
+
+int nxhip_set_frame_number(nxhip_ctx* c, uint32_t f)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    return set_frame_number_device(c, f);
+}
+
+uint32_t nxhip_frame_number(nxhip_ctx* c) { return c ? c->frameNumber : 0u; }
+
+static int check_scene_ready(nxhip_ctx* c)
+{
+    if (!c->h.tlasNodes || c->h.instanceCount == 0) return fail_invalid("no TLAS has been set");
+    if (!c->h.materials) return fail_invalid("no materials have been set");
+    return NXHIP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Launch {
+    const void* fn;
+    dim3 grid, block;
+    int klass;
+    // argument storage (pointers into this struct are handed to HIP)
+    const DeviceState* s;
+    int bounce;
+    const float4* src;
+    uint32_t count, frameOverride;
+    int nargs;  // 1: (S), 2: (S, bounce), 4: accumulate
+};
+
+Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceState* s, int bounce = -1)
+{
+    Launch l{};
+    l.fn = fn;
+    l.grid = dim3((unsigned)grid);
+    l.block = dim3((unsigned)block);
+    l.klass = klass;
+    l.s = s;
+    l.bounce = bounce;
+    l.nargs = bounce >= 0 ? 2 : 1;
+    return l;
+}
+
+// The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
+// starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
+std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
+{
+    const DeviceState* S = c->dState.as<DeviceState>();
+    const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
+    const bool stats = c->statsEnabled;
+    const int wide = c->wideBlocks;
+    const int wideThreads = kWideBlockThreads;
+    std::vector<std::vector<Launch>> levels;
+    levels.push_back({make_launch(begin_frame_kernel_ptr(), 1, kWideBlockThreads, NXHIP_K_GENERATE, S)});
+    levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
+    levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
+    const int pathLength = c->h.settings.pathLength;
+    const int og = ordered ? 1 : wide, ob = ordered ? kOrderedBlockThreads : wideThreads;
+    for (int bounce = 1; bounce <= pathLength; bounce++) {
+        levels.push_back({make_launch(logic_kernel_ptr(ordered), og, ob, NXHIP_K_LOGIC, S, bounce)});
+        // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
+        std::vector<Launch> shade;
+        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_PLASTIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIELECTRIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_CONDUCTOR, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (ordered) for (auto& l : shade) levels.push_back({l});  // serial slot order needs the kernels one after the other
+        else levels.push_back(shade);
+        levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce),
+                          make_launch(trace_kernel_ptr(true, stats), c->shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
+    }
+    return levels;
+}
+
+void fill_args(Launch& l, void** args)
+{
+    args[0] = (void*)&l.s;
+    if (l.nargs == 2) args[1] = (void*)&l.bounce;
+    if (l.nargs == 4) { args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.frameOverride; }
+}
+
+int launch_now(nxhip_ctx* c, Launch& l)
+{
+    void* args[4];
+    fill_args(l, args);
+    KernelTimer* t = nullptr;
+    if (c->timingEnabled) {
+        c->timerPool.emplace_back();
+        t = &c->timerPool.back();
+        NX_HIP(hipEventCreate(&t->start));
+        NX_HIP(hipEventCreate(&t->stop));
+        NX_HIP(hipEventRecord(t->start, c->stream));
+    }
+    NX_HIP(hipLaunchKernel(l.fn, l.grid, l.block, args, 0, c->stream));
+    if (t) {
+        NX_HIP(hipEventRecord(t->stop, c->stream));
+        c->times.launches[l.klass]++;  // elapsed times are resolved in nxhip_read_kernel_times
+    }
+    return NXHIP_OK;
+}
+
+}  // namespace
+
+static int build_graph(nxhip_ctx* c)
+{
+    invalidate_graph(c);
+    NX_HIP(hipGraphCreate(&c->graph, 0));
+    auto levels = frame_levels(c);
+    std::vector<hipGraphNode_t> prev;
+    for (auto& level : levels) {
+        std::vector<hipGraphNode_t> cur;
+        for (auto& l : level) {
+            void* args[4];
+            fill_args(l, args);
+            hipKernelNodeParams p;
+            std::memset(&p, 0, sizeof p);
+            p.func = const_cast<void*>(l.fn);
+            p.gridDim = l.grid;
+            p.blockDim = l.block;
+            p.sharedMemBytes = 0;
+            p.kernelParams = args;
+            p.extra = nullptr;
+            hipGraphNode_t node;
+            NX_HIP(hipGraphAddKernelNode(&node, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
+            cur.push_back(node);
+        }
+        prev.swap(cur);
+    }
+    NX_HIP(hipGraphInstantiate(&c->graphExec, c->graph, nullptr, nullptr, 0));
+    c->graphValid = true;
+    return NXHIP_OK;
+}
+
+extern "C" {
+
+int nxhip_render_frame(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    int rc = check_scene_ready(c);
+    if (rc != NXHIP_OK) return rc;
+    rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    if (c->timingEnabled) {
+        // eager path: one event pair per launch, launches strictly in level order on one stream
+        auto levels = frame_levels(c);
+        for (auto& level : levels)
+            for (auto& l : level) {
+                const size_t before = c->timerPool.size();
+                rc = launch_now(c, l);
+                if (rc != NXHIP_OK) return rc;
+                if (c->timerPool.size() > before) c->timerClass.push_back(l.klass);
+            }
+    } else {
+        if (!c->graphValid) {
+            rc = build_graph(c);
+            if (rc != NXHIP_OK) return rc;
+        }
+        NX_HIP(hipGraphLaunch(c->graphExec, c->stream));
+    }
+    c->frameNumber++;
+    return NXHIP_OK;
+}
+
+static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t frameOverride)
+{
+    Launch l = make_launch(accumulate_kernel_ptr(), c->wideBlocks, kWideBlockThreads, NXHIP_K_ACCUMULATE, c->dState.as<DeviceState>());
+    l.nargs = 4;
+    l.src = src;
+    l.count = count;
+    l.frameOverride = frameOverride;
+    const size_t before = c->timerPool.size();
+    const int rc = launch_now(c, l);
+    if (rc == NXHIP_OK && c->timerPool.size() > before) c->timerClass.push_back(l.klass);
+    return rc;
+}
+
+int nxhip_accumulate(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    const int rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    return launch_accumulate(c, nullptr, c->localCount, 0u);
+}
+
+int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uint32_t frameNumber)
+{
+    NX_CHECK_CTX(c);
+    if (!src || count == 0 || count > c->width * c->height || frameNumber == 0) return fail_invalid("nxhip_accumulate_external: bad arguments");
+    NX_HIP(hipSetDevice(c->device));
+    const int rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    return launch_accumulate(c, static_cast<const float4*>(src), count, frameNumber);
+}
+
+int nxhip_render(nxhip_ctx* c, uint32_t frames)
+{
+    for (uint32_t f = 0; f < frames; f++) {
+        int rc = nxhip_render_frame(c);
+        if (rc != NXHIP_OK) return rc;
+        rc = nxhip_accumulate(c);
+        if (rc != NXHIP_OK) return rc;
+    }
+    return NXHIP_OK;
+}
+
+static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, float* dst)
+{
+    if (!dst) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float4> tmp(count);
+    NX_HIP(hipMemcpy(tmp.data(), dev, (size_t)count * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < count; i++) {
+        dst[3 * (size_t)i + 0] = tmp[i].x;
+        dst[3 * (size_t)i + 1] = tmp[i].y;
+        dst[3 * (size_t)i + 2] = tmp[i].z;
+    }
+    return NXHIP_OK;
+}
+
+int nxhip_read_radiance(nxhip_ctx* c, float* dst)
+{
+    NX_CHECK_CTX(c);
+    return read_float4_as_float3(c, c->radiance.p, c->localCount, dst);
+}
+
+int nxhip_read_accumulation(nxhip_ctx* c, float* dst)
+{
+    NX_CHECK_CTX(c);
+    return read_float4_as_float3(c, c->accumulation.p, c->localCount, dst);
+}
+
+int nxhip_read_rgba8(nxhip_ctx* c, uint32_t* dst)
+{
+    NX_CHECK_CTX(c);
+    if (!dst) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_HIP(hipMemcpy(dst, c->rgba8.p, (size_t)c->localCount * 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+void* nxhip_radiance_device_ptr(nxhip_ctx* c) { return c ? c->radiance.p : nullptr; }
+void* nxhip_accumulation_device_ptr(nxhip_ctx* c) { return c ? c->accumulation.p : nullptr; }
+
+int nxhip_read_queue_sizes(nxhip_ctx* c, nxhip_queue_sizes* out)
+{
+    NX_CHECK_CTX(c);
+    if (!out) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    Counters h;
+    NX_HIP(hipMemcpy(&h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    std::memcpy(out->traceSize, h.traceSize, sizeof h.traceSize);
+    std::memcpy(out->traceShadowSize, h.traceShadowSize, sizeof h.traceShadowSize);
+    std::memcpy(out->diffuseSize, h.materialSize[NX_MAT_DIFFUSE], sizeof h.traceSize);
+    std::memcpy(out->plasticSize, h.materialSize[NX_MAT_PLASTIC], sizeof h.traceSize);
+    std::memcpy(out->dielectricSize, h.materialSize[NX_MAT_DIELECTRIC], sizeof h.traceSize);
+    std::memcpy(out->conductorSize, h.materialSize[NX_MAT_CONDUCTOR], sizeof h.traceSize);
+    return NXHIP_OK;
+}
+
+int nxhip_set_pixel_query(nxhip_ctx* c, uint32_t x, uint32_t y)
+{
+    NX_CHECK_CTX(c);
+    if (x >= c->width || y >= c->height) return fail_invalid("nxhip_set_pixel_query: pixel outside the viewport");
+    NX_HIP(hipSetDevice(c->device));
+    const int32_t q[2] = {(int32_t)(c->width * y + x), -1};
+    NX_HIP(hipMemcpyAsync(&c->frame.as<FrameState>()->pixelQueryPixel, q, 8, hipMemcpyHostToDevice, c->stream));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    return NXHIP_OK;
+}
+
+int nxhip_get_selected_instance(nxhip_ctx* c, int32_t* instanceIdx)
+{
+    NX_CHECK_CTX(c);
+    if (!instanceIdx) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_HIP(hipMemcpy(instanceIdx, &c->frame.as<FrameState>()->pixelQueryInstance, 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+// ---- kernel-level hooks -----------------------------------------------------------------------------
+
+static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
+{
+    // queue size + zeroed fetch heads for the reserved bounce slot
+    Counters* dc = c->counters.as<Counters>();
+    const int32_t size = (int32_t)n;
+    int32_t* sizeWord = anyHit ? &dc->traceShadowSize[kHookBounceSlot] : &dc->traceSize[kHookBounceSlot];
+    int32_t* heads = anyHit ? dc->shadowHead[kHookBounceSlot] : dc->traceHead[kHookBounceSlot];
+    NX_HIP(hipMemcpyAsync(sizeWord, &size, 4, hipMemcpyHostToDevice, c->stream));
+    NX_HIP(hipMemsetAsync(heads, 0, kXcds * 4, c->stream));
+    Launch l = make_launch(trace_kernel_ptr(anyHit, c->statsEnabled), anyHit ? c->shadowBlocks : c->traceBlocks, kTraceBlockThreads,
+                           anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot);
+    const size_t before = c->timerPool.size();
+    const int rc = launch_now(c, l);
+    if (rc == NXHIP_OK && c->timerPool.size() > before) c->timerClass.push_back(l.klass);
+    return rc;
+}
+
+int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* hits)
+{
+    NX_CHECK_CTX(c);
+    if (!rays || !hits) return fail_invalid("nxhip_trace_batch: null buffer");
+    NX_HIP(hipSetDevice(c->device));
+    if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
+    int rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    const uint32_t cap = c->localCount;
+    std::vector<float4> o(std::min(cap, count)), d(std::min(cap, count)), h(std::min(cap, count));
+    std::vector<uint32_t> hi(std::min(cap, count));
+    for (uint32_t first = 0; first < count; first += cap) {
+        const uint32_t n = std::min(cap, count - first);
+        for (uint32_t i = 0; i < n; i++) {
+            const nx_ray& r = rays[first + i];
+            float idx;
+            std::memcpy(&idx, &i, 4);
+            o[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], 0.0f);
+            d[i] = make_float4(r.direction[0], r.direction[1], r.direction[2], idx);
+        }
+        NX_HIP(hipMemcpyAsync(c->trRayO.p, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        NX_HIP(hipMemcpyAsync(c->trRayD.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        rc = run_trace_chunk(c, false, n);
+        if (rc != NXHIP_OK) return rc;
+        NX_HIP(hipMemcpyAsync(h.data(), c->trHit.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        NX_HIP(hipMemcpyAsync(hi.data(), c->trHitInst.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        NX_HIP(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < n; i++) {
+            nx_hit& out = hits[first + i];
+            out.hitDistance = h[i].x;
+            out.u = h[i].y;
+            out.v = h[i].z;
+            std::memcpy(&out.triIdx, &h[i].w, 4);
+            out.instanceIdx = hi[i];
+        }
+    }
+    return NXHIP_OK;
+}
+
+int nxhip_trace_shadow_batch(nxhip_ctx* c, const nx_ray* rays, const float* tmax, uint32_t count, uint8_t* occluded)
+{
+    NX_CHECK_CTX(c);
+    if (!rays || !tmax || !occluded) return fail_invalid("nxhip_trace_shadow_batch: null buffer");
+    NX_HIP(hipSetDevice(c->device));
+    if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
+    int rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    const uint32_t cap = c->localCount;
+    const uint32_t m = std::min(cap, count);
+    std::vector<float4> o(m), d(m), rad(m, make_float4(1.0f, 0.0f, 0.0f, 0.0f)), res(m);
+    for (uint32_t first = 0; first < count; first += cap) {
+        const uint32_t n = std::min(cap, count - first);
+        for (uint32_t i = 0; i < n; i++) {
+            const nx_ray& r = rays[first + i];
+            float idx;
+            std::memcpy(&idx, &i, 4);
+            o[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], tmax[first + i]);
+            d[i] = make_float4(r.direction[0], r.direction[1], r.direction[2], idx);
+        }
+        // the kernel's tail adds the request's radiance to the path's pixel when unoccluded: radiance 1 into a zeroed buffer
+        NX_HIP(hipMemcpyAsync(c->shRayO.p, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        NX_HIP(hipMemcpyAsync(c->shRayD.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        NX_HIP(hipMemcpyAsync(c->shRadiance.p, rad.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        NX_HIP(hipMemsetAsync(c->radiance.p, 0, (size_t)n * 16, c->stream));
+        rc = run_trace_chunk(c, true, n);
+        if (rc != NXHIP_OK) return rc;
+        NX_HIP(hipMemcpyAsync(res.data(), c->radiance.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        NX_HIP(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < n; i++) occluded[first + i] = res[i].x == 1.0f ? 0 : 1;
+    }
+    return NXHIP_OK;
+}
+
+int nxhip_enable_trace_stats(nxhip_ctx* c, int enable)
+{
+    NX_CHECK_CTX(c);
+    if ((enable != 0) != c->statsEnabled) invalidate_graph(c);
+    c->statsEnabled = enable != 0;
+    return NXHIP_OK;
+}
+
+int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace_stats* shadow, int reset)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    TraceStatsDev h[2];
+    NX_HIP(hipMemcpy(h, c->traceStats.p, sizeof h, hipMemcpyDeviceToHost));
+    if (closest) *closest = nxhip_trace_stats{h[0].rays, h[0].nodes, h[0].tris, h[0].instances};
+    if (shadow) *shadow = nxhip_trace_stats{h[1].rays, h[1].nodes, h[1].tris, h[1].instances};
+    if (reset) NX_HIP(hipMemset(c->traceStats.p, 0, sizeof h));
+    return NXHIP_OK;
+}
+
+int nxhip_enable_kernel_timing(nxhip_ctx* c, int enable)
+{
+    NX_CHECK_CTX(c);
+    c->timingEnabled = enable != 0;
+    return NXHIP_OK;
+}
+
+int nxhip_read_kernel_times(nxhip_ctx* c, nxhip_kernel_times* out, int reset)
+{
+    NX_CHECK_CTX(c);
+    if (!out) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->timerPool.size(); i++) {
+        float ms = 0.0f;
+        NX_HIP(hipEventElapsedTime(&ms, c->timerPool[i].start, c->timerPool[i].stop));
+        c->times.ms[c->timerClass[i]] += ms;
+        (void)hipEventDestroy(c->timerPool[i].start);
+        (void)hipEventDestroy(c->timerPool[i].stop);
+    }
+    c->timerPool.clear();
+    c->timerClass.clear();
+    *out = c->times;
+    if (reset) std::memset(&c->times, 0, sizeof c->times);
+    return NXHIP_OK;
+}
+
+}  // extern "C"
