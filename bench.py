@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the wavefront path tracer on BASELINE.json's configs[1]
+(1 048 576-triangle BVH8 mesh, 1920x1080, pathLength 8, diffuse + conductor), 1..8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one frame = one primary sample per pixel through the whole hot path (generate, trace, then pathLength x
+(logic, shade x4 + NEE, trace || shadow trace), accumulate), replayed as one hipGraph per frame.  Msamples/s is the
+reference viewer's "Megarays/sec": width * height * frames / seconds / 1e6
+(/root/reference/Nexus/src/Renderer/Panels/MetricsPanel.cpp:28,35,56).  Scene and BVH live in HBM before the timed
+region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every rank renders its tiles with the scene
+replicated, and the radiance tiles are gathered to rank 0 with ONE RCCL gather per frame, where they are
+de-interleaved, accumulated and tonemapped.  Total work per step is fixed (one 1080p frame): strong scaling.
+
+Rank 0 prints ONE JSON line.  It also carries
+  roofline     : the trace kernel (closest hit) — algorithmic bytes per launch (SURVEY.md section 8d:
+                 44 B/ray + 80 B/node visit + 40 B/triangle test + 104 B/instance entry, visits counted by the
+                 kernel's own counting variant on the same frames) / average launch duration from hipEvents around
+                 every launch of that kernel (second pass over the same K frames, launched kernel by kernel on the
+                 context's stream), against 8 TB/s HBM peak.
+  cpu_baseline : the CPU oracle (port of the reference algorithm) on one full frame of the same scene, timed on the
+                 host cores of this box.  A reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from nexus_amd import capi, pod, scenegen  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+TILE_ROWS = 5          # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
+
+
+def build_config2(width, height, nu, nv, path_length):
+    """configs[1]: seeded displaced torus (2*nu*nv triangles) resting on a 2-triangle floor under a 2-triangle emissive
+    quad; mesh = CONDUCTOR (ior (0.2,0.9,1.1), k (3.9,2.4,2.2), roughness 0.3), floor = DIFFUSE 0.7, light intensity 20."""
+    t0 = time.time()
+    torus = scenegen.displaced_torus(nu, nv, seed=1, major=1.0, minor=0.45, amp=0.06, center=(0.0, 0.56, 0.0))
+    floor = scenegen.quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+    light = scenegen.quad((-1.2, 4.0, -1.2), (1.2, 4.0, -1.2), (1.2, 4.0, 1.2), (-1.2, 4.0, 1.2))
+    t_gen = time.time() - t0
+    mats = np.array([
+        pod.make_material(pod.MAT_CONDUCTOR, roughness=0.3, conductor_ior=(0.2, 0.9, 1.1), conductor_k=(3.9, 2.4, 2.2)),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.7, 0.7, 0.7)),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 1.0, 1.0), intensity=20.0),
+    ], dtype=pod.MAT_DT)
+    t0 = time.time()
+    blas = []
+    for mesh in (torus, floor, light):
+        nodes, idx = capi.bvh8_build(mesh, threads=0)
+        blas.append((nodes, mesh, idx))
+    t_build = time.time() - t0
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    insts = np.array([capi.instance_init(i, i, ident, blas[i][0][0]) for i in range(3)], dtype=pod.INST_DT)
+    tlas_nodes, tlas_idx = capi.tlas_build(insts)
+    light_rec = np.zeros(1, dtype=pod.LIGHT_DT)
+    light_rec["meshId"] = 2
+    light_rec["type"] = pod.LIGHT_MESH
+    eye = np.array([0.0, 3.0, 3.9])
+    fwd = np.array([0.0, 0.45, 0.0]) - eye
+    fwd /= np.linalg.norm(fwd)
+    cam = capi.camera_init(eye, fwd, 52.0, width, height, 5.0, 0.0)
+    settings = np.zeros((), dtype=pod.SETTINGS_DT)
+    settings["useMIS"] = 1
+    settings["pathLength"] = path_length
+    settings["backgroundColor"] = (1, 1, 1)
+    settings["backgroundIntensity"] = 0.0
+    return dict(blas=blas, instances=insts, tlas_nodes=tlas_nodes, tlas_idx=tlas_idx, materials=mats, lights=light_rec, camera=cam,
+                settings=settings, triangles=int(len(torus) + 4), bvh8_nodes=int(len(blas[0][0])), t_gen=t_gen, t_build=t_build)
+
+
+def upload(ctx, sc):
+    for nodes, tris, idx in sc["blas"]:
+        ctx.upload_blas(nodes, tris, idx)
+    ctx.set_tlas(sc["tlas_nodes"], sc["tlas_idx"], sc["instances"])
+    ctx.set_materials(sc["materials"])
+    ctx.set_lights(sc["lights"])
+    ctx.set_camera(sc["camera"])
+    ctx.set_render_settings(sc["settings"])
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+
+
+def tile_pixel_map(width, height, rank, world):
+    rows = [r for r in range(height) if (r // TILE_ROWS) % world == rank]
+    return np.concatenate([np.arange(r * width, (r + 1) * width, dtype=np.uint32) for r in rows])
+
+
+def trace_algorithmic_bytes(st):
+    """SURVEY.md section 8d, closest-hit kernel: 44 B per ray (24 in + 20 out), 80 B per node visited, 40 B per triangle
+    tested (4 index + 36 positions), 104 B per instance entered."""
+    return 44 * st["rays"] + 80 * st["nodes"] + 40 * st["tris"] + 104 * st["instances"]
+
+
+def cpu_baseline(sc, width, height, threads):
+    from tests import oracle_lib as O  # test infrastructure, used here only as the reported CPU baseline
+
+    scene = O.OracleScene(sc["blas"], sc["instances"], sc["tlas_nodes"], sc["tlas_idx"], sc["materials"], sc["lights"], sc["camera"], sc["settings"])
+    w = O.Wavefront(scene, width * height, None, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
+    frames = 4
+    t0 = time.time()
+    for f in range(1, frames + 1):
+        w.render(f, threads=threads)
+        w.accumulate(f)
+    dt = time.time() - t0
+    return dict(value=width * height * frames / dt / 1e6, unit="Msamples/s", cores=threads, kind="port",
+                sample="%d full frames (%dx%d, same scene/camera/settings, frames 1..%d); both trace passes on %d pthreads, logic/shade serial; %.1f s"
+                       % (frames, width, height, frames, threads, dt)), w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--path-length", type=int, default=8)
+    ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
+    ap.add_argument("--nv", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run with N ranks")
+        args.gpus = world
+
+    W, H = args.width, args.height
+    sc = build_config2(W, H, args.nu, args.nv, args.path_length)
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx = capi.Context(W, H, device=local_rank, stream=stream)
+    else:
+        ctx = capi.Context(W, H, device=0)
+    upload(ctx, sc)
+
+    if world > 1:
+        pm = tile_pixel_map(W, H, rank, world)
+        ctx.set_pixel_map(pm)
+        n_local = len(pm)
+        rad = torch.zeros((n_local, 4), dtype=torch.float32, device="cuda")
+        ctx.bind_radiance(rad.data_ptr(), n_local)
+        if rank == 0:
+            gathered = [torch.zeros((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
+            all_maps = np.concatenate([tile_pixel_map(W, H, r, world) for r in range(world)])
+            assert len(all_maps) == W * H and len(np.unique(all_maps)) == W * H
+            maps_dev = torch.from_numpy(all_maps.astype(np.int64)).to("cuda").to(torch.int32)
+            flat = torch.zeros((world * n_local, 4), dtype=torch.float32, device="cuda")
+        frame_counter = [0]
+
+        def step():
+            ctx.render_frame()
+            frame_counter[0] += 1
+            # the one collective of the path: radiance tiles -> rank 0 over xGMI
+            dist.gather(rad, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.cat(gathered, out=flat)
+                ctx.accumulate_external(flat.data_ptr(), W * H, frame_counter[0], maps_dev.data_ptr())
+
+        def sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def step():
+            ctx.render_frame()
+            ctx.accumulate()
+
+        def sync():
+            ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    value = W * H * args.steps / elapsed / 1e6
+    out = {
+        "metric": "Msamples/sec (rays traced/sec) at 1080p, 8-bounce, 1M-tri BVH8",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
+                        % (sc["triangles"], sc["bvh8_nodes"], W, H, args.path_length),
+            "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, one RCCL gather per frame" % (world, TILE_ROWS),
+            "rng": "pixel-keyed", "compaction": "wave-aggregated atomics", "launch": "one hipGraph per frame",
+            "host_bvh_build_s": round(sc["t_build"], 2),
+        },
+    }
+
+    # ---- roofline of the dominant kernel (closest-hit trace), rank 0 / single GPU only
+    if rank == 0 and world == 1 and not args.no_roofline:
+        frames = max(1, min(args.steps, 16))
+        # (a) units: the counting variant of the same kernel over `frames` frames
+        ctx.enable_trace_stats(True)
+        ctx.read_trace_stats(reset=True)
+        for _ in range(frames):
+            ctx.render_frame()
+        closest, shadow = ctx.read_trace_stats(reset=True)
+        ctx.enable_trace_stats(False)
+        q = ctx.read_queue_sizes()
+        # (b) durations: hipEvent pair around every launch, same frames again
+        ctx.enable_kernel_timing(True)
+        ctx.read_kernel_times(reset=True)
+        for _ in range(frames):
+            ctx.render_frame()
+            ctx.accumulate()
+        kt = ctx.read_kernel_times(reset=True)
+        ctx.enable_kernel_timing(False)
+        launches = kt["trace"]["launches"]
+        avg_ms = kt["trace"]["ms"] / max(1, launches)
+        bytes_per_launch = trace_algorithmic_bytes(closest) / max(1, launches)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "trace_kernel<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+            "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
+            "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
+            "mrays_per_s": round(closest["rays"] / (kt["trace"]["ms"] * 1e-3) / 1e6, 1) if kt["trace"]["ms"] > 0 else None,
+            "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
+                       "achieved_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"])) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
+            "kernel_ms_per_frame": {k: round(v["ms"] / frames, 4) for k, v in kt.items()},
+            "live_rays_by_bounce": [int(x) for x in q["traceSize"][: args.path_length + 1]],
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # a 1-GPU box's CPU share is 16 hardware threads
+        threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        cb, _ = cpu_baseline(sc, W, H, threads)
+        cb["value"] = round(cb["value"], 4)
+        out["cpu_baseline"] = cb
+
+    if rank == 0 and args.png:
+        from nexus_amd import imageio
+
+        img = ctx.read_full_rgba8() if world > 1 else ctx.read_rgba8()
+        imageio.write_png(args.png, img, W, H)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,8 +95,18 @@ int nxhip_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);
  * float4 per local pixel (xyz = radiance, w unused).  Valid until the next resize / set_pixel_map. */
 void *nxhip_radiance_device_ptr(nxhip_ctx *ctx);
 void *nxhip_accumulation_device_ptr(nxhip_ctx *ctx);
-/* Root-side accumulate of an externally gathered full image: src = device float4[count] radiance. */
-int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t frameNumber);
+/* Make the context write its per-frame radiance into caller-owned device memory (float4[capacity], capacity >=
+ * localCount) — e.g. a torch tensor that is then handed to an RCCL gather without a copy.  NULL: back to the
+ * context's own buffer.  The binding is dropped by nxhip_resize / nxhip_set_pixel_map. */
+int nxhip_bind_radiance(nxhip_ctx *ctx, void *radianceDevice, uint32_t capacity);
+/* Root-side accumulate + tonemap of externally gathered radiance: src = device float4[count]; element i belongs to
+ * full-image pixel srcPixelMapDevice[i] (device uint32[count]; NULL: i).  Writes the context's accumulation / RGBA8
+ * buffers, which always cover width*height pixels. */
+int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t frameNumber,
+                              const void *srcPixelMapDevice);
+/* Read-back of the full width*height accumulation / RGBA8 image (after nxhip_accumulate_external). */
+int nxhip_read_full_accumulation(nxhip_ctx *ctx, float *dst);
+int nxhip_read_full_rgba8(nxhip_ctx *ctx, uint32_t *dst);
 
 /* D_QueueSize after the last rendered frame — Cuda/PathTracer/PathTracer.cuh:61-73.  Each array NX_PATH_MAX_LENGTH ints. */
 typedef struct nxhip_queue_sizes {

@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "nxhip_upload_texture", "nxhip_clear_textures", "nxhip_set_camera", "nxhip_set_render_settings", "nxhip_set_modes",
     "nxhip_set_pixel_map", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
     "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
-    "nxhip_read_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external",
+    "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
@@ -97,7 +97,10 @@ def lib():
     L.nxhip_radiance_device_ptr.restype = vp
     L.nxhip_accumulation_device_ptr.argtypes = [vp]
     L.nxhip_accumulation_device_ptr.restype = vp
-    L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32]
+    L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32, vp]
+    L.nxhip_bind_radiance.argtypes = [vp, vp, u32]
+    L.nxhip_read_full_accumulation.argtypes = [vp, vp]
+    L.nxhip_read_full_rgba8.argtypes = [vp, vp]
     L.nxhip_read_queue_sizes.argtypes = [vp, C.POINTER(QueueSizes)]
     L.nxhip_set_pixel_query.argtypes = [vp, u32, u32]
     L.nxhip_get_selected_instance.argtypes = [vp, C.POINTER(i32)]
@@ -334,8 +337,22 @@ class Context:
     def accumulate(self):
         check(self.L.nxhip_accumulate(self.h), "nxhip_accumulate")
 
-    def accumulate_external(self, dev_ptr, count, frame_number):
-        check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, frame_number), "nxhip_accumulate_external")
+    def accumulate_external(self, dev_ptr, count, frame_number, pixel_map_dev_ptr=None):
+        check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, frame_number,
+                                               C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None), "nxhip_accumulate_external")
+
+    def bind_radiance(self, dev_ptr, capacity):
+        check(self.L.nxhip_bind_radiance(self.h, C.c_void_p(dev_ptr) if dev_ptr else None, capacity), "nxhip_bind_radiance")
+
+    def read_full_accumulation(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        check(self.L.nxhip_read_full_accumulation(self.h, _ptr(out)), "nxhip_read_full_accumulation")
+        return out
+
+    def read_full_rgba8(self):
+        out = np.zeros(self.width * self.height, np.uint32)
+        check(self.L.nxhip_read_full_rgba8(self.h, _ptr(out)), "nxhip_read_full_rgba8")
+        return out
 
     def render(self, frames):
         check(self.L.nxhip_render(self.h, frames), "nxhip_render")

@@ -454,12 +454,13 @@ NXD uint32_t tonemap_rgba8(f3 c)
 
 // src == nullptr: accumulate this context's own radiance with the device frame number.
 __global__ void __launch_bounds__(kWideBlock) accumulate_kernel(const DeviceState* __restrict__ S, const float4* __restrict__ src, const uint32_t count,
-                                                                 const uint32_t frameOverride)
+                                                                 const uint32_t frameOverride, const uint32_t* __restrict__ dstMap)
 {
     const uint32_t frame = frameOverride ? frameOverride : S->frame->frameNumber;
     const float4* in = src ? src : S->radiance;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const float4 r = in[i];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const float4 r = in[k];
+        const uint32_t i = dstMap ? dstMap[k] : k;
         float4 a;
         if (frame == 1u) a = make_float4(r.x, r.y, r.z, 0.0f);
         else {

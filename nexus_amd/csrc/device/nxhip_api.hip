@@ -66,6 +66,8 @@ using namespace nxd;
         if (!(buf).alloc(n)) return NXHIP_ERR_HIP;        \
     } while (0)
 
+static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, float* dst);
+
 static int fail_invalid(const char* msg)
 {
     set_error(msg);
@@ -589,7 +591,8 @@ struct Launch {
     int bounce;
     const float4* src;
     uint32_t count, frameOverride;
-    int nargs;  // 1: (S), 2: (S, bounce), 4: accumulate
+    const uint32_t* dstMap;
+    int nargs;  // 1: (S), 2: (S, bounce), 5: accumulate
 };
 
 Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceState* s, int bounce = -1)
@@ -640,12 +643,12 @@ void fill_args(Launch& l, void** args)
 {
     args[0] = (void*)&l.s;
     if (l.nargs == 2) args[1] = (void*)&l.bounce;
-    if (l.nargs == 4) { args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.frameOverride; }
+    if (l.nargs == 5) { args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.frameOverride; args[4] = (void*)&l.dstMap; }
 }
 
 int launch_now(nxhip_ctx* c, Launch& l)
 {
-    void* args[4];
+    void* args[5];
     fill_args(l, args);
     KernelTimer* t = nullptr;
     if (c->timingEnabled) {
@@ -674,7 +677,7 @@ static int build_graph(nxhip_ctx* c)
     for (auto& level : levels) {
         std::vector<hipGraphNode_t> cur;
         for (auto& l : level) {
-            void* args[4];
+            void* args[5];
             fill_args(l, args);
             hipKernelNodeParams p;
             std::memset(&p, 0, sizeof p);
@@ -726,13 +729,14 @@ int nxhip_render_frame(nxhip_ctx* c)
     return NXHIP_OK;
 }
 
-static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t frameOverride)
+static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t frameOverride, const uint32_t* dstMap)
 {
     Launch l = make_launch(accumulate_kernel_ptr(), c->wideBlocks, kWideBlockThreads, NXHIP_K_ACCUMULATE, c->dState.as<DeviceState>());
-    l.nargs = 4;
+    l.nargs = 5;
     l.src = src;
     l.count = count;
     l.frameOverride = frameOverride;
+    l.dstMap = dstMap;
     const size_t before = c->timerPool.size();
     const int rc = launch_now(c, l);
     if (rc == NXHIP_OK && c->timerPool.size() > before) c->timerClass.push_back(l.klass);
@@ -745,17 +749,48 @@ int nxhip_accumulate(nxhip_ctx* c)
     NX_HIP(hipSetDevice(c->device));
     const int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, nullptr, c->localCount, 0u);
+    return launch_accumulate(c, nullptr, c->localCount, 0u, nullptr);
 }
 
-int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uint32_t frameNumber)
+int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    if (radianceDevice) {
+        if (capacity < c->localCount) return fail_invalid("nxhip_bind_radiance: buffer smaller than localCount");
+        c->h.radiance = static_cast<float4*>(radianceDevice);
+    } else {
+        c->h.radiance = c->radiance.as<float4>();
+    }
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_read_full_accumulation(nxhip_ctx* c, float* dst)
+{
+    NX_CHECK_CTX(c);
+    return read_float4_as_float3(c, c->accumulation.p, c->width * c->height, dst);
+}
+
+int nxhip_read_full_rgba8(nxhip_ctx* c, uint32_t* dst)
+{
+    NX_CHECK_CTX(c);
+    if (!dst) return fail_invalid("null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_HIP(hipMemcpy(dst, c->rgba8.p, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uint32_t frameNumber, const void* srcPixelMapDevice)
 {
     NX_CHECK_CTX(c);
     if (!src || count == 0 || count > c->width * c->height || frameNumber == 0) return fail_invalid("nxhip_accumulate_external: bad arguments");
     NX_HIP(hipSetDevice(c->device));
     const int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, static_cast<const float4*>(src), count, frameNumber);
+    return launch_accumulate(c, static_cast<const float4*>(src), count, frameNumber, static_cast<const uint32_t*>(srcPixelMapDevice));
 }
 
 int nxhip_render(nxhip_ctx* c, uint32_t frames)
@@ -787,7 +822,7 @@ static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, 
 int nxhip_read_radiance(nxhip_ctx* c, float* dst)
 {
     NX_CHECK_CTX(c);
-    return read_float4_as_float3(c, c->radiance.p, c->localCount, dst);
+    return read_float4_as_float3(c, c->h.radiance, c->localCount, dst);
 }
 
 int nxhip_read_accumulation(nxhip_ctx* c, float* dst)
@@ -806,7 +841,7 @@ int nxhip_read_rgba8(nxhip_ctx* c, uint32_t* dst)
     return NXHIP_OK;
 }
 
-void* nxhip_radiance_device_ptr(nxhip_ctx* c) { return c ? c->radiance.p : nullptr; }
+void* nxhip_radiance_device_ptr(nxhip_ctx* c) { return c ? (void*)c->h.radiance : nullptr; }
 void* nxhip_accumulation_device_ptr(nxhip_ctx* c) { return c ? c->accumulation.p : nullptr; }
 
 int nxhip_read_queue_sizes(nxhip_ctx* c, nxhip_queue_sizes* out)
@@ -869,6 +904,7 @@ static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
 int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* hits)
 {
     NX_CHECK_CTX(c);
+    if (count == 0) return NXHIP_OK;
     if (!rays || !hits) return fail_invalid("nxhip_trace_batch: null buffer");
     NX_HIP(hipSetDevice(c->device));
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
@@ -908,6 +944,7 @@ int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* 
 int nxhip_trace_shadow_batch(nxhip_ctx* c, const nx_ray* rays, const float* tmax, uint32_t count, uint8_t* occluded)
 {
     NX_CHECK_CTX(c);
+    if (count == 0) return NXHIP_OK;
     if (!rays || !tmax || !occluded) return fail_invalid("nxhip_trace_shadow_batch: null buffer");
     NX_HIP(hipSetDevice(c->device));
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");

@@ -1,0 +1,211 @@
+"""Scene ingestion without Assimp: a minimal binary glTF (.glb) and Wavefront .obj reader.
+
+The reference imports everything through Assimp (/root/reference/Nexus/src/Assets/OBJLoader.cpp:8-239), which is
+not available here (empty submodule).  This reader reproduces what that path yields for the files the reference
+ships: one mesh + BVH per glTF *primitive* (Assimp splits primitives into aiMeshes, OBJLoader.cpp:165-181), one
+instance per (node, primitive) placed with the node's TRS decomposed to Euler degrees (OBJLoader.cpp:183-211), and
+the material heuristics of OBJLoader.cpp:71-163 (PLASTIC by default, DIELECTRIC if transmission > 0, emissive =
+emissiveFactor with intensity = KHR_materials_emissive_strength, ior from KHR_materials_ior, roughness from the
+glTF roughnessFactor — Assimp maps it to shininess (1-r)^2*1000 and the reference maps that back with
+1 - sqrt(shininess)/31.62278).
+"""
+import json
+import struct
+
+import numpy as np
+
+from . import pod
+
+_COMPONENT = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _quat_to_matrix(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _node_local_matrix(node):
+    if "matrix" in node:
+        return np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T  # glTF stores column major
+    m = np.eye(4)
+    r = _quat_to_matrix(node.get("rotation", [0, 0, 0, 1]))
+    s = np.array(node.get("scale", [1, 1, 1]), dtype=np.float64)
+    m[:3, :3] = r * s[None, :]
+    m[:3, 3] = node.get("translation", [0, 0, 0])
+    return m
+
+
+def decompose_trs(m):
+    """aiMatrix4x4::Decompose into (position, euler XYZ in degrees, scale), as the reference consumes it."""
+    pos = m[:3, 3].copy()
+    cols = [m[:3, 0].copy(), m[:3, 1].copy(), m[:3, 2].copy()]
+    scale = np.array([np.linalg.norm(c) for c in cols])
+    if np.linalg.det(m[:3, :3]) < 0:
+        scale = -scale
+    cols = [c / s if s != 0 else c for c, s in zip(cols, scale)]
+    eps = 1e-10
+    ry = np.arcsin(-cols[0][2])
+    c = np.cos(ry)
+    if abs(c) > eps:
+        rx = np.arctan2(cols[1][2], cols[2][2])
+        rz = np.arctan2(cols[0][1], cols[0][0])
+    else:
+        rx = 0.0
+        rz = np.arctan2(-cols[1][0], cols[1][1])
+    return pos, np.degrees([rx, ry, rz]), scale
+
+
+class LoadedScene:
+    """meshes: list of TRI_DT arrays; materials: MAT_DT array; instances: list of dict(mesh, material, position,
+    rotation (degrees), scale, name)."""
+
+    def __init__(self):
+        self.meshes = []
+        self.mesh_names = []
+        self.materials = np.zeros(0, dtype=pod.MAT_DT)
+        self.material_names = []
+        self.instances = []
+
+
+def _gltf_material(m):
+    pbr = m.get("pbrMetallicRoughness", {})
+    ext = m.get("extensions", {})
+    base = pbr.get("baseColorFactor", [1, 1, 1, 1])
+    rough = float(pbr.get("roughnessFactor", 1.0))
+    shininess = (1.0 - rough) ** 2 * 1000.0
+    roughness = float(np.clip(1.0 - np.sqrt(shininess) / 31.62278, 0.0, 1.0))
+    ior = float(ext.get("KHR_materials_ior", {}).get("ior", 1.45))
+    transmission = float(ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0))
+    mtype = pod.MAT_DIELECTRIC if transmission > 0.0 else pod.MAT_PLASTIC
+    emissive = m.get("emissiveFactor", [0, 0, 0])
+    intensity = float(ext.get("KHR_materials_emissive_strength", {}).get("emissiveStrength", 1.0))
+    return pod.make_material(type=mtype, albedo=base[:3], roughness=roughness, ior=ior, emissive=emissive, intensity=intensity,
+                             opacity=float(base[3]) if len(base) > 3 else 1.0)
+
+
+def load_glb(path):
+    data = open(path, "rb").read()
+    magic, version, _length = struct.unpack_from("<III", data, 0)
+    if magic != 0x46546C67 or version != 2:
+        raise ValueError("not a glTF 2.0 binary file")
+    off = 12
+    doc, blob = None, b""
+    while off < len(data):
+        clen, ctype = struct.unpack_from("<II", data, off)
+        chunk = data[off + 8: off + 8 + clen]
+        if ctype == 0x4E4F534A:
+            doc = json.loads(chunk)
+        elif ctype == 0x004E4942:
+            blob = chunk
+        off += 8 + clen
+    if doc is None:
+        raise ValueError("glb without a JSON chunk")
+
+    def accessor(i):
+        a = doc["accessors"][i]
+        bv = doc["bufferViews"][a["bufferView"]]
+        dt = np.dtype(_COMPONENT[a["componentType"]])
+        nc = _NCOMP[a["type"]]
+        start = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0) or dt.itemsize * nc
+        count = a["count"]
+        if stride == dt.itemsize * nc:
+            arr = np.frombuffer(blob, dtype=dt, count=count * nc, offset=start).reshape(count, nc)
+        else:
+            arr = np.stack([np.frombuffer(blob, dtype=dt, count=nc, offset=start + k * stride) for k in range(count)])
+        return arr
+
+    out = LoadedScene()
+    mats = [_gltf_material(m) for m in doc.get("materials", [])]
+    out.material_names = [m.get("name", "") for m in doc.get("materials", [])]
+    out.materials = np.array(mats, dtype=pod.MAT_DT) if mats else np.array([pod.make_material()], dtype=pod.MAT_DT)
+
+    # one mesh per primitive (what Assimp hands the reference)
+    prim_mesh = {}
+    for mi, mesh in enumerate(doc.get("meshes", [])):
+        for pi, prim in enumerate(mesh["primitives"]):
+            if prim.get("mode", 4) != 4:
+                continue
+            pos = accessor(prim["attributes"]["POSITION"]).astype(np.float32)
+            nrm = accessor(prim["attributes"]["NORMAL"]).astype(np.float32) if "NORMAL" in prim["attributes"] else None
+            uv = accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in prim["attributes"] else None
+            idx = accessor(prim["indices"]).reshape(-1).astype(np.int64) if "indices" in prim else np.arange(len(pos))
+            tri = idx.reshape(-1, 3)
+            normals = nrm[tri] if nrm is not None else np.zeros((len(tri), 3, 3), np.float32)
+            if uv is not None:
+                uv = uv.copy()
+                uv[:, 1] = 1.0 - uv[:, 1]  # aiProcess_FlipUVs, OBJLoader.cpp:219-220
+            t = pod.make_triangles(pos[tri], normals=normals, uvs=uv[tri] if uv is not None else None)
+            prim_mesh[(mi, pi)] = (len(out.meshes), prim.get("material", 0))
+            out.meshes.append(t)
+            out.mesh_names.append(mesh.get("name", "mesh%d" % mi))
+
+    def walk(ni, parent):
+        node = doc["nodes"][ni]
+        m = parent @ _node_local_matrix(node)
+        if "mesh" in node:
+            pos, rot, scale = decompose_trs(m)
+            for (mi, pi), (mesh_id, mat_id) in prim_mesh.items():
+                if mi == node["mesh"]:
+                    out.instances.append(dict(mesh=mesh_id, material=mat_id, position=pos.astype(np.float32), rotation=rot.astype(np.float32),
+                                              scale=scale.astype(np.float32), name=node.get("name", "")))
+        for c in node.get("children", []):
+            walk(c, m)
+
+    scene = doc["scenes"][doc.get("scene", 0)]
+    for ni in scene["nodes"]:
+        walk(ni, np.eye(4))
+    return out
+
+
+def load_obj(path):
+    """Triangulated Wavefront .obj (v / vn / vt / f, fan triangulation), one mesh, default material."""
+    v, vn, vt, faces = [], [], [], []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                v.append([float(x) for x in p[1:4]])
+            elif p[0] == "vn":
+                vn.append([float(x) for x in p[1:4]])
+            elif p[0] == "vt":
+                vt.append([float(x) for x in p[1:3]])
+            elif p[0] == "f":
+                corners = []
+                for tok in p[1:]:
+                    parts = tok.split("/")
+                    vi = int(parts[0])
+                    ti = int(parts[1]) if len(parts) > 1 and parts[1] else 0
+                    ni = int(parts[2]) if len(parts) > 2 and parts[2] else 0
+                    corners.append((vi, ti, ni))
+                for k in range(1, len(corners) - 1):
+                    faces.append((corners[0], corners[k], corners[k + 1]))
+    v = np.array(v, np.float32)
+    vn = np.array(vn, np.float32) if vn else None
+    vt = np.array(vt, np.float32) if vt else None
+
+    def fix(i, n):
+        return i - 1 if i > 0 else n + i
+
+    pos = np.array([[v[fix(c[0], len(v))] for c in f] for f in faces], np.float32)
+    normals = None
+    if vn is not None and all(c[2] for f in faces for c in f):
+        normals = np.array([[vn[fix(c[2], len(vn))] for c in f] for f in faces], np.float32)
+    uvs = None
+    if vt is not None and all(c[1] for f in faces for c in f):
+        uvs = np.array([[vt[fix(c[1], len(vt))] for c in f] for f in faces], np.float32)
+        uvs[..., 1] = 1.0 - uvs[..., 1]
+    out = LoadedScene()
+    out.meshes = [pod.make_triangles(pos, normals=normals, uvs=uvs)]
+    out.mesh_names = [path]
+    out.materials = np.array([pod.make_material(type=pod.MAT_PLASTIC, albedo=(0.6, 0.6, 0.6), roughness=1.0 - np.sqrt(20.0) / 31.62278)], dtype=pod.MAT_DT)
+    out.material_names = ["default"]
+    out.instances = [dict(mesh=0, material=0, position=np.zeros(3, np.float32), rotation=np.zeros(3, np.float32), scale=np.ones(3, np.float32), name=path)]
+    return out

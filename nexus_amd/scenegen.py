@@ -29,8 +29,9 @@ def _grid_surface_triangles(P, N, uv, wrap_u, wrap_v):
             t["texCoord%d" % k] = uv[ii].reshape(-1, 2)
         return t
 
-    t0 = tri(idx00, idx10, idx11)
-    t1 = tri(idx00, idx11, idx01)
+    # winding chosen so that the geometric normal cross(p1-p0, p2-p0) agrees with the vertex normals cross(dv, du)
+    t0 = tri(idx00, idx11, idx10)
+    t1 = tri(idx00, idx01, idx11)
     out = np.empty(2 * a.size, dtype=pod.TRI_DT)
     out[0::2] = t0
     out[1::2] = t1

@@ -85,3 +85,77 @@ def hit_records_equal(a, b):
     return (np.array_equal(a["hitDistance"].view(np.uint32), b["hitDistance"].view(np.uint32)) and np.array_equal(a["u"].view(np.uint32), b["u"].view(np.uint32))
             and np.array_equal(a["v"].view(np.uint32), b["v"].view(np.uint32)) and np.array_equal(a["triIdx"], b["triIdx"])
             and np.array_equal(a["instanceIdx"], b["instanceIdx"]))
+
+
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cornell_scene(width=512, height=512, path_length=4, force_diffuse=True, use_mis=True):
+    """BASELINE.json configs[0]: the reference's cornell_box.glb (8 primitives -> 8 BLAS/instances, node rotated +90 deg
+    about X), all materials DIFFUSE with the glb base colours, light emissive (1,1,1) x 35, camera at (0,1,3.9) looking
+    down -z with a 40 degree horizontal FOV (the file carries no camera; SURVEY.md section 8d fixes these numbers)."""
+    from nexus_amd import loaders
+
+    ls = loaders.load_glb(os.path.join(GOLDEN, "cornell_box.glb"))
+    mats = ls.materials.copy()
+    if force_diffuse:
+        mats["type"] = pod.MAT_DIFFUSE
+    placements = []
+    for inst in ls.instances:
+        xf = capi.mat4_from_trs(inst["position"], inst["rotation"], inst["scale"])
+        placements.append((inst["mesh"], inst["material"], xf))
+    cam = capi.camera_init((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, width, height, 5.0, 0.0)
+    settings = O.make_settings(use_mis=use_mis, path_length=path_length, background=(1, 1, 1), background_intensity=0.0)
+    sc = BuiltScene(ls.meshes, placements, materials=mats, camera=cam, settings=settings)
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc
+
+
+def checker_texture(w=64, h=32, seed=0, alpha=False):
+    rng = np.random.RandomState(seed)
+    img = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    chk = ((xx // 8 + yy // 8) % 2).astype(bool)
+    img[chk, :3] = img[chk, :3] // 3
+    img[..., 3] = rng.randint(128, 256, size=(h, w)) if alpha else 255
+    return img
+
+
+def material_zoo_scene(width=96, height=64, path_length=5, hdr=True, textures=True):
+    """Every material type, an emissive-textured light, diffuse texture with alpha, opacity < 1, instanced + rotated BLAS,
+    equirectangular background."""
+    torus = scenegen.displaced_torus(40, 20, seed=4, major=0.5, minor=0.22)
+    floor = scenegen.quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4))
+    light = scenegen.quad((-0.8, 0, -0.8), (0.8, 0, -0.8), (0.8, 0, 0.8), (-0.8, 0, 0.8))
+    mats = np.array([
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.7, 0.7, 0.7), diffuse_map=0 if textures else -1),
+        pod.make_material(pod.MAT_PLASTIC, albedo=(0.8, 0.3, 0.2), roughness=0.4, ior=1.5),
+        pod.make_material(pod.MAT_DIELECTRIC, albedo=(0.95, 0.97, 1.0), roughness=0.2, ior=1.45),
+        pod.make_material(pod.MAT_CONDUCTOR, roughness=0.3),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 0.9, 0.8), intensity=12.0, emissive_map=0 if textures else -1),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.3, 0.6, 0.9), opacity=0.6),
+    ], dtype=pod.MAT_DT)
+    placements = [
+        (1, 0, capi.mat4_from_trs((0, 0, 0))),
+        (0, 1, capi.mat4_from_trs((-1.4, 0.55, 0.0), (20, 30, 0))),
+        (0, 2, capi.mat4_from_trs((0.0, 0.55, 0.3), (90, 0, 15), (1.1, 1.1, 1.1))),
+        (0, 3, capi.mat4_from_trs((1.4, 0.6, -0.2), (0, 60, 40), (1.0, 1.3, 1.0))),
+        (0, 5, capi.mat4_from_trs((0.2, 0.5, 1.6), (45, 0, 0), (0.7, 0.7, 0.7))),
+        (2, 4, capi.mat4_from_trs((0, 3.0, 0), (180, 0, 0))),
+    ]
+    cam = capi.camera_init((0.0, 1.6, 5.0), (0.0, -0.2, -0.98), 50.0, width, height, 5.0, 1.5)
+    settings = O.make_settings(use_mis=True, path_length=path_length, background=(0.6, 0.7, 0.9), background_intensity=0.5)
+    sc = BuiltScene([torus, floor, light], placements, materials=mats, camera=cam, settings=settings,
+                    diffuse_maps=[checker_texture(64, 32, 1, alpha=True)] if textures else (), emissive_maps=[checker_texture(32, 32, 2)] if textures else (),
+                    hdr_map=checker_texture(128, 64, 3) if hdr else None)
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc
+
+
+def image_agreement(got, want, rel=1e-3):
+    """Fraction of pixels whose RGB all satisfy |got - want| <= rel * max(1, |want|)."""
+    tol = rel * np.maximum(1.0, np.abs(want))
+    ok = np.all(np.abs(got - want) <= tol, axis=1)
+    return float(ok.mean())
