@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from nexus_amd import capi, pod, scenegen  # noqa: E402
+from nexus_amd import capi, multigpu, pod, scenegen  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 TILE_ROWS = 5          # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
@@ -65,8 +65,8 @@ def build_config2(width, height, nu, nv, path_length):
     light_rec = np.zeros(1, dtype=pod.LIGHT_DT)
     light_rec["meshId"] = 2
     light_rec["type"] = pod.LIGHT_MESH
-    eye = np.array([0.0, 3.0, 3.9])
-    fwd = np.array([0.0, 0.45, 0.0]) - eye
+    eye = np.array([0.0, 3.3, 4.9])
+    fwd = np.array([0.0, 0.35, 0.0]) - eye
     fwd /= np.linalg.norm(fwd)
     cam = capi.camera_init(eye, fwd, 52.0, width, height, 5.0, 0.0)
     settings = np.zeros((), dtype=pod.SETTINGS_DT)
@@ -90,8 +90,7 @@ def upload(ctx, sc):
 
 
 def tile_pixel_map(width, height, rank, world):
-    rows = [r for r in range(height) if (r // TILE_ROWS) % world == rank]
-    return np.concatenate([np.arange(r * width, (r + 1) * width, dtype=np.uint32) for r in rows])
+    return multigpu.tile_pixel_map(width, height, rank, world, multigpu.tile_rows_for(height, world, (TILE_ROWS, 8, 4, 6, 3, 2, 1)))
 
 
 def trace_algorithmic_bytes(st):
@@ -126,6 +125,7 @@ def main():
     ap.add_argument("--path-length", type=int, default=8)
     ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
     ap.add_argument("--nv", type=int, default=512)
+    ap.add_argument("--frames-per-pass", type=int, default=4, help="frames batched into one wavefront pass (steps must be a multiple)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -140,6 +140,9 @@ def main():
         args.gpus = world
 
     W, H = args.width, args.height
+    S = max(1, args.frames_per_pass)
+    if args.steps % S or args.warmup % S:
+        raise SystemExit("--steps and --warmup must be multiples of --frames-per-pass (%d)" % S)
     sc = build_config2(W, H, args.nu, args.nv, args.path_length)
 
     dist = None
@@ -159,31 +162,39 @@ def main():
     if world > 1:
         pm = tile_pixel_map(W, H, rank, world)
         ctx.set_pixel_map(pm)
+        ctx.set_frames_per_pass(S)
         n_local = len(pm)
-        rad = torch.zeros((n_local, 4), dtype=torch.float32, device="cuda")
-        ctx.bind_radiance(rad.data_ptr(), n_local)
+        rad = torch.zeros((S * n_local, 4), dtype=torch.float32, device="cuda")
+        ctx.bind_radiance(rad.data_ptr(), S * n_local)
         if rank == 0:
-            gathered = [torch.zeros((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
-            all_maps = np.concatenate([tile_pixel_map(W, H, r, world) for r in range(world)])
-            assert len(all_maps) == W * H and len(np.unique(all_maps)) == W * H
-            maps_dev = torch.from_numpy(all_maps.astype(np.int64)).to("cuda").to(torch.int32)
-            flat = torch.zeros((world * n_local, 4), dtype=torch.float32, device="cuda")
+            gathered = [torch.zeros((S * n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
+            maps_dev = []
+            seen = np.zeros(W * H, dtype=bool)
+            for r in range(world):
+                m = tile_pixel_map(W, H, r, world)
+                assert len(m) == n_local and not seen[m].any()
+                seen[m] = True
+                maps_dev.append(torch.from_numpy(m.astype(np.int64)).to("cuda").to(torch.int32))
+            assert seen.all()
         frame_counter = [0]
 
         def step():
             ctx.render_frame()
-            frame_counter[0] += 1
+            first = frame_counter[0] + 1
+            frame_counter[0] += S
             # the one collective of the path: radiance tiles -> rank 0 over xGMI
             dist.gather(rad, gathered if rank == 0 else None, dst=0)
             if rank == 0:
-                torch.cat(gathered, out=flat)
-                ctx.accumulate_external(flat.data_ptr(), W * H, frame_counter[0], maps_dev.data_ptr())
+                for r in range(world):
+                    ctx.accumulate_external(gathered[r].data_ptr(), n_local, first, maps_dev[r].data_ptr(), slices=S, slice_stride=n_local)
 
         def sync():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
     else:
+        ctx.set_frames_per_pass(S)
+
         def step():
             ctx.render_frame()
             ctx.accumulate()
@@ -191,11 +202,12 @@ def main():
         def sync():
             ctx.sync()
 
-    for _ in range(args.warmup):
+    # one step = one frame; a pass renders S frames
+    for _ in range(args.warmup // S):
         step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // S):
         step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -222,18 +234,20 @@ def main():
             "workload": "configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
                         % (sc["triangles"], sc["bvh8_nodes"], W, H, args.path_length),
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, one RCCL gather per frame" % (world, TILE_ROWS),
-            "rng": "pixel-keyed", "compaction": "wave-aggregated atomics", "launch": "one hipGraph per frame",
+            "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of %d frames" % S,
+            "frames_per_pass": S,
             "host_bvh_build_s": round(sc["t_build"], 2),
         },
     }
 
     # ---- roofline of the dominant kernel (closest-hit trace), rank 0 / single GPU only
     if rank == 0 and world == 1 and not args.no_roofline:
-        frames = max(1, min(args.steps, 16))
+        passes = max(1, min(args.steps // S, 8))
+        frames = passes * S
         # (a) units: the counting variant of the same kernel over `frames` frames
         ctx.enable_trace_stats(True)
         ctx.read_trace_stats(reset=True)
-        for _ in range(frames):
+        for _ in range(passes):
             ctx.render_frame()
         closest, shadow = ctx.read_trace_stats(reset=True)
         ctx.enable_trace_stats(False)
@@ -241,7 +255,7 @@ def main():
         # (b) durations: hipEvent pair around every launch, same frames again
         ctx.enable_kernel_timing(True)
         ctx.read_kernel_times(reset=True)
-        for _ in range(frames):
+        for _ in range(passes):
             ctx.render_frame()
             ctx.accumulate()
         kt = ctx.read_kernel_times(reset=True)

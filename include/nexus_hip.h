@@ -72,6 +72,13 @@ int nxhip_set_modes(nxhip_ctx *ctx, int rngMode, int compactMode, int conductorM
  * pixel i (NULL: identity over width*height).  Re-allocates the queues for localCount paths. */
 int nxhip_set_pixel_map(nxhip_ctx *ctx, const uint32_t *pixelMap, uint32_t localCount);
 
+/* Batch `frames` consecutive frames into one pass of the wavefront (default 1 = the reference's one frame per
+ * Render()).  Every queue then holds localCount * frames paths, so each kernel launch carries `frames` times the work:
+ * the latency tail of a trace launch (its slowest ray) and the per-launch overheads are amortised, at the price of
+ * HBM capacity (about 0.3 KB per path).  Each frame keeps its own frame number / RNG streams; the accumulate step
+ * applies the frames' running-mean updates in order.  Re-allocates the queues and resets the frame number. */
+int nxhip_set_frames_per_pass(nxhip_ctx *ctx, uint32_t frames);
+
 /* ---- rendering ----------------------------------------------------------------------------------- */
 
 /* PathTracer::ResetFrameNumber — PathTracer.cpp:243-246 */
@@ -79,14 +86,16 @@ int nxhip_reset_frame_number(nxhip_ctx *ctx);
 int nxhip_set_frame_number(nxhip_ctx *ctx, uint32_t frameNumber); /* next render uses frameNumber + 1 */
 uint32_t nxhip_frame_number(nxhip_ctx *ctx);
 /* PathTracer::Render minus AccumulateKernel — PathTracer.cpp:248-276: frameNumber++, Generate, Trace, then
- * pathLength x (Logic, 4 x Shade, Trace || TraceShadow), replayed as one hipGraph.  Asynchronous. */
+ * pathLength x (Logic, 4 x Shade, Trace || TraceShadow), replayed as one hipGraph.  Asynchronous.  Renders one pass
+ * = frames-per-pass frames (1 unless nxhip_set_frames_per_pass was called). */
 int nxhip_render_frame(nxhip_ctx *ctx);
 /* AccumulateKernel — Cuda/PathTracer/PathTracer.cu:480-496, PathTracer.cpp:278.  Asynchronous. */
 int nxhip_accumulate(nxhip_ctx *ctx);
 /* nxhip_render_frame + nxhip_accumulate `frames` times (one graph replay per frame). */
 int nxhip_render(nxhip_ctx *ctx, uint32_t frames);
 
-/* Read-back (synchronises).  radiance/accumulation: localCount x 3 floats; rgba8: localCount uint32
+/* Read-back (synchronises).  radiance: localCount * framesPerPass x 3 floats (frame slices one after the other);
+ * accumulation: localCount x 3 floats; rgba8: localCount uint32
  * (the reference's GL pixel buffer, OpenGL/PixelBuffer.cpp:4-41). */
 int nxhip_read_radiance(nxhip_ctx *ctx, float *dst);
 int nxhip_read_accumulation(nxhip_ctx *ctx, float *dst);
@@ -96,14 +105,15 @@ int nxhip_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);
 void *nxhip_radiance_device_ptr(nxhip_ctx *ctx);
 void *nxhip_accumulation_device_ptr(nxhip_ctx *ctx);
 /* Make the context write its per-frame radiance into caller-owned device memory (float4[capacity], capacity >=
- * localCount) — e.g. a torch tensor that is then handed to an RCCL gather without a copy.  NULL: back to the
+ * localCount * framesPerPass) — e.g. a torch tensor that is then handed to an RCCL gather without a copy.  NULL: back to the
  * context's own buffer.  The binding is dropped by nxhip_resize / nxhip_set_pixel_map. */
 int nxhip_bind_radiance(nxhip_ctx *ctx, void *radianceDevice, uint32_t capacity);
-/* Root-side accumulate + tonemap of externally gathered radiance: src = device float4[count]; element i belongs to
- * full-image pixel srcPixelMapDevice[i] (device uint32[count]; NULL: i).  Writes the context's accumulation / RGBA8
- * buffers, which always cover width*height pixels. */
-int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t frameNumber,
-                              const void *srcPixelMapDevice);
+/* Root-side accumulate + tonemap of externally gathered radiance: src = device float4 laid out [slices][sliceStride];
+ * element k (< count) of slice s is the radiance of frame firstFrame + s at full-image pixel srcPixelMapDevice[k]
+ * (device uint32[count]; NULL: k).  Writes the context's accumulation / RGBA8 buffers, which always cover
+ * width*height pixels. */
+int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t slices, uint32_t sliceStride,
+                              uint32_t firstFrame, const void *srcPixelMapDevice);
 /* Read-back of the full width*height accumulation / RGBA8 image (after nxhip_accumulate_external). */
 int nxhip_read_full_accumulation(nxhip_ctx *ctx, float *dst);
 int nxhip_read_full_rgba8(nxhip_ctx *ctx, uint32_t *dst);

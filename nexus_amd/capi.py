@@ -18,7 +18,7 @@ HIP_SYMBOLS = [
     "nxhip_last_error", "nxhip_device_count", "nxhip_create", "nxhip_destroy", "nxhip_resize", "nxhip_sync",
     "nxhip_upload_blas", "nxhip_clear_blas", "nxhip_set_tlas", "nxhip_set_materials", "nxhip_set_lights",
     "nxhip_upload_texture", "nxhip_clear_textures", "nxhip_set_camera", "nxhip_set_render_settings", "nxhip_set_modes",
-    "nxhip_set_pixel_map", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
+    "nxhip_set_pixel_map", "nxhip_set_frames_per_pass", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
     "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
     "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
@@ -97,7 +97,8 @@ def lib():
     L.nxhip_radiance_device_ptr.restype = vp
     L.nxhip_accumulation_device_ptr.argtypes = [vp]
     L.nxhip_accumulation_device_ptr.restype = vp
-    L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32, vp]
+    L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32, u32, u32, vp]
+    L.nxhip_set_frames_per_pass.argtypes = [vp, u32]
     L.nxhip_bind_radiance.argtypes = [vp, vp, u32]
     L.nxhip_read_full_accumulation.argtypes = [vp, vp]
     L.nxhip_read_full_rgba8.argtypes = [vp, vp]
@@ -241,6 +242,7 @@ class Context:
         check(self.L.nxhip_create(device, self.width, self.height, C.c_void_p(stream) if stream else None, C.byref(h)), "nxhip_create")
         self.h = h
         self.local_count = self.width * self.height
+        self.frames_per_pass = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -337,9 +339,13 @@ class Context:
     def accumulate(self):
         check(self.L.nxhip_accumulate(self.h), "nxhip_accumulate")
 
-    def accumulate_external(self, dev_ptr, count, frame_number, pixel_map_dev_ptr=None):
-        check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, frame_number,
-                                               C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None), "nxhip_accumulate_external")
+    def accumulate_external(self, dev_ptr, count, first_frame, pixel_map_dev_ptr=None, slices=1, slice_stride=None):
+        check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, slices, slice_stride if slice_stride is not None else count,
+                                               first_frame, C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None), "nxhip_accumulate_external")
+
+    def set_frames_per_pass(self, frames):
+        check(self.L.nxhip_set_frames_per_pass(self.h, frames), "nxhip_set_frames_per_pass")
+        self.frames_per_pass = int(frames)
 
     def bind_radiance(self, dev_ptr, capacity):
         check(self.L.nxhip_bind_radiance(self.h, C.c_void_p(dev_ptr) if dev_ptr else None, capacity), "nxhip_bind_radiance")
@@ -361,7 +367,7 @@ class Context:
         check(self.L.nxhip_sync(self.h), "nxhip_sync")
 
     def read_radiance(self):
-        out = np.zeros((self.local_count, 3), np.float32)
+        out = np.zeros((self.local_count * self.frames_per_pass, 3), np.float32)
         check(self.L.nxhip_read_radiance(self.h, _ptr(out)), "nxhip_read_radiance")
         return out
 

@@ -68,6 +68,7 @@ struct nxhip_ctx {
     int numCUs = 0;
 
     uint32_t width = 0, height = 0, localCount = 0;
+    uint32_t framesPerPass = 1, pathCount = 0;
 
     nxd::DeviceState h{};  // host mirror, uploaded to dState when dirty
     nxd::DevBuf dState;

@@ -111,8 +111,12 @@ struct DeviceState {
     nx_camera camera;
     nx_render_settings settings;
     int32_t rngMode, compactMode, conductorMode;
-    // paths
-    uint32_t localCount;       // paths rendered by this context
+    // paths: a pass renders framesPerPass consecutive frames at once; path p belongs to frame slice p / localCount
+    // and to local pixel p % localCount.  Batching frames keeps every kernel large (the tail of a trace launch is
+    // set by its slowest ray) and uses HBM capacity instead of launches.
+    uint32_t localCount;       // pixels rendered by this context
+    uint32_t framesPerPass;    // S >= 1
+    uint32_t pathCount;        // localCount * framesPerPass
     const uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
     float4* throughputPdf;     // rgb throughput, w = lastPdf
     float4* radiance;

@@ -21,88 +21,101 @@
 
 namespace nxd {
 
-constexpr int kWideBlock = 256;
-constexpr int kOrderedBlock = 1024;
+constexpr int kWideBlock = 256;     // generate / accumulate
+constexpr int kLogicBlock = 1024;   // one slot atomic per 1024 items
+constexpr int kShadeBlock = 512;
+constexpr int kOrderedBlock = 1024;  // single-workgroup ordered mode
 
 // ------------------------------------------------------------------------------------------------------
-// slot allocation
+// slot allocation: K queues at once, one round of workgroup-wide cooperation per tile.
+//   FAST    : per-wave ballots -> per-workgroup totals in LDS -> ONE atomicAdd per workgroup and counter (a single
+//             global counter sustains only ~88 returning atomics per microsecond on MI355X, so per-wave atomics
+//             serialise a 2M-item pass; per-workgroup ones do not).
+//   ORDERED : a single workgroup whose running bases live in LDS; slots follow ascending item index, i.e. the
+//             reference's serial order.
+// Must be called by every thread of the workgroup (uniform control flow).
 
-template <bool ORDERED> struct SlotAllocator;
+constexpr int kMaxWavesPerBlock = kOrderedBlock / kWave;
 
-// FAST: one atomic per wave.
-template <> struct SlotAllocator<false> {
-    NXD void init(const DeviceState*, int) {}
-    NXD void finish(const DeviceState*, int) {}
-    NXD int alloc(bool want, int* counter, int /*which*/)
+template <bool ORDERED, int K>
+struct SlotAllocator {
+    int* sWave;  // [K][kMaxWavesPerBlock] per-wave counts of the current tile
+    int* sBase;  // [K] base slot of the current tile
+    int* sRun;   // [K] ORDERED: running bases
+    int* counters[K];
+
+    NXD void init(int* const (&ctr)[K])
     {
-        const unsigned long long mask = __ballot(want);
-        if (mask == 0ull) return -1;
-        const int lane = threadIdx.x & (kWave - 1);
-        const int leader = __ffsll((long long)mask) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-        base = __shfl(base, leader);
-        return base + __popcll(mask & ((1ull << lane) - 1ull));
-    }
-};
-
-// ORDERED: single workgroup; running bases live in LDS, slots follow ascending thread index.
-// which: 0 trace, 1 shadow, 2..5 material queues.
-template <> struct SlotAllocator<true> {
-    int* sBase;   // [6]
-    int* sWave;   // [kOrderedBlock / 64]
-    NXD void init(const DeviceState* S, int bounce)
-    {
-        __shared__ int base[6];
-        __shared__ int wave[kOrderedBlock / kWave];
-        sBase = base;
+        __shared__ int wave[K * kMaxWavesPerBlock];
+        __shared__ int base[K];
+        __shared__ int run[K];
         sWave = wave;
-        if (threadIdx.x == 0) {
-            Counters* C = S->counters;
-            base[0] = C->traceSize[bounce];
-            base[1] = C->traceShadowSize[bounce];
-            for (int m = 0; m < 4; m++) base[2 + m] = C->materialSize[m][bounce];
+        sBase = base;
+        sRun = run;
+#pragma unroll
+        for (int k = 0; k < K; k++) counters[k] = ctr[k];
+        if (ORDERED) {
+            if (threadIdx.x < K) run[threadIdx.x] = *ctr[threadIdx.x];
         }
         __syncthreads();
     }
-    NXD void finish(const DeviceState* S, int bounce)
+    NXD void finish()
     {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            Counters* C = S->counters;
-            C->traceSize[bounce] = sBase[0];
-            C->traceShadowSize[bounce] = sBase[1];
-            for (int m = 0; m < 4; m++) C->materialSize[m][bounce] = sBase[2 + m];
+        if (ORDERED) {
+            if (threadIdx.x < K) *counters[threadIdx.x] = sRun[threadIdx.x];
         }
     }
-    // must be called by every thread of the workgroup
-    NXD int alloc(bool want, int* /*counter*/, int which)
+    NXD void alloc(const bool (&want)[K], int (&slot)[K])
     {
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-        const unsigned long long mask = __ballot(want);
-        if (lane == 0) sWave[wave] = __popcll(mask);
-        __syncthreads();
         const int nWaves = blockDim.x / kWave;
-        int prefix = 0, total = 0;
-        for (int w = 0; w < nWaves; w++) {
-            const int c = sWave[w];
-            prefix += (w < wave) ? c : 0;
-            total += c;
+        unsigned long long mask[K];
+        __syncthreads();  // the previous tile's readers are done with sWave / sBase
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            mask[k] = __ballot(want[k]);
+            if (lane == 0) sWave[k * kMaxWavesPerBlock + wave] = __popcll(mask[k]);
         }
-        const int base = sBase[which];
         __syncthreads();
-        if (threadIdx.x == 0) sBase[which] = base + total;
+        if (threadIdx.x < K) {
+            int total = 0;
+            for (int w = 0; w < nWaves; w++) total += sWave[threadIdx.x * kMaxWavesPerBlock + w];
+            if (ORDERED) {
+                sBase[threadIdx.x] = sRun[threadIdx.x];
+                sRun[threadIdx.x] += total;
+            } else {
+                sBase[threadIdx.x] = total ? atomicAdd(counters[threadIdx.x], total) : 0;
+            }
+        }
         __syncthreads();
-        return want ? base + prefix + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            slot[k] = -1;
+            if (want[k]) {
+                int prefix = 0;
+                for (int w = 0; w < wave; w++) prefix += sWave[k * kMaxWavesPerBlock + w];
+                slot[k] = sBase[k] + prefix + __popcll(mask[k] & ((1ull << lane) - 1ull));
+            }
+        }
     }
 };
 
 NXD uint32_t global_pixel(const DeviceState* S, uint32_t local) { return S->pixelMap ? S->pixelMap[local] : local; }
 
-NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pixelIdx, uint32_t bounce, uint32_t stage, uint32_t frame)
+// frame number and local pixel of a path; frameLast = number of the last frame of the current pass
+struct PathId { uint32_t frame, pixel; };
+NXD PathId path_id(const DeviceState* S, uint32_t pathIdx, uint32_t frameLast)
 {
-    if (S->rngMode == NX_RNG_PIXEL_KEYED) return rng_init_keyed(global_pixel(S, pixelIdx), bounce, frame, stage);
-    return rng_init_index(slot, S->camera.resolution[0], frame);
+    const uint32_t slice = S->framesPerPass > 1u ? pathIdx / S->localCount : 0u;
+    return PathId{frameLast - (S->framesPerPass - 1u) + slice, pathIdx - slice * S->localCount};
+}
+
+NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pathIdx, uint32_t bounce, uint32_t stage, uint32_t frameLast)
+{
+    const PathId id = path_id(S, pathIdx, frameLast);
+    if (S->rngMode == NX_RNG_PIXEL_KEYED) return rng_init_keyed(global_pixel(S, id.pixel), bounce, id.frame, stage);
+    return rng_init_index(slot, S->camera.resolution[0], id.frame);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -116,8 +129,8 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(const DeviceSta
     for (int i = threadIdx.x; i < n; i += blockDim.x) c[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        S->counters->traceSize[0] = (int)S->localCount;
-        S->frame->frameNumber += 1u;
+        S->counters->traceSize[0] = (int)S->pathCount;
+        S->frame->frameNumber += S->framesPerPass;
     }
 }
 
@@ -126,17 +139,18 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(const DeviceSta
 
 __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState* __restrict__ S)
 {
-    const uint32_t n = S->localCount;
-    const uint32_t frame = S->frame->frameNumber;
+    const uint32_t n = S->pathCount;
+    const uint32_t frameLast = S->frame->frameNumber;
     const uint32_t resX = S->camera.resolution[0], resY = S->camera.resolution[1];
     const f3 camPos = ld3(S->camera.position), camRight = ld3(S->camera.right), camUp = ld3(S->camera.up);
     const f3 llc = ld3(S->camera.lowerLeftCorner), vpX = ld3(S->camera.viewportX), vpY = ld3(S->camera.viewportY);
     const float lensRadius = S->camera.lensRadius;
     for (uint32_t index = blockIdx.x * blockDim.x + threadIdx.x; index < n; index += gridDim.x * blockDim.x) {
-        const uint32_t g = global_pixel(S, index);
+        const PathId id = path_id(S, index, frameLast);
+        const uint32_t g = global_pixel(S, id.pixel);
         const uint32_t j = g / resX;
         const uint32_t i = g - j * resX;
-        uint32_t rng = rng_init_pixel(i, j, resX, frame);
+        uint32_t rng = rng_init_pixel(i, j, resX, id.frame);
         const float x = ((float)i + rng_next(rng)) / (float)resX;
         const float y = ((float)j + rng_next(rng)) / (float)resY;
         const f2 disk = unit_disk(rng);
@@ -171,13 +185,14 @@ NXD f3 sample_background(const DeviceState* S, f3 d)
 // LogicKernel — PathTracer.cu:136-210
 
 template <bool ORDERED>
-__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const int size = C->traceSize[bounce - 1];
     const uint32_t frame = S->frame->frameNumber;
-    SlotAllocator<ORDERED> slots;
-    slots.init(S, bounce);
+    SlotAllocator<ORDERED, 4> slots;
+    int* const ctr[4] = {&C->materialSize[0][bounce], &C->materialSize[1][bounce], &C->materialSize[2][bounce], &C->materialSize[3][bounce]};
+    slots.init(ctr);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
         const int index = tile + (int)threadIdx.x;
@@ -197,7 +212,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) logic_ke
                 r.x += bg.x; r.y += bg.y; r.z += bg.z;
                 if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 S->radiance[pixelIdx] = r;
-                if (bounce == 1 && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
+                if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
             } else {
                 uint32_t rng = seed_for(S, (uint32_t)index, pixelIdx, (uint32_t)bounce, 0u, frame);
                 const float probability = maxcomp3(throughput);
@@ -211,18 +226,18 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) logic_ke
                 }
             }
         }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const bool want = type == m;
-            const int slot = slots.alloc(want, &C->materialSize[m][bounce], 2 + m);
-            if (want) {
-                S->material[m].hit[slot] = hit;
-                S->material[m].dirInst[slot] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
-                S->material[m].pixel[slot] = pixelIdx;
-            }
+        const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
+        int slot[4];
+        slots.alloc(want, slot);
+        if (type >= 0) {
+            const MaterialQueue mq = S->material[type];
+            const int sl = type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3]));
+            mq.hit[sl] = hit;
+            mq.dirInst[sl] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
+            mq.pixel[sl] = pixelIdx;
         }
     }
-    slots.finish(S, bounce);
+    slots.finish();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -303,14 +318,15 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
 }
 
 template <int TYPE, bool ORDERED>
-__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, 4) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const int size = C->materialSize[TYPE][bounce];
     const uint32_t frame = S->frame->frameNumber;
     const MaterialQueue mq = S->material[TYPE];
-    SlotAllocator<ORDERED> slots;
-    slots.init(S, bounce);
+    SlotAllocator<ORDERED, 2> slots;  // 0: shadow requests, 1: continuation rays
+    int* const ctr[2] = {&C->traceShadowSize[bounce], &C->traceSize[bounce]};
+    slots.init(ctr);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
         const int requestIdx = tile + (int)threadIdx.x;
@@ -378,7 +394,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) shade_ke
             }
 
             if (bounce != (int)S->settings.pathLength) {
-                if (bounce == 1 && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = (int)instanceIdx;
+                if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = (int)instanceIdx;
 
                 float4 color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 if (material.diffuseMapId != -1) {
@@ -414,14 +430,15 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) shade_ke
                 }
             }
         }
-        // slot order within a thread: shadow request first, then the continuation ray (PathTracer.cu:303, 448)
-        const int shadowSlot = slots.alloc(wantShadow, &C->traceShadowSize[bounce], 1);
+        const bool want[2] = {wantShadow, wantTrace};
+        int slot[2];
+        slots.alloc(want, slot);
+        const int shadowSlot = slot[0], traceSlot = slot[1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
             S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
             S->shadow.radiance[shadowSlot] = make_float4(sh.radiance.x, sh.radiance.y, sh.radiance.z, 0.0f);
         }
-        const int traceSlot = slots.alloc(wantTrace, &C->traceSize[bounce], 0);
         if (wantTrace) {
             S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
             S->trace.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
@@ -431,7 +448,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kWideBlock) shade_ke
             }
         }
     }
-    slots.finish(S, bounce);
+    slots.finish();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -452,23 +469,30 @@ NXD uint32_t tonemap_rgba8(f3 c)
     return out | (255u << 24);
 }
 
-// src == nullptr: accumulate this context's own radiance with the device frame number.
+// Running mean over `slices` consecutive frames per pixel, then tonemap.  src == nullptr: this context's own radiance
+// (slices = framesPerPass, the pass's frame numbers); otherwise externally gathered radiance laid out
+// [slices][sliceStride] whose element k belongs to full-image pixel dstMap[k] (nullptr: k), first frame = firstFrame.
 __global__ void __launch_bounds__(kWideBlock) accumulate_kernel(const DeviceState* __restrict__ S, const float4* __restrict__ src, const uint32_t count,
-                                                                 const uint32_t frameOverride, const uint32_t* __restrict__ dstMap)
+                                                                 const uint32_t slicesIn, const uint32_t sliceStrideIn, const uint32_t firstFrameIn,
+                                                                 const uint32_t* __restrict__ dstMap)
 {
-    const uint32_t frame = frameOverride ? frameOverride : S->frame->frameNumber;
     const float4* in = src ? src : S->radiance;
+    const uint32_t slices = src ? slicesIn : S->framesPerPass;
+    const uint32_t sliceStride = src ? sliceStrideIn : S->localCount;
+    const uint32_t firstFrame = src ? firstFrameIn : S->frame->frameNumber - (S->framesPerPass - 1u);
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const float4 r = in[k];
         const uint32_t i = dstMap ? dstMap[k] : k;
-        float4 a;
-        if (frame == 1u) a = make_float4(r.x, r.y, r.z, 0.0f);
-        else {
-            a = S->accumulation[i];
-            const float f = (float)frame;
-            a.x += (r.x - a.x) / f;
-            a.y += (r.y - a.y) / f;
-            a.z += (r.z - a.z) / f;
+        float4 a = firstFrame == 1u ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : S->accumulation[i];
+        for (uint32_t sl = 0; sl < slices; sl++) {
+            const float4 r = in[(size_t)sl * sliceStride + k];
+            const uint32_t frame = firstFrame + sl;
+            if (frame == 1u) a = make_float4(r.x, r.y, r.z, 0.0f);
+            else {
+                const float f = (float)frame;
+                a.x += (r.x - a.x) / f;
+                a.y += (r.y - a.y) / f;
+                a.z += (r.z - a.z) / f;
+            }
         }
         S->accumulation[i] = a;
         S->rgba8[i] = tonemap_rgba8(mk3(a.x, a.y, a.z));

@@ -46,6 +46,8 @@ bool DevBuf::alloc(size_t n)
 
 constexpr int kTraceBlockThreads = 256;
 constexpr int kWideBlockThreads = 256;
+constexpr int kLogicBlockThreads = 1024;
+constexpr int kShadeBlockThreads = 512;
 constexpr int kOrderedBlockThreads = 1024;
 constexpr int kHookBounceSlot = NX_PATH_MAX_LENGTH - 1;  // queue-size slot used by the batch test hooks
 
@@ -95,8 +97,8 @@ static int upload_state(nxhip_ctx* c)
 
 static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
 {
-    const size_t n = std::max<uint32_t>(localCount, 1u);
-    const size_t full = std::max<size_t>((size_t)c->width * c->height, n);
+    const size_t n = (size_t)std::max<uint32_t>(localCount, 1u) * c->framesPerPass;
+    const size_t full = std::max<size_t>((size_t)c->width * c->height, localCount);
     NX_ALLOC(c->throughputPdf, n * 16);
     NX_ALLOC(c->radiance, n * 16);
     NX_ALLOC(c->rayOrigin, n * 16);
@@ -118,8 +120,11 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
     NX_HIP(hipMemsetAsync(c->rgba8.p, 0, full * 4, c->stream));
     NX_HIP(hipMemsetAsync(c->radiance.p, 0, n * 16, c->stream));
     c->localCount = localCount;
+    c->pathCount = localCount * c->framesPerPass;
     DeviceState& h = c->h;
     h.localCount = localCount;
+    h.framesPerPass = c->framesPerPass;
+    h.pathCount = c->pathCount;
     h.throughputPdf = c->throughputPdf.as<float4>();
     h.radiance = c->radiance.as<float4>();
     h.rayOrigin = c->rayOrigin.as<float4>();
@@ -590,9 +595,9 @@ struct Launch {
     const DeviceState* s;
     int bounce;
     const float4* src;
-    uint32_t count, frameOverride;
+    uint32_t count, slices, sliceStride, firstFrame;
     const uint32_t* dstMap;
-    int nargs;  // 1: (S), 2: (S, bounce), 5: accumulate
+    int nargs;  // 1: (S), 2: (S, bounce), 7: accumulate
 };
 
 Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceState* s, int bounce = -1)
@@ -622,9 +627,10 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
-    const int og = ordered ? 1 : wide, ob = ordered ? kOrderedBlockThreads : wideThreads;
+    const int og = ordered ? 1 : 4 * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
+    const int lg = ordered ? 1 : 2 * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
     for (int bounce = 1; bounce <= pathLength; bounce++) {
-        levels.push_back({make_launch(logic_kernel_ptr(ordered), og, ob, NXHIP_K_LOGIC, S, bounce)});
+        levels.push_back({make_launch(logic_kernel_ptr(ordered), lg, lb, NXHIP_K_LOGIC, S, bounce)});
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
         std::vector<Launch> shade;
         shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
@@ -643,12 +649,15 @@ void fill_args(Launch& l, void** args)
 {
     args[0] = (void*)&l.s;
     if (l.nargs == 2) args[1] = (void*)&l.bounce;
-    if (l.nargs == 5) { args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.frameOverride; args[4] = (void*)&l.dstMap; }
+    if (l.nargs == 7) {
+        args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.slices; args[4] = (void*)&l.sliceStride;
+        args[5] = (void*)&l.firstFrame; args[6] = (void*)&l.dstMap;
+    }
 }
 
 int launch_now(nxhip_ctx* c, Launch& l)
 {
-    void* args[5];
+    void* args[8];
     fill_args(l, args);
     KernelTimer* t = nullptr;
     if (c->timingEnabled) {
@@ -677,7 +686,7 @@ static int build_graph(nxhip_ctx* c)
     for (auto& level : levels) {
         std::vector<hipGraphNode_t> cur;
         for (auto& l : level) {
-            void* args[5];
+            void* args[8];
             fill_args(l, args);
             hipKernelNodeParams p;
             std::memset(&p, 0, sizeof p);
@@ -725,17 +734,20 @@ int nxhip_render_frame(nxhip_ctx* c)
         }
         NX_HIP(hipGraphLaunch(c->graphExec, c->stream));
     }
-    c->frameNumber++;
+    c->frameNumber += c->framesPerPass;
     return NXHIP_OK;
 }
 
-static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t frameOverride, const uint32_t* dstMap)
+static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t slices, uint32_t sliceStride, uint32_t firstFrame,
+                             const uint32_t* dstMap)
 {
     Launch l = make_launch(accumulate_kernel_ptr(), c->wideBlocks, kWideBlockThreads, NXHIP_K_ACCUMULATE, c->dState.as<DeviceState>());
-    l.nargs = 5;
+    l.nargs = 7;
     l.src = src;
     l.count = count;
-    l.frameOverride = frameOverride;
+    l.slices = slices;
+    l.sliceStride = sliceStride;
+    l.firstFrame = firstFrame;
     l.dstMap = dstMap;
     const size_t before = c->timerPool.size();
     const int rc = launch_now(c, l);
@@ -749,7 +761,20 @@ int nxhip_accumulate(nxhip_ctx* c)
     NX_HIP(hipSetDevice(c->device));
     const int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, nullptr, c->localCount, 0u, nullptr);
+    return launch_accumulate(c, nullptr, c->localCount, 0u, 0u, 0u, nullptr);
+}
+
+int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
+{
+    NX_CHECK_CTX(c);
+    if (frames == 0 || frames > 64) return fail_invalid("nxhip_set_frames_per_pass: frames must be in [1, 64]");
+    if ((uint64_t)c->localCount * frames > 0x7fffffffull) return fail_invalid("nxhip_set_frames_per_pass: more than 2^31 paths");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    c->framesPerPass = frames;
+    const int rc = alloc_paths(c, c->localCount);
+    if (rc != NXHIP_OK) return rc;
+    return set_frame_number_device(c, 0);
 }
 
 int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
@@ -758,7 +783,7 @@ int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
     if (radianceDevice) {
-        if (capacity < c->localCount) return fail_invalid("nxhip_bind_radiance: buffer smaller than localCount");
+        if (capacity < c->pathCount) return fail_invalid("nxhip_bind_radiance: buffer smaller than localCount * framesPerPass");
         c->h.radiance = static_cast<float4*>(radianceDevice);
     } else {
         c->h.radiance = c->radiance.as<float4>();
@@ -783,19 +808,23 @@ int nxhip_read_full_rgba8(nxhip_ctx* c, uint32_t* dst)
     return NXHIP_OK;
 }
 
-int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uint32_t frameNumber, const void* srcPixelMapDevice)
+int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uint32_t slices, uint32_t sliceStride, uint32_t firstFrame,
+                              const void* srcPixelMapDevice)
 {
     NX_CHECK_CTX(c);
-    if (!src || count == 0 || count > c->width * c->height || frameNumber == 0) return fail_invalid("nxhip_accumulate_external: bad arguments");
+    if (!src || count == 0 || count > c->width * c->height || firstFrame == 0 || slices == 0 || sliceStride < count)
+        return fail_invalid("nxhip_accumulate_external: bad arguments");
     NX_HIP(hipSetDevice(c->device));
     const int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, static_cast<const float4*>(src), count, frameNumber, static_cast<const uint32_t*>(srcPixelMapDevice));
+    return launch_accumulate(c, static_cast<const float4*>(src), count, slices, sliceStride, firstFrame, static_cast<const uint32_t*>(srcPixelMapDevice));
 }
 
 int nxhip_render(nxhip_ctx* c, uint32_t frames)
 {
-    for (uint32_t f = 0; f < frames; f++) {
+    NX_CHECK_CTX(c);
+    if (frames % c->framesPerPass) return fail_invalid("nxhip_render: frames must be a multiple of frames-per-pass");
+    for (uint32_t f = 0; f < frames; f += c->framesPerPass) {
         int rc = nxhip_render_frame(c);
         if (rc != NXHIP_OK) return rc;
         rc = nxhip_accumulate(c);
@@ -822,7 +851,7 @@ static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, 
 int nxhip_read_radiance(nxhip_ctx* c, float* dst)
 {
     NX_CHECK_CTX(c);
-    return read_float4_as_float3(c, c->h.radiance, c->localCount, dst);
+    return read_float4_as_float3(c, c->h.radiance, c->pathCount, dst);
 }
 
 int nxhip_read_accumulation(nxhip_ctx* c, float* dst)
@@ -910,7 +939,7 @@ int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* 
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
     int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    const uint32_t cap = c->localCount;
+    const uint32_t cap = c->pathCount;
     std::vector<float4> o(std::min(cap, count)), d(std::min(cap, count)), h(std::min(cap, count));
     std::vector<uint32_t> hi(std::min(cap, count));
     for (uint32_t first = 0; first < count; first += cap) {
@@ -950,7 +979,7 @@ int nxhip_trace_shadow_batch(nxhip_ctx* c, const nx_ray* rays, const float* tmax
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
     int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    const uint32_t cap = c->localCount;
+    const uint32_t cap = c->pathCount;
     const uint32_t m = std::min(cap, count);
     std::vector<float4> o(m), d(m), rad(m, make_float4(1.0f, 0.0f, 0.0f, 0.0f)), res(m);
     for (uint32_t first = 0; first < count; first += cap) {

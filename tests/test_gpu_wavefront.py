@@ -182,3 +182,28 @@ def test_pixel_query_and_resize(gpu_ctx_factory):
     ctx.accumulate()
     _, want = _render_oracle(scene, 32 * 32, 1, pod.RNG_REFERENCE_SLOT, pod.CONDUCTOR_REFERENCE)
     assert ctx.read_radiance().shape == (32 * 32, 3)
+
+
+def test_frames_per_pass_equals_single_frames(gpu_ctx_factory):
+    """Batching S frames into one pass changes how much work each launch carries, not the result: every frame slice and
+    the accumulated image are bit-identical to S single-frame passes (pixel-keyed RNG)."""
+    W, H, S = 80, 48, 3
+    scene = SH.material_zoo_scene(W, H, path_length=4)
+    a = gpu_ctx_factory(W, H)
+    scene.upload(a)
+    a.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    singles = _render_gpu(a, 2 * S)
+    acc_single = a.read_accumulation()
+    b = gpu_ctx_factory(W, H)
+    scene.upload(b)
+    b.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    b.set_frames_per_pass(S)
+    for p in range(2):
+        b.render_frame()
+        b.accumulate()
+        rad = b.read_radiance().reshape(S, W * H, 3)
+        for s in range(S):
+            assert np.array_equal(rad[s].view(np.uint32), singles[p * S + s].view(np.uint32)), (p, s)
+    assert b.frame_number() == 2 * S
+    assert np.array_equal(b.read_accumulation().view(np.uint32), acc_single.view(np.uint32))
+    assert np.array_equal(b.read_rgba8(), a.read_rgba8())
