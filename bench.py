@@ -270,6 +270,10 @@ def main():
             "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
+            "simd": {"iters_per_ray_lane": round(64.0 * closest["waveIters"] / max(1, closest["rays"]), 2),
+                     "active_frac": round(closest["lanesActive"] / max(1, 64 * closest["waveIters"]), 3),
+                     "node_frac": round(closest["lanesNode"] / max(1, 64 * closest["waveIters"]), 3),
+                     "prim_frac": round(closest["lanesPrim"] / max(1, 64 * closest["waveIters"]), 3)},
             "mrays_per_s": round(closest["rays"] / (kt["trace"]["ms"] * 1e-3) / 1e6, 1) if kt["trace"]["ms"] > 0 else None,
             "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
                        "achieved_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"])) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},

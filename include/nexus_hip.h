@@ -144,6 +144,9 @@ int nxhip_trace_shadow_batch(nxhip_ctx *ctx, const nx_ray *rays, const float *tm
  * the trace kernels run their counting variant; off by default. */
 typedef struct nxhip_trace_stats {
     uint64_t rays, nodes, tris, instances;
+    /* SIMD-efficiency diagnostics: traversal-loop iterations summed over waves, and the number of lanes that were
+     * busy / took a node step / took a primitive step in them (ideal: 64 per iteration). */
+    uint64_t waveIters, lanesActive, lanesNode, lanesPrim;
 } nxhip_trace_stats;
 int nxhip_enable_trace_stats(nxhip_ctx *ctx, int enable);
 int nxhip_read_trace_stats(nxhip_ctx *ctx, nxhip_trace_stats *closest, nxhip_trace_stats *shadow, int reset);

@@ -25,6 +25,17 @@
 
 #include "nexus_pod.h"
 
+// Pointers stored in device-resident structs are global-memory pointers.  Telling the device compiler so
+// (address_space(1)) turns every access through them into global_load/store instead of flat_load/store (a pointer
+// loaded from memory is otherwise "generic" and pays the flat path: LDS-aperture check, both wait counters).
+// The host (and nxhip_api.hip, which only fills the structs) sees plain pointers of the same size; kernel translation
+// units define NX_KERNEL_TU before including this header.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NX_KERNEL_TU)
+#define NX_G __attribute__((address_space(1)))
+#else
+#define NX_G
+#endif
+
 namespace nxd {
 
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with its own L2
@@ -32,10 +43,10 @@ constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;
 
 struct BlasDev {
-    const uint4* nodes;
-    const float4* isect;
-    const nx_triangle* tris;
-    const uint32_t* triIdx;
+    const NX_G uint4* nodes;
+    const NX_G float4* isect;
+    const NX_G nx_triangle* tris;
+    const NX_G uint32_t* triIdx;
     uint32_t nodeCount, triCount;
     uint32_t pad_[2];
 };
@@ -43,31 +54,31 @@ static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
 
 struct __attribute__((aligned(16))) InstTrav {
     float4 r0, r1, r2;  // rows 0..2 of invTransform
-    const uint4* nodes;
-    const float4* isect;
+    const NX_G uint4* nodes;
+    const NX_G float4* isect;
 };
 static_assert(sizeof(InstTrav) == 64, "InstTrav layout");
 
 struct TextureDev {
-    const uint32_t* texels;  // RGBA8, row 0 first
+    const NX_G uint32_t* texels;  // RGBA8, row 0 first
     uint32_t width, height;
 };
 
 struct TraceQueue {
-    float4* rayO;
-    float4* rayD;
-    float4* hit;
-    uint32_t* hitInst;
+    NX_G float4* rayO;
+    NX_G float4* rayD;
+    NX_G float4* hit;
+    NX_G uint32_t* hitInst;
 };
 struct ShadowQueue {
-    float4* rayO;
-    float4* rayD;
-    float4* radiance;
+    NX_G float4* rayO;
+    NX_G float4* rayD;
+    NX_G float4* radiance;
 };
 struct MaterialQueue {
-    float4* hit;
-    float4* dirInst;
-    uint32_t* pixel;
+    NX_G float4* hit;
+    NX_G float4* dirInst;
+    NX_G uint32_t* pixel;
 };
 
 // Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize
@@ -91,20 +102,23 @@ struct FrameState {
 
 struct TraceStatsDev {
     unsigned long long rays, nodes, tris, instances;
+    // SIMD-efficiency diagnostics of the counting variant: loop iterations per wave, and how many lanes were busy /
+    // took the node step / took the primitive step in them
+    unsigned long long waveIters, lanesActive, lanesNode, lanesPrim;
 };
 
 struct DeviceState {
     // scene
-    const uint4* tlasNodes;
-    const uint32_t* tlasInstIdx;
-    const InstTrav* instTrav;
-    const nx_bvh_instance* instances;
-    const BlasDev* blas;
-    const nx_material* materials;
-    const nx_light* lights;
-    const TextureDev* diffuseMaps;
-    const TextureDev* emissiveMaps;
-    const float* srgbLut;  // 256 floats
+    const NX_G uint4* tlasNodes;
+    const NX_G uint32_t* tlasInstIdx;
+    const NX_G InstTrav* instTrav;
+    const NX_G nx_bvh_instance* instances;
+    const NX_G BlasDev* blas;
+    const NX_G nx_material* materials;
+    const NX_G nx_light* lights;
+    const NX_G TextureDev* diffuseMaps;
+    const NX_G TextureDev* emissiveMaps;
+    const NX_G float* srgbLut;  // 256 floats
     TextureDev hdrMap;     // texels == nullptr: flat background
     uint32_t lightCount;
     uint32_t instanceCount;
@@ -117,18 +131,18 @@ struct DeviceState {
     uint32_t localCount;       // pixels rendered by this context
     uint32_t framesPerPass;    // S >= 1
     uint32_t pathCount;        // localCount * framesPerPass
-    const uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
-    float4* throughputPdf;     // rgb throughput, w = lastPdf
-    float4* radiance;
-    float4* rayOrigin;
-    float4* accumulation;
-    uint32_t* rgba8;
+    const NX_G uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
+    NX_G float4* throughputPdf;     // rgb throughput, w = lastPdf
+    NX_G float4* radiance;
+    NX_G float4* rayOrigin;
+    NX_G float4* accumulation;
+    NX_G uint32_t* rgba8;
     TraceQueue trace;
     ShadowQueue shadow;
     MaterialQueue material[4];
-    Counters* counters;
-    FrameState* frame;
-    TraceStatsDev* traceStats;  // [0] closest, [1] shadow
+    NX_G Counters* counters;
+    NX_G FrameState* frame;
+    NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
 };
 
 }  // namespace nxd

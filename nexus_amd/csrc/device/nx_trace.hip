@@ -23,6 +23,7 @@
 //     conflict-free, with a scratch overflow; the world-space ray is re-read from the queue when an
 //     instance is left instead of being kept in 6 VGPRs.
 // No MFMA: this is pointer chasing, bounded by memory latency / bandwidth.
+#define NX_KERNEL_TU 1
 #include "nx_device.h"
 #include "nx_math.h"
 
@@ -33,33 +34,39 @@ constexpr int kLdsDepth = 12;     // stack entries per lane held in LDS (24 KiB 
 constexpr int kSpillDepth = 20;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
 constexpr int kRefillBelow = 40;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
-struct Stack {
-    uint2* lds;  // &ldsStack[tid]
-    uint2 spill[kSpillDepth];
-    int sp;
-    NXD void push(uint2 e)
-    {
-        if (sp < kLdsDepth) lds[sp * kTraceBlock] = e;
-        else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = e;
-        sp++;
+using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
+using GF4 = const NX_G float4*;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;  // one stack entry (uint2) as a 64-bit scalar
+
+// Traversal stack: entries [0, kLdsDepth) live in LDS (entry-major: lane stride 1, depth stride kTraceBlock), the rest in
+// a scratch array.  The stack pointer and the LDS base stay in registers: they are deliberately NOT members of a struct
+// together with the scratch array (a struct holding a dynamically indexed array is kept in scratch as a whole, which
+// turned every push / pop into scratch loads of its own stack pointer).
+NXD void stack_push(lds_u64* lds, uint2* spill, int& sp, uint2 e)
+{
+    if (sp < kLdsDepth) lds[sp * kTraceBlock] = ((unsigned long long)e.y << 32) | e.x;
+    else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = e;
+    sp++;
+}
+NXD uint2 stack_pop(lds_u64* lds, const uint2* spill, int& sp)
+{
+    sp--;
+    if (sp < kLdsDepth) {
+        const unsigned long long v = lds[sp * kTraceBlock];
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     }
-    NXD uint2 pop()
-    {
-        sp--;
-        if (sp < kLdsDepth) return lds[sp * kTraceBlock];
-        if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
-        return make_uint2(0u, 0u);
-    }
-};
+    if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
+    return make_uint2(0u, 0u);
+}
 
 NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
 NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
 NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
 
 // ChildTrace — BVH8Traversal.cuh:55-146
-NXD void child_trace(const uint4* __restrict__ nodes, uint32_t nodeIdx, f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
+NXD void child_trace(GU4 nodes, uint32_t nodeIdx, f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
 {
-    const uint4* n = nodes + (size_t)nodeIdx * 5u;
+    GU4 n = nodes + (size_t)nodeIdx * 5u;
     const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3], n4 = n[4];
 
     const f3 p = mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
@@ -105,17 +112,17 @@ NXD void child_trace(const uint4* __restrict__ nodes, uint32_t nodeIdx, f3 org, 
 template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
-    __shared__ uint2 ldsStack[kLdsDepth * kTraceBlock];
+    __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
 
-    Counters* __restrict__ C = S->counters;
+    NX_G Counters* C = S->counters;
     const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
     if (size <= 0) return;
-    int* heads = ANY_HIT ? C->shadowHead[bounce] : C->traceHead[bounce];
-    const float4* __restrict__ rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
-    const float4* __restrict__ rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
-    const uint4* __restrict__ tlasNodes = S->tlasNodes;
-    const uint32_t* __restrict__ tlasInstIdx = S->tlasInstIdx;
-    const InstTrav* __restrict__ instTrav = S->instTrav;
+    NX_G int* heads = ANY_HIT ? C->shadowHead[bounce] : C->traceHead[bounce];
+    GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
+    GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
+    GU4 tlasNodes = S->tlasNodes;
+    const NX_G uint32_t* tlasInstIdx = S->tlasInstIdx;
+    const NX_G InstTrav* instTrav = S->instTrav;
 
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -125,9 +132,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     int shardsTried = 0;
     bool exhausted = false;
 
-    Stack st;
-    st.lds = &ldsStack[threadIdx.x];
-    st.sp = 0;
+    lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
+    uint2 stackSpill[kSpillDepth];
+    int sp = 0;
 
     bool active = false;
     f3 org = mk3(0.0f), dir = mk3(0.0f), idir = mk3(0.0f);
@@ -136,9 +143,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     uint32_t rayIdx = 0, pixelBits = 0, instIdx = 0, invOct4 = 0;
     int instSp = -1;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
-    const uint4* nodes = tlasNodes;
-    const float4* isect = nullptr;
+    GU4 nodes = tlasNodes;
+    GF4 isect = nullptr;
     unsigned long long nNodes = 0, nTris = 0, nInst = 0, nRays = 0;
+    unsigned long long wIters = 0, wActive = 0, wNode = 0, wPrim = 0;  // lane 0 only (STATS)
 
     for (;;) {
         // ---- refill idle lanes: one atomic per wave and shard
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     invOct4 = (7u - oct) * 0x01010101u;
                     ng = make_uint2(0u, 0x80000000u);
                     tg = make_uint2(0u, 0u);
-                    st.sp = 0;
+                    sp = 0;
                     instSp = -1;
                     nodes = tlasNodes;
                     if (STATS) nRays++;
@@ -186,15 +194,19 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 
         // ---- traverse until too many lanes have run out of work
         do {
+            if (STATS) {
+                wIters++;
+                wActive += __popcll(__ballot(active));
+            }
             // A: acquire work from the stack, or retire the ray
             if (active && tg.y == 0u && (ng.y & 0xff000000u) == 0u) {
-                if (st.sp == 0) {
+                if (sp == 0) {
                     active = false;
                     if (ANY_HIT) {
                         // unoccluded: pathRadiance[pixelIdx] += radiance (BVH8Traversal.cuh:515-516);
                         // at most one shadow ray per pixel and bounce, so no atomic is needed
                         const float4 r = S->shadow.radiance[rayIdx];
-                        float4* dst = &S->radiance[pixelBits];
+                        NX_G float4* dst = &S->radiance[pixelBits];
                         float4 cur = *dst;
                         cur.x += r.x; cur.y += r.y; cur.z += r.z;
                         *dst = cur;
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         S->trace.hitInst[rayIdx] = hitInst;
                     }
                 } else {
-                    if (st.sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
+                    if (sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
                         const float4 o = rayO[rayIdx], d = rayD[rayIdx];
                         org = mk3(o.x, o.y, o.z);
                         dir = mk3(d.x, d.y, d.z);
@@ -211,31 +223,33 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         nodes = tlasNodes;
                         instSp = -1;
                     }
-                    const uint2 e = st.pop();
+                    const uint2 e = stack_pop(stackLds, stackSpill, sp);
                     if (e.y & 0xff000000u) ng = e;
                     else { tg = e; ng = make_uint2(0u, 0u); }
                 }
             }
             // B: one node test
+            if (STATS) wNode += __popcll(__ballot(active && tg.y == 0u && (ng.y & 0xff000000u) != 0u));
             if (active && tg.y == 0u && (ng.y & 0xff000000u) != 0u) {
                 const int nodeOffset = 31 - __clz((int)ng.y);
                 ng.y &= ~(1u << nodeOffset);
-                if (ng.y & 0xff000000u) st.push(ng);
+                if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
                 const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
                 const int rel = __popc(ng.y & ~(0xffffffffu << slot));
                 child_trace(nodes, ng.x + (uint32_t)rel, org, dir, idir, invOct4, hitT, ng, tg);
                 if (STATS) nNodes++;
             }
             // C: one leaf primitive: an instance (TLAS) or a triangle (BLAS)
+            if (STATS) wPrim += __popcll(__ballot(active && tg.y != 0u));
             if (active && tg.y != 0u) {
                 const int off = 31 - __clz((int)tg.y);
                 tg.y &= ~(1u << off);
                 if (instSp < 0) {
                     instIdx = tlasInstIdx[tg.x + (uint32_t)off];
-                    if (tg.y) st.push(tg);
-                    if (ng.y & 0xff000000u) st.push(ng);
-                    instSp = st.sp;
-                    const InstTrav* it = &instTrav[instIdx];
+                    if (tg.y) stack_push(stackLds, stackSpill, sp, tg);
+                    if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+                    instSp = sp;
+                    const NX_G InstTrav* it = &instTrav[instIdx];
                     const float4 r0 = it->r0, r1 = it->r1, r2 = it->r2;
                     nodes = it->nodes;
                     isect = it->isect;
@@ -248,7 +262,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     if (STATS) nInst++;
                 } else {
                     // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
-                    const float4* tp = isect + (size_t)(tg.x + (uint32_t)off) * 3u;
+                    GF4 tp = isect + (size_t)(tg.x + (uint32_t)off) * 3u;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     const f3 p0 = mk3(a.x, a.y, a.z), edge0 = mk3(b.x, b.y, b.z), edge1 = mk3(c.x, c.y, c.z);
                     const f3 rayCrossEdge1 = cross3(dir, edge1);
@@ -285,11 +299,15 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             nInst += __shfl_down(nInst, o);
         }
         if (lane == 0) {
-            TraceStatsDev* ts = &S->traceStats[ANY_HIT ? 1 : 0];
+            NX_G TraceStatsDev* ts = &S->traceStats[ANY_HIT ? 1 : 0];
             atomicAdd(&ts->rays, nRays);
             atomicAdd(&ts->nodes, nNodes);
             atomicAdd(&ts->tris, nTris);
             atomicAdd(&ts->instances, nInst);
+            atomicAdd(&ts->waveIters, wIters);
+            atomicAdd(&ts->lanesActive, wActive);
+            atomicAdd(&ts->lanesNode, wNode);
+            atomicAdd(&ts->lanesPrim, wPrim);
         }
     }
 }

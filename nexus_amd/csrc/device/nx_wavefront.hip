@@ -14,6 +14,7 @@
 //     allocation, outside divergent control flow;
 //   * the frame number lives on the device and is advanced by begin_frame_kernel, so a frame is one
 //     hipGraph replay with no host-side writes in between.
+#define NX_KERNEL_TU 1
 #include "nx_bsdf.h"
 #include "nx_device.h"
 #include "nx_math.h"

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -231,6 +232,10 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel_ptr(true, false), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
         c->shadowBlocks = std::max(1, perCU) * c->numCUs;
         c->wideBlocks = 8 * c->numCUs;
+        if (const char* e = std::getenv("NX_TRACE_BLOCKS_PER_CU")) {  // tuning experiments only
+            const int n = std::atoi(e);
+            if (n >= 1 && n <= 16) c->traceBlocks = c->shadowBlocks = n * c->numCUs;
+        }
     } while (false);
     if (rc != NXHIP_OK) {
         nxhip_destroy(c);
@@ -1020,8 +1025,8 @@ int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace
     NX_HIP(hipStreamSynchronize(c->stream));
     TraceStatsDev h[2];
     NX_HIP(hipMemcpy(h, c->traceStats.p, sizeof h, hipMemcpyDeviceToHost));
-    if (closest) *closest = nxhip_trace_stats{h[0].rays, h[0].nodes, h[0].tris, h[0].instances};
-    if (shadow) *shadow = nxhip_trace_stats{h[1].rays, h[1].nodes, h[1].tris, h[1].instances};
+    if (closest) *closest = nxhip_trace_stats{h[0].rays, h[0].nodes, h[0].tris, h[0].instances, h[0].waveIters, h[0].lanesActive, h[0].lanesNode, h[0].lanesPrim};
+    if (shadow) *shadow = nxhip_trace_stats{h[1].rays, h[1].nodes, h[1].tris, h[1].instances, h[1].waveIters, h[1].lanesActive, h[1].lanesNode, h[1].lanesPrim};
     if (reset) NX_HIP(hipMemset(c->traceStats.p, 0, sizeof h));
     return NXHIP_OK;
 }
