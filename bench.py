@@ -139,6 +139,13 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run with N ranks")
         args.gpus = world
 
+    if world > 1:
+        # torch ships its own libamdhip64 / libhsa-runtime64: import it BEFORE libnexus_amd.so is loaded so that the
+        # library's libamdhip64.so.7 dependency binds to the copy torch already holds (two HIP runtimes in one process
+        # cannot share the device, nor a stream handle).
+        import torch  # noqa: F401
+        import torch.distributed  # noqa: F401
+
     W, H = args.width, args.height
     S = max(1, args.frames_per_pass)
     if args.steps % S or args.warmup % S:
@@ -151,10 +158,22 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        stream = torch.cuda.current_stream().cuda_stream
-        ctx = capi.Context(W, H, device=local_rank, stream=stream)
+        # NX_BENCH_BACKEND=gloo + NX_BENCH_SHARE_GPU=1 rehearse the N > 1 path on a single GPU (tiles staged through
+        # host memory); the real run is one rank per GPU over RCCL ("nccl").
+        backend = os.environ.get("NX_BENCH_BACKEND", "nccl")
+        dev = 0 if os.environ.get("NX_BENCH_SHARE_GPU") else local_rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
+        # One explicit (non-default) torch stream carries everything: the context launches its kernels on it, torch ops
+        # and the collective are ordered on it, so the path needs no host synchronisation between render, gather and
+        # accumulate.  (The default stream's handle is 0, which nxhip_create reads as "make your own stream".)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        assert side.cuda_stream != 0
+        ctx = capi.Context(W, H, device=dev, stream=side.cuda_stream)
     else:
         ctx = capi.Context(W, H, device=0)
     upload(ctx, sc)
@@ -183,7 +202,15 @@ def main():
             first = frame_counter[0] + 1
             frame_counter[0] += S
             # the one collective of the path: radiance tiles -> rank 0 over xGMI
-            dist.gather(rad, gathered if rank == 0 else None, dst=0)
+            if backend == "nccl":
+                dist.gather(rad, gathered if rank == 0 else None, dst=0)
+            else:
+                host = rad.cpu()
+                parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(parts[r])
             if rank == 0:
                 for r in range(world):
                     ctx.accumulate_external(gathered[r].data_ptr(), n_local, first, maps_dev[r].data_ptr(), slices=S, slice_stride=n_local)

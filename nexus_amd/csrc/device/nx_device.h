@@ -38,6 +38,17 @@
 
 namespace nxd {
 
+// Record strides of the device-side BVH arrays, in 16-byte units.  The payload is always 5 / 3 chunks (80-B node, 48-B
+// triangle record); a larger stride pads every record so that it never straddles a 64-B sector / 128-B line.
+#ifndef NX_NODE_STRIDE
+#define NX_NODE_STRIDE 5
+#endif
+#ifndef NX_TRI_STRIDE
+#define NX_TRI_STRIDE 3
+#endif
+constexpr int kNodeStride = NX_NODE_STRIDE;
+constexpr int kTriStride = NX_TRI_STRIDE;
+
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with its own L2
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;

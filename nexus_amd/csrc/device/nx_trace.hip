@@ -14,11 +14,18 @@
 //   * every lane's loop iteration is "pop -> one node test -> one triangle test" so that the 64 lanes
 //     reconverge at the node test and at the triangle test in every iteration (the reference's
 //     `while (triangleEntry.y)` inner loop serialises lanes with long triangle lists on a 64-wide wave);
-//   * an 80-byte node is five 16-byte loads; quantised bounds are converted with v_cvt_f32_ubyteN and the
-//     slab test is 6 v_fma per child + integer max3/min3 on the float bit patterns (identical ordering to
-//     the reference's vmax.s32/vmin.s32 PTX, including its NaN behaviour);
-//   * triangles come from a leaf-ordered 48-byte stream (p0|id, e0, e1) built at upload: three 16-byte
-//     loads and no triangleIdx indirection; instances from a 64-byte traversal record;
+//   * nodes (80 B), triangle records (48 B) and instance records (64 B) are fetched COOPERATIVELY through LDS: the
+//     lanes that need a record publish its address, then the wave's 64 lanes issue direct-to-LDS loads
+//     (global_load_lds_dwordx4) of consecutive 16-byte chunks, so the chunks of one record sit in adjacent lanes
+//     and coalesce into one or two cache-line requests; each owner then reads its record back with ds_read_b128
+//     (bank-conflict free at an 80-byte stride).  A per-lane "5 x dwordx4 from my own node" costs one L1 lookup per
+//     lane and chunk — measured: the trace kernel ran at one VMEM wave-instruction per ~63 cycles per CU whatever the
+//     occupancy, i.e. bound by L1/TA lookups, not by HBM or latency — the cooperative form needs 2-3x fewer;
+//   * quantised bounds are converted with v_cvt_f32_ubyteN and the slab test is 6 v_fma per child + integer
+//     max3/min3 on the float bit patterns (identical ordering to the reference's vmax.s32/vmin.s32 PTX, including
+//     its NaN behaviour);
+//   * triangles come from a leaf-ordered 48-byte stream (p0|id, e0, e1) built at upload: no triangleIdx
+//     indirection; instances from a 64-byte traversal record;
 //   * the traversal stack lives in LDS, entry-major ([depth][lane]) so ds_read/write_b64 are
 //     conflict-free, with a scratch overflow; the world-space ray is re-read from the queue when an
 //     instance is left instead of being kept in 6 VGPRs.
@@ -30,13 +37,45 @@
 namespace nxd {
 
 constexpr int kTraceBlock = 256;  // 4 waves
-constexpr int kLdsDepth = 12;     // stack entries per lane held in LDS (24 KiB per workgroup)
-constexpr int kSpillDepth = 20;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
+constexpr int kLdsDepth = 8;      // stack entries per lane held in LDS (16 KiB per workgroup)
+constexpr int kSpillDepth = 24;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
+constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
 constexpr int kRefillBelow = 40;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
 using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
 using GF4 = const NX_G float4*;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;  // one stack entry (uint2) as a 64-bit scalar
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void g_cvoid;
+
+// Cooperative record fetch (see the header comment).  Must be reached by all lanes of the wave.  `need` lanes get the
+// CHUNKS*16 bytes at `addr` in out[]; waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
+template <int CHUNKS>
+NXD void coop_fetch(bool need, unsigned long long addr, lds_u64* waveAddr, lds_u32* waveStage, int lane, uint4 (&out)[CHUNKS])
+{
+    const unsigned long long mask = __ballot(need);
+    const int total = __popcll(mask) * CHUNKS;
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    // earlier ds_reads of the staging area must have returned before the DMA below may overwrite it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (need) waveAddr[rank] = addr;
+    for (int base = 0; base < total; base += kWave) {
+        const int c = base + lane;
+        if (c < total) {
+            const int r = c / CHUNKS, part = c - r * CHUNKS;
+            const unsigned long long a = waveAddr[r] + (unsigned long long)(part * 16);
+            // lane L of this instruction lands at (waveStage + base*16 bytes) + L*16: chunk c at byte 16*c
+            __builtin_amdgcn_global_load_lds((g_cvoid*)a, (lds_void*)(waveStage + base * 4), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (need) {
+        const lds_u32* rec = waveStage + rank * (CHUNKS * 4);
+#pragma unroll
+        for (int k = 0; k < CHUNKS; k++) out[k] = make_uint4(rec[4 * k + 0], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+    }
+}
 
 // Traversal stack: entries [0, kLdsDepth) live in LDS (entry-major: lane stride 1, depth stride kTraceBlock), the rest in
 // a scratch array.  The stack pointer and the LDS base stay in registers: they are deliberately NOT members of a struct
@@ -64,10 +103,9 @@ NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                
 NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
 
 // ChildTrace — BVH8Traversal.cuh:55-146
-NXD void child_trace(GU4 nodes, uint32_t nodeIdx, f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
+NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
 {
-    GU4 n = nodes + (size_t)nodeIdx * 5u;
-    const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3], n4 = n[4];
+    const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
 
     const f3 p = mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
     const uint32_t e_imask = n0.w;
@@ -113,6 +151,8 @@ template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
+    __shared__ unsigned long long ldsAddr[kTraceBlock];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsStage[kTraceBlock * kMaxChunks * 4];
 
     NX_G Counters* C = S->counters;
     const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
@@ -133,6 +173,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     bool exhausted = false;
 
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
+    const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    lds_u64* const waveAddr = (lds_u64*)&ldsAddr[waveInBlock * kWave];
+    lds_u32* const waveStage = (lds_u32*)&ldsStage[waveInBlock * kWave * kMaxChunks * 4];
     uint2 stackSpill[kSpillDepth];
     int sp = 0;
 
@@ -229,30 +272,48 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 }
             }
             // B: one node test
-            if (STATS) wNode += __popcll(__ballot(active && tg.y == 0u && (ng.y & 0xff000000u) != 0u));
-            if (active && tg.y == 0u && (ng.y & 0xff000000u) != 0u) {
-                const int nodeOffset = 31 - __clz((int)ng.y);
-                ng.y &= ~(1u << nodeOffset);
-                if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
-                const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
-                const int rel = __popc(ng.y & ~(0xffffffffu << slot));
-                child_trace(nodes, ng.x + (uint32_t)rel, org, dir, idir, invOct4, hitT, ng, tg);
-                if (STATS) nNodes++;
+            const bool doNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
+            if (STATS) wNode += __popcll(__ballot(doNode));
+            if (__ballot(doNode)) {
+                unsigned long long nodeAddr = 0ull;
+                if (doNode) {
+                    const int nodeOffset = 31 - __clz((int)ng.y);
+                    ng.y &= ~(1u << nodeOffset);
+                    if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+                    const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
+                    const int rel = __popc(ng.y & ~(0xffffffffu << slot));
+                    nodeAddr = (unsigned long long)(nodes + (size_t)(ng.x + (uint32_t)rel) * (unsigned)kNodeStride);
+                }
+                uint4 nd[5];
+                coop_fetch<5>(doNode, nodeAddr, waveAddr, waveStage, lane, nd);
+                if (doNode) {
+                    child_trace(nd, org, dir, idir, invOct4, hitT, ng, tg);
+                    if (STATS) nNodes++;
+                }
             }
             // C: one leaf primitive: an instance (TLAS) or a triangle (BLAS)
-            if (STATS) wPrim += __popcll(__ballot(active && tg.y != 0u));
-            if (active && tg.y != 0u) {
-                const int off = 31 - __clz((int)tg.y);
-                tg.y &= ~(1u << off);
-                if (instSp < 0) {
+            const bool doPrim = active && tg.y != 0u;
+            const bool doInst = doPrim && instSp < 0, doTri = doPrim && instSp >= 0;
+            if (STATS) wPrim += __popcll(__ballot(doPrim));
+            if (__ballot(doInst)) {
+                unsigned long long recAddr = 0ull;
+                if (doInst) {
+                    const int off = 31 - __clz((int)tg.y);
+                    tg.y &= ~(1u << off);
                     instIdx = tlasInstIdx[tg.x + (uint32_t)off];
                     if (tg.y) stack_push(stackLds, stackSpill, sp, tg);
                     if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
                     instSp = sp;
-                    const NX_G InstTrav* it = &instTrav[instIdx];
-                    const float4 r0 = it->r0, r1 = it->r1, r2 = it->r2;
-                    nodes = it->nodes;
-                    isect = it->isect;
+                    recAddr = (unsigned long long)&instTrav[instIdx];
+                }
+                uint4 rec[4];
+                coop_fetch<4>(doInst, recAddr, waveAddr, waveStage, lane, rec);
+                if (doInst) {
+                    const float4 r0 = make_float4(__uint_as_float(rec[0].x), __uint_as_float(rec[0].y), __uint_as_float(rec[0].z), __uint_as_float(rec[0].w));
+                    const float4 r1 = make_float4(__uint_as_float(rec[1].x), __uint_as_float(rec[1].y), __uint_as_float(rec[1].z), __uint_as_float(rec[1].w));
+                    const float4 r2 = make_float4(__uint_as_float(rec[2].x), __uint_as_float(rec[2].y), __uint_as_float(rec[2].z), __uint_as_float(rec[2].w));
+                    nodes = (GU4)(((unsigned long long)rec[3].y << 32) | rec[3].x);
+                    isect = (GF4)(((unsigned long long)rec[3].w << 32) | rec[3].z);
                     ng = make_uint2(0u, 0x80000000u);
                     tg = make_uint2(0u, 0u);
                     // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264)
@@ -260,11 +321,22 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     dir = mat_vec(r0, r1, r2, dir);
                     idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                     if (STATS) nInst++;
-                } else {
+                }
+            }
+            if (__ballot(doTri)) {
+                unsigned long long triAddr = 0ull;
+                if (doTri) {
+                    const int off = 31 - __clz((int)tg.y);
+                    tg.y &= ~(1u << off);
+                    triAddr = (unsigned long long)(isect + (size_t)(tg.x + (uint32_t)off) * (unsigned)kTriStride);
+                }
+                uint4 tr[3];
+                coop_fetch<3>(doTri, triAddr, waveAddr, waveStage, lane, tr);
+                if (doTri) {
                     // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
-                    GF4 tp = isect + (size_t)(tg.x + (uint32_t)off) * 3u;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    const f3 p0 = mk3(a.x, a.y, a.z), edge0 = mk3(b.x, b.y, b.z), edge1 = mk3(c.x, c.y, c.z);
+                    const f3 p0 = mk3(__uint_as_float(tr[0].x), __uint_as_float(tr[0].y), __uint_as_float(tr[0].z));
+                    const f3 edge0 = mk3(__uint_as_float(tr[1].x), __uint_as_float(tr[1].y), __uint_as_float(tr[1].z));
+                    const f3 edge1 = mk3(__uint_as_float(tr[2].x), __uint_as_float(tr[2].y), __uint_as_float(tr[2].z));
                     const f3 rayCrossEdge1 = cross3(dir, edge1);
                     const float det = dot3(edge0, rayCrossEdge1);
                     const float invDet = 1.0f / det;
@@ -280,7 +352,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                             active = false;  // occluded: nothing to add
                         } else {
                             hitT = t; hitU = u; hitV = v;
-                            hitTri = __float_as_uint(a.w);
+                            hitTri = tr[0].w;
                             hitInst = instIdx;
                         }
                     }

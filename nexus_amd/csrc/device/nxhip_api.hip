@@ -236,6 +236,10 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             const int n = std::atoi(e);
             if (n >= 1 && n <= 16) c->traceBlocks = c->shadowBlocks = n * c->numCUs;
         }
+        if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
+            const int n = std::atoi(e);
+            if (n >= 1 && n <= 65536) c->traceBlocks = c->shadowBlocks = n;
+        }
     } while (false);
     if (rc != NXHIP_OK) {
         nxhip_destroy(c);
@@ -285,6 +289,14 @@ int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
 }
 
 // ---- scene upload -----------------------------------------------------------------------------------
+
+// 80-byte nodes at a stride of kNodeStride 16-byte chunks (5 = packed as uploaded)
+static std::vector<uint4> pad_nodes(const nx_bvh8_node* nodes, uint32_t nodeCount)
+{
+    std::vector<uint4> out((size_t)nodeCount * kNodeStride, make_uint4(0u, 0u, 0u, 0u));
+    for (uint32_t i = 0; i < nodeCount; i++) std::memcpy(&out[(size_t)i * kNodeStride], &nodes[i], sizeof(nx_bvh8_node));
+    return out;
+}
 
 static int refresh_blas_table(nxhip_ctx* c)
 {
@@ -357,21 +369,22 @@ int nxhip_upload_blas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCoun
     b.triCount = triCount;
     // leaf-ordered intersection stream: {p0 | original index}, {edge0}, {edge1}; the edges are the same float
     // subtractions the reference performs per test (Triangle.cuh:55-56), done once here
-    std::vector<float4> isect((size_t)triCount * 3);
+    std::vector<float4> isect((size_t)triCount * kTriStride, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     for (uint32_t k = 0; k < triCount; k++) {
         const uint32_t t = triIdx[k];
         const nx_triangle& tr = tris[t];
         float idBits;
         std::memcpy(&idBits, &t, 4);
-        isect[3 * (size_t)k + 0] = make_float4(tr.pos0[0], tr.pos0[1], tr.pos0[2], idBits);
-        isect[3 * (size_t)k + 1] = make_float4(tr.pos1[0] - tr.pos0[0], tr.pos1[1] - tr.pos0[1], tr.pos1[2] - tr.pos0[2], 0.0f);
-        isect[3 * (size_t)k + 2] = make_float4(tr.pos2[0] - tr.pos0[0], tr.pos2[1] - tr.pos0[1], tr.pos2[2] - tr.pos0[2], 0.0f);
+        isect[kTriStride * (size_t)k + 0] = make_float4(tr.pos0[0], tr.pos0[1], tr.pos0[2], idBits);
+        isect[kTriStride * (size_t)k + 1] = make_float4(tr.pos1[0] - tr.pos0[0], tr.pos1[1] - tr.pos0[1], tr.pos1[2] - tr.pos0[2], 0.0f);
+        isect[kTriStride * (size_t)k + 2] = make_float4(tr.pos2[0] - tr.pos0[0], tr.pos2[1] - tr.pos0[1], tr.pos2[2] - tr.pos0[2], 0.0f);
     }
-    NX_ALLOC(b.nodes, (size_t)nodeCount * sizeof(nx_bvh8_node));
+    std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
+    NX_ALLOC(b.nodes, padded.size() * sizeof(uint4));
     NX_ALLOC(b.isect, isect.size() * sizeof(float4));
     NX_ALLOC(b.tris, (size_t)triCount * sizeof(nx_triangle));
     NX_ALLOC(b.triIdx, (size_t)triCount * 4);
-    NX_HIP(hipMemcpy(b.nodes.p, nodes, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(b.nodes.p, padded.data(), padded.size() * sizeof(uint4), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(b.isect.p, isect.data(), isect.size() * sizeof(float4), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(b.tris.p, tris, (size_t)triCount * sizeof(nx_triangle), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(b.triIdx.p, triIdx, (size_t)triCount * 4, hipMemcpyHostToDevice));
@@ -413,10 +426,11 @@ int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, 
         if (prims && (uint64_t)n.triangleBaseIdx + prims > instanceCount) return fail_invalid("nxhip_set_tlas: leaf range out of range");
     }
     NX_HIP(hipStreamSynchronize(c->stream));
-    NX_ALLOC(c->tlasNodes, (size_t)nodeCount * sizeof(nx_bvh8_node));
+    std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
+    NX_ALLOC(c->tlasNodes, padded.size() * sizeof(uint4));
     NX_ALLOC(c->tlasInstIdx, (size_t)instanceCount * 4);
     NX_ALLOC(c->instances, (size_t)instanceCount * sizeof(nx_bvh_instance));
-    NX_HIP(hipMemcpy(c->tlasNodes.p, nodes, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->tlasNodes.p, padded.data(), padded.size() * sizeof(uint4), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(c->tlasInstIdx.p, instanceIdx, (size_t)instanceCount * 4, hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(c->instances.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
     c->hostInstances.assign(instances, instances + instanceCount);
