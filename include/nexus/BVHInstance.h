@@ -20,6 +20,7 @@ public:
     void SetTransform(float3 pos, float3 rotationDegrees, float3 scale);
     const AABB& GetBounds() const { return m_Bounds; }
     void AssignMaterial(int mIdx) { m_MaterialId = mIdx; }
+    void SetBvh(const BVH8* bvh) { m_Bvh = bvh; }  // the owning vector may have been re-allocated
     int GetMaterialId() const { return m_MaterialId; }
     unsigned int GetBvhIdx() const { return m_BvhIdx; }
     const Mat4& GetTransform() const { return m_Transform; }

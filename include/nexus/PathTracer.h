@@ -1,0 +1,45 @@
+// nexus/PathTracer.h — host driver of the hot path with the reference's interface
+// (/root/reference/Nexus/src/Renderer/PathTracer.h:9-70, PathTracer.cpp:5-317).  Every method maps onto the C-ABI device
+// layer (include/nexus_hip.h) instead of CUDA symbols, kernels and a CUDA graph.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "../nexus_hip.h"
+#include "Scene.h"
+
+namespace nexus {
+
+class PathTracer {
+public:
+    PathTracer(uint32_t width, uint32_t height, int device = 0);
+    ~PathTracer();
+    PathTracer(const PathTracer&) = delete;
+    PathTracer& operator=(const PathTracer&) = delete;
+
+    void Reset();
+    void ResetFrameNumber();
+    void Render(const Scene& scene);  // one frame: generate, trace, pathLength x (logic, shade, trace, shadow), accumulate
+    void OnResize(uint32_t width, uint32_t height);
+    void UpdateDeviceScene(const Scene& scene);
+    void SetPixelQuery(uint32_t x, uint32_t y);
+    int32_t GetSelectedInstance();
+    uint32_t GetFrameNumber() const { return m_FrameNumber; }
+    // The reference hands out a GL pixel buffer; headless here: the RGBA8 image, read back on demand.
+    const std::vector<uint32_t>& GetPixelBuffer();
+    // Extensions (see nexus_pod.h)
+    void SetModes(int rngMode, int compactMode, int conductorMode);
+    nxhip_ctx* GetDeviceContext() const { return m_Ctx; }
+    uint32_t GetWidth() const { return m_ViewportWidth; }
+    uint32_t GetHeight() const { return m_ViewportHeight; }
+
+private:
+    nxhip_ctx* m_Ctx = nullptr;
+    uint32_t m_FrameNumber = 0;
+    uint32_t m_ViewportWidth = 0, m_ViewportHeight = 0;
+    std::vector<uint32_t> m_Pixels;
+    bool m_PixelQueryPending = false;
+};
+
+}  // namespace nexus

@@ -41,6 +41,39 @@ int nxh_instance_init(nx_bvh_instance *out, uint32_t bvhIdx, int32_t materialId,
 int nxh_camera_init(nx_camera *out, const float position[3], const float forward[3], float horizontalFovDeg,
                     uint32_t width, uint32_t height, float focusDist, float defocusAngleDeg);
 
+/* ---- flat view of nexus::Scene / nexus::AssetManager / nexus::PathTracer (include/nexus/Scene.h, PathTracer.h) ------
+ * The call sequence is the reference's: load meshes -> AssetManager::CreateBVH + AddMesh, Scene::CreateMeshInstance,
+ * Scene::Update (TLAS build), PathTracer::UpdateDeviceScene, PathTracer::Render (Renderer/Renderer.cpp:41-77). */
+typedef struct nxs_scene nxs_scene;
+typedef struct nxs_pathtracer nxs_pathtracer;
+struct nxhip_ctx;
+
+const char *nxs_last_error(void);
+int nxs_scene_create(uint32_t width, uint32_t height, nxs_scene **out);
+void nxs_scene_destroy(nxs_scene *s);
+int nxs_scene_add_material(nxs_scene *s, const nx_material *m, int32_t *materialId);
+int nxs_scene_add_texture(nxs_scene *s, int kind /*0 diffuse, 1 emissive*/, const uint8_t *rgba8, uint32_t w, uint32_t h, int32_t *texId);
+int nxs_scene_set_hdr_map(nxs_scene *s, const uint8_t *rgba8, uint32_t w, uint32_t h);
+int nxs_scene_add_mesh(nxs_scene *s, const nx_triangle *tris, uint32_t triCount, int32_t materialId, int32_t *meshId);
+int nxs_scene_create_instance(nxs_scene *s, uint32_t meshId, int32_t materialId, const float pos[3], const float rotDeg[3],
+                              const float scale[3], int32_t *instanceId);
+int nxs_scene_set_camera(nxs_scene *s, const float pos[3], const float forward[3], float horizontalFovDeg, float focusDist,
+                         float defocusAngleDeg);
+int nxs_scene_set_render_settings(nxs_scene *s, const nx_render_settings *settings);
+int nxs_scene_update(nxs_scene *s);
+uint32_t nxs_scene_light_count(const nxs_scene *s);
+uint32_t nxs_scene_instance_count(const nxs_scene *s);
+
+int nxs_pathtracer_create(uint32_t width, uint32_t height, int device, nxs_pathtracer **out);
+void nxs_pathtracer_destroy(nxs_pathtracer *p);
+int nxs_pathtracer_set_modes(nxs_pathtracer *p, int rngMode, int compactMode, int conductorMode);
+int nxs_pathtracer_update_device_scene(nxs_pathtracer *p, nxs_scene *s);
+int nxs_pathtracer_render(nxs_pathtracer *p, nxs_scene *s);
+int nxs_pathtracer_reset_frame_number(nxs_pathtracer *p);
+uint32_t nxs_pathtracer_frame_number(const nxs_pathtracer *p);
+int nxs_pathtracer_read_pixels(nxs_pathtracer *p, uint32_t *rgba8);
+struct nxhip_ctx *nxs_pathtracer_device_context(nxs_pathtracer *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,11 @@ HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
     "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
     "nxh_instance_init", "nxh_camera_init",
+    "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
+    "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
+    "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes",
+    "nxs_pathtracer_update_device_scene", "nxs_pathtracer_render", "nxs_pathtracer_reset_frame_number", "nxs_pathtracer_frame_number",
+    "nxs_pathtracer_read_pixels", "nxs_pathtracer_device_context",
 ]
 
 
@@ -132,6 +137,35 @@ def lib():
     L.nxh_mat4_invert.restype = None
     L.nxh_instance_init.argtypes = [vp, u32, i32, vp, vp]
     L.nxh_camera_init.argtypes = [vp, vp, vp, f32, u32, u32, f32, f32]
+    # Scene / PathTracer facade
+    L.nxs_last_error.restype = C.c_char_p
+    L.nxs_scene_create.argtypes = [u32, u32, C.POINTER(vp)]
+    L.nxs_scene_destroy.argtypes = [vp]
+    L.nxs_scene_destroy.restype = None
+    L.nxs_scene_add_material.argtypes = [vp, vp, C.POINTER(i32)]
+    L.nxs_scene_add_texture.argtypes = [vp, C.c_int, vp, u32, u32, C.POINTER(i32)]
+    L.nxs_scene_set_hdr_map.argtypes = [vp, vp, u32, u32]
+    L.nxs_scene_add_mesh.argtypes = [vp, vp, u32, i32, C.POINTER(i32)]
+    L.nxs_scene_create_instance.argtypes = [vp, u32, i32, vp, vp, vp, C.POINTER(i32)]
+    L.nxs_scene_set_camera.argtypes = [vp, vp, vp, f32, f32, f32]
+    L.nxs_scene_set_render_settings.argtypes = [vp, vp]
+    L.nxs_scene_update.argtypes = [vp]
+    L.nxs_scene_light_count.argtypes = [vp]
+    L.nxs_scene_light_count.restype = u32
+    L.nxs_scene_instance_count.argtypes = [vp]
+    L.nxs_scene_instance_count.restype = u32
+    L.nxs_pathtracer_create.argtypes = [u32, u32, C.c_int, C.POINTER(vp)]
+    L.nxs_pathtracer_destroy.argtypes = [vp]
+    L.nxs_pathtracer_destroy.restype = None
+    L.nxs_pathtracer_set_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.nxs_pathtracer_update_device_scene.argtypes = [vp, vp]
+    L.nxs_pathtracer_render.argtypes = [vp, vp]
+    L.nxs_pathtracer_reset_frame_number.argtypes = [vp]
+    L.nxs_pathtracer_frame_number.argtypes = [vp]
+    L.nxs_pathtracer_frame_number.restype = u32
+    L.nxs_pathtracer_read_pixels.argtypes = [vp, vp]
+    L.nxs_pathtracer_device_context.argtypes = [vp]
+    L.nxs_pathtracer_device_context.restype = vp
     _lib = L
     return L
 
@@ -434,3 +468,125 @@ class Context:
 
 def device_count():
     return int(lib().nxhip_device_count())
+
+
+# ---- C++ Scene / PathTracer facade (include/nexus/Scene.h, PathTracer.h) -------------------------------
+
+def _scheck(rc, what):
+    if rc != 0:
+        msg = lib().nxs_last_error()
+        raise NexusError(f"{what} failed: {msg.decode() if msg else ''}")
+
+
+class Scene:
+    """nexus::Scene + its AssetManager, driven with the reference's call sequence."""
+
+    def __init__(self, width, height):
+        self.L = lib()
+        h = C.c_void_p()
+        _scheck(self.L.nxs_scene_create(width, height, C.byref(h)), "nxs_scene_create")
+        self.h = h
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nxs_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_material(self, mat):
+        m = np.ascontiguousarray(mat, dtype=pod.MAT_DT).reshape(1)
+        i = C.c_int32(-1)
+        _scheck(self.L.nxs_scene_add_material(self.h, _ptr(m), C.byref(i)), "nxs_scene_add_material")
+        return i.value
+
+    def add_texture(self, kind, rgba8):
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        i = C.c_int32(-1)
+        _scheck(self.L.nxs_scene_add_texture(self.h, {"diffuse": 0, "emissive": 1}[kind], _ptr(img), img.shape[1], img.shape[0], C.byref(i)), "nxs_scene_add_texture")
+        return i.value
+
+    def set_hdr_map(self, rgba8):
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        _scheck(self.L.nxs_scene_set_hdr_map(self.h, _ptr(img), img.shape[1], img.shape[0]), "nxs_scene_set_hdr_map")
+
+    def add_mesh(self, tris, material_id=-1):
+        t = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+        i = C.c_int32(-1)
+        _scheck(self.L.nxs_scene_add_mesh(self.h, _ptr(t), len(t), material_id, C.byref(i)), "nxs_scene_add_mesh")
+        return i.value
+
+    def create_instance(self, mesh_id, material_id, position=(0, 0, 0), rotation_deg=(0, 0, 0), scale=(1, 1, 1)):
+        p, r, s = (np.asarray(x, np.float32) for x in (position, rotation_deg, scale))
+        i = C.c_int32(-1)
+        _scheck(self.L.nxs_scene_create_instance(self.h, mesh_id, material_id, _ptr(p), _ptr(r), _ptr(s), C.byref(i)), "nxs_scene_create_instance")
+        return i.value
+
+    def set_camera(self, position, forward, hfov_deg, focus_dist=5.0, defocus_deg=0.0):
+        p, f = np.asarray(position, np.float32), np.asarray(forward, np.float32)
+        _scheck(self.L.nxs_scene_set_camera(self.h, _ptr(p), _ptr(f), hfov_deg, focus_dist, defocus_deg), "nxs_scene_set_camera")
+
+    def set_render_settings(self, st):
+        st = np.ascontiguousarray(st, dtype=pod.SETTINGS_DT).reshape(1)
+        _scheck(self.L.nxs_scene_set_render_settings(self.h, _ptr(st)), "nxs_scene_set_render_settings")
+
+    def update(self):
+        _scheck(self.L.nxs_scene_update(self.h), "nxs_scene_update")
+
+    def light_count(self):
+        return int(self.L.nxs_scene_light_count(self.h))
+
+    def instance_count(self):
+        return int(self.L.nxs_scene_instance_count(self.h))
+
+
+class PathTracer:
+    """nexus::PathTracer: Render(scene) = one frame through the device layer + accumulate."""
+
+    def __init__(self, width, height, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _scheck(self.L.nxs_pathtracer_create(width, height, device, C.byref(h)), "nxs_pathtracer_create")
+        self.h = h
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nxs_pathtracer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_modes(self, rng_mode, compact_mode, conductor_mode):
+        _scheck(self.L.nxs_pathtracer_set_modes(self.h, rng_mode, compact_mode, conductor_mode), "nxs_pathtracer_set_modes")
+
+    def update_device_scene(self, scene):
+        _scheck(self.L.nxs_pathtracer_update_device_scene(self.h, scene.h), "nxs_pathtracer_update_device_scene")
+
+    def render(self, scene):
+        _scheck(self.L.nxs_pathtracer_render(self.h, scene.h), "nxs_pathtracer_render")
+
+    def reset_frame_number(self):
+        _scheck(self.L.nxs_pathtracer_reset_frame_number(self.h), "nxs_pathtracer_reset_frame_number")
+
+    def frame_number(self):
+        return int(self.L.nxs_pathtracer_frame_number(self.h))
+
+    def read_pixels(self):
+        out = np.zeros(self.width * self.height, np.uint32)
+        _scheck(self.L.nxs_pathtracer_read_pixels(self.h, _ptr(out)), "nxs_pathtracer_read_pixels")
+        return out
+
+    def read_radiance(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        check(self.L.nxhip_read_radiance(self.L.nxs_pathtracer_device_context(self.h), _ptr(out)), "nxhip_read_radiance")
+        return out

@@ -1,0 +1,152 @@
+// nexus_scene_capi.cpp — flat C wrappers over nexus::Scene / nexus::PathTracer (see include/nexus_host.h).
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "nexus/PathTracer.h"
+#include "nexus/Scene.h"
+#include "nexus_host.h"
+
+using namespace nexus;
+
+struct nxs_scene {
+    Scene scene;
+    nxs_scene(uint32_t w, uint32_t h) : scene(w, h) {}
+};
+struct nxs_pathtracer {
+    PathTracer pt;
+    nxs_pathtracer(uint32_t w, uint32_t h, int dev) : pt(w, h, dev) {}
+};
+
+namespace {
+thread_local std::string g_err;
+template <typename F> int guarded(F&& f)
+{
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* nxs_last_error(void) { return g_err.c_str(); }
+
+int nxs_scene_create(uint32_t width, uint32_t height, nxs_scene** out)
+{
+    return guarded([&] { *out = new nxs_scene(width, height); });
+}
+void nxs_scene_destroy(nxs_scene* s) { delete s; }
+
+int nxs_scene_add_material(nxs_scene* s, const nx_material* m, int32_t* materialId)
+{
+    return guarded([&] {
+        Material mat;
+        std::memcpy(static_cast<nx_material*>(&mat), m, sizeof(nx_material));
+        const int id = s->scene.GetAssetManager().AddMaterial(mat);
+        if (materialId) *materialId = id;
+    });
+}
+
+int nxs_scene_add_texture(nxs_scene* s, int kind, const uint8_t* rgba8, uint32_t w, uint32_t h, int32_t* texId)
+{
+    return guarded([&] {
+        Texture t(w, h, 4, rgba8);
+        t.type = kind == 1 ? Texture::Type::EMISSIVE : Texture::Type::DIFFUSE;
+        const int id = s->scene.GetAssetManager().AddTexture(t);
+        if (texId) *texId = id;
+    });
+}
+
+int nxs_scene_set_hdr_map(nxs_scene* s, const uint8_t* rgba8, uint32_t w, uint32_t h)
+{
+    return guarded([&] { s->scene.AddHDRMap(Texture(w, h, 4, rgba8)); });
+}
+
+int nxs_scene_add_mesh(nxs_scene* s, const nx_triangle* tris, uint32_t triCount, int32_t materialId, int32_t* meshId)
+{
+    return guarded([&] {
+        std::vector<Triangle> v;
+        v.reserve(triCount);
+        for (uint32_t i = 0; i < triCount; i++) v.emplace_back(tris[i]);
+        AssetManager& am = s->scene.GetAssetManager();
+        const int32_t bvhId = am.CreateBVH(v);
+        const int32_t id = am.AddMesh(Mesh("mesh" + std::to_string(bvhId), bvhId, materialId));
+        if (meshId) *meshId = id;
+    });
+}
+
+int nxs_scene_create_instance(nxs_scene* s, uint32_t meshId, int32_t materialId, const float pos[3], const float rotDeg[3], const float scale[3],
+                              int32_t* instanceId)
+{
+    return guarded([&] {
+        MeshInstance& mi = s->scene.CreateMeshInstance(meshId);
+        mi.AssignMaterial(materialId);
+        mi.SetTransform(make_float3(pos), make_float3(rotDeg), make_float3(scale));
+        if (instanceId) *instanceId = static_cast<int32_t>(s->scene.GetMeshInstances().size()) - 1;
+    });
+}
+
+int nxs_scene_set_camera(nxs_scene* s, const float pos[3], const float forward[3], float hfov, float focusDist, float defocusAngle)
+{
+    return guarded([&] {
+        Camera& c = *s->scene.GetCamera();
+        c.LookAt(make_float3(pos), make_float3(forward));
+        c.SetHorizontalFOV(hfov);
+        c.GetFocusDist() = focusDist;
+        c.GetDefocusAngle() = defocusAngle;
+    });
+}
+
+int nxs_scene_set_render_settings(nxs_scene* s, const nx_render_settings* settings)
+{
+    return guarded([&] {
+        std::memcpy(&s->scene.GetRenderSettings(), settings, sizeof(nx_render_settings));
+        s->scene.Invalidate();
+    });
+}
+
+int nxs_scene_update(nxs_scene* s)
+{
+    return guarded([&] { s->scene.Update(); });
+}
+
+uint32_t nxs_scene_light_count(const nxs_scene* s) { return static_cast<uint32_t>(s->scene.GetLights().size()); }
+uint32_t nxs_scene_instance_count(const nxs_scene* s) { return static_cast<uint32_t>(s->scene.GetBVHInstances().size()); }
+
+int nxs_pathtracer_create(uint32_t width, uint32_t height, int device, nxs_pathtracer** out)
+{
+    return guarded([&] { *out = new nxs_pathtracer(width, height, device); });
+}
+void nxs_pathtracer_destroy(nxs_pathtracer* p) { delete p; }
+int nxs_pathtracer_set_modes(nxs_pathtracer* p, int rngMode, int compactMode, int conductorMode)
+{
+    return guarded([&] { p->pt.SetModes(rngMode, compactMode, conductorMode); });
+}
+int nxs_pathtracer_update_device_scene(nxs_pathtracer* p, nxs_scene* s)
+{
+    return guarded([&] { p->pt.UpdateDeviceScene(s->scene); });
+}
+int nxs_pathtracer_render(nxs_pathtracer* p, nxs_scene* s)
+{
+    return guarded([&] { p->pt.Render(s->scene); });
+}
+int nxs_pathtracer_reset_frame_number(nxs_pathtracer* p)
+{
+    return guarded([&] { p->pt.ResetFrameNumber(); });
+}
+uint32_t nxs_pathtracer_frame_number(const nxs_pathtracer* p) { return p->pt.GetFrameNumber(); }
+int nxs_pathtracer_read_pixels(nxs_pathtracer* p, uint32_t* rgba8)
+{
+    return guarded([&] {
+        const std::vector<uint32_t>& px = p->pt.GetPixelBuffer();
+        std::memcpy(rgba8, px.data(), px.size() * 4);
+    });
+}
+struct nxhip_ctx* nxs_pathtracer_device_context(nxs_pathtracer* p) { return p->pt.GetDeviceContext(); }
+
+}  // extern "C"

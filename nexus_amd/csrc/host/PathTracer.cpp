@@ -1,0 +1,123 @@
+// PathTracer.cpp — see include/nexus/PathTracer.h.  Where the reference binds CUDA symbols, allocates queues and replays a
+// CUDA graph (/root/reference/Nexus/src/Renderer/PathTracer.cpp:5-317), this class forwards to the C-ABI device layer.
+#include "nexus/PathTracer.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace nexus {
+
+namespace {
+void Check(int rc, const char* what)
+{
+    if (rc != NXHIP_OK) throw std::runtime_error(std::string(what) + ": " + nxhip_last_error());
+}
+}  // namespace
+
+PathTracer::PathTracer(uint32_t width, uint32_t height, int device) : m_ViewportWidth(width), m_ViewportHeight(height)
+{
+    Check(nxhip_create(device, width, height, nullptr, &m_Ctx), "nxhip_create");
+}
+
+PathTracer::~PathTracer() { nxhip_destroy(m_Ctx); }
+
+void PathTracer::Reset()
+{
+    Check(nxhip_resize(m_Ctx, m_ViewportWidth, m_ViewportHeight), "nxhip_resize");
+    m_FrameNumber = 0;
+}
+
+void PathTracer::ResetFrameNumber()
+{
+    m_FrameNumber = 0;
+    Check(nxhip_reset_frame_number(m_Ctx), "nxhip_reset_frame_number");
+}
+
+void PathTracer::OnResize(uint32_t width, uint32_t height)
+{
+    if ((m_ViewportWidth != width || m_ViewportHeight != height) && width != 0 && height != 0) {
+        m_ViewportWidth = width;
+        m_ViewportHeight = height;
+        Reset();
+    }
+}
+
+void PathTracer::SetModes(int rngMode, int compactMode, int conductorMode) { Check(nxhip_set_modes(m_Ctx, rngMode, compactMode, conductorMode), "nxhip_set_modes"); }
+
+void PathTracer::UpdateDeviceScene(const Scene& scene)
+{
+    const AssetManager& assets = scene.GetAssetManager();
+    AssetManager& mutableAssets = const_cast<AssetManager&>(assets);
+    // BLAS k of the device == BVH k of the asset manager (instances carry the *mesh* id, whose bvhId the reference assumes
+    // equal: Scene.cpp:69)
+    const std::vector<BVH8>& bvhs = assets.GetBVHs();
+    for (size_t i = assets.uploadedBvhs; i < bvhs.size(); i++) {
+        std::vector<nx_triangle> tris(bvhs[i].triangles.size());
+        for (size_t t = 0; t < tris.size(); t++) tris[t] = Triangle::ToDevice(bvhs[i].triangles[t]);
+        int32_t id = -1;
+        Check(nxhip_upload_blas(m_Ctx, bvhs[i].nodes.data(), static_cast<uint32_t>(bvhs[i].nodes.size()), tris.data(), static_cast<uint32_t>(tris.size()),
+                                bvhs[i].triangleIdx.data(), &id), "nxhip_upload_blas");
+        mutableAssets.GetBVHs()[i].deviceBlasId = id;
+        mutableAssets.uploadedBvhs = i + 1;
+    }
+    if (assets.texturesDirty) {
+        Check(nxhip_clear_textures(m_Ctx), "nxhip_clear_textures");
+        for (const Texture& t : assets.GetDiffuseMaps()) Check(nxhip_upload_texture(m_Ctx, 0, t.pixels.data(), t.width, t.height, nullptr), "nxhip_upload_texture");
+        for (const Texture& t : assets.GetEmissiveMaps()) Check(nxhip_upload_texture(m_Ctx, 1, t.pixels.data(), t.width, t.height, nullptr), "nxhip_upload_texture");
+        if (!scene.GetHDRMap().pixels.empty()) Check(nxhip_upload_texture(m_Ctx, 2, scene.GetHDRMap().pixels.data(), scene.GetHDRMap().width, scene.GetHDRMap().height, nullptr), "nxhip_upload_texture");
+        mutableAssets.texturesDirty = false;
+        scene.hdrDirty = false;
+    } else if (scene.hdrDirty) {
+        Check(nxhip_upload_texture(m_Ctx, 2, scene.GetHDRMap().pixels.data(), scene.GetHDRMap().width, scene.GetHDRMap().height, nullptr), "nxhip_upload_texture");
+        scene.hdrDirty = false;
+    }
+    if (assets.materialsDirty && !assets.GetMaterials().empty()) {
+        Check(nxhip_set_materials(m_Ctx, assets.GetMaterials().data(), static_cast<uint32_t>(assets.GetMaterials().size())), "nxhip_set_materials");
+        mutableAssets.materialsDirty = false;
+    }
+    if (scene.tlasDirty && scene.GetTLAS() && !scene.GetTLAS()->bvh8.nodes.empty()) {
+        const TLAS& tlas = *scene.GetTLAS();
+        std::vector<nx_bvh_instance> inst(tlas.bvhInstances.size());
+        for (size_t i = 0; i < inst.size(); i++) inst[i] = BVHInstance::ToDevice(tlas.bvhInstances[i]);
+        Check(nxhip_set_tlas(m_Ctx, tlas.bvh8.nodes.data(), static_cast<uint32_t>(tlas.bvh8.nodes.size()), tlas.bvh8.triangleIdx.data(), inst.data(),
+                             static_cast<uint32_t>(inst.size())), "nxhip_set_tlas");
+        scene.tlasDirty = false;
+    }
+    if (scene.lightsDirty) {
+        Check(nxhip_set_lights(m_Ctx, scene.GetLights().data(), static_cast<uint32_t>(scene.GetLights().size())), "nxhip_set_lights");
+        scene.lightsDirty = false;
+    }
+    const nx_camera cam = Camera::ToDevice(*scene.GetCamera());
+    Check(nxhip_set_camera(m_Ctx, &cam), "nxhip_set_camera");
+    Check(nxhip_set_render_settings(m_Ctx, reinterpret_cast<const nx_render_settings*>(&scene.GetRenderSettings())), "nxhip_set_render_settings");
+}
+
+void PathTracer::Render(const Scene&)
+{
+    m_FrameNumber++;
+    Check(nxhip_render_frame(m_Ctx), "nxhip_render_frame");
+    Check(nxhip_accumulate(m_Ctx), "nxhip_accumulate");
+}
+
+void PathTracer::SetPixelQuery(uint32_t x, uint32_t y)
+{
+    Check(nxhip_set_pixel_query(m_Ctx, x, y), "nxhip_set_pixel_query");
+    m_PixelQueryPending = true;
+}
+
+int32_t PathTracer::GetSelectedInstance()
+{
+    int32_t idx = -1;
+    Check(nxhip_get_selected_instance(m_Ctx, &idx), "nxhip_get_selected_instance");
+    m_PixelQueryPending = false;
+    return idx;
+}
+
+const std::vector<uint32_t>& PathTracer::GetPixelBuffer()
+{
+    m_Pixels.resize(static_cast<size_t>(m_ViewportWidth) * m_ViewportHeight);
+    Check(nxhip_read_rgba8(m_Ctx, m_Pixels.data()), "nxhip_read_rgba8");
+    return m_Pixels;
+}
+
+}  // namespace nexus
