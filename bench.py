@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
     ap.add_argument("--nv", type=int, default=512)
     ap.add_argument("--frames-per-pass", type=int, default=4, help="frames batched into one wavefront pass (steps must be a multiple)")
+    ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -180,6 +181,8 @@ def main():
 
     if world > 1:
         pm = tile_pixel_map(W, H, rank, world)
+        if args.pixel_order == "tiles":
+            pm = multigpu.tiled_order(pm, W)
         ctx.set_pixel_map(pm)
         ctx.set_frames_per_pass(S)
         n_local = len(pm)
@@ -191,6 +194,8 @@ def main():
             seen = np.zeros(W * H, dtype=bool)
             for r in range(world):
                 m = tile_pixel_map(W, H, r, world)
+                if args.pixel_order == "tiles":
+                    m = multigpu.tiled_order(m, W)
                 assert len(m) == n_local and not seen[m].any()
                 seen[m] = True
                 maps_dev.append(torch.from_numpy(m.astype(np.int64)).to("cuda").to(torch.int32))
@@ -220,6 +225,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
     else:
+        if args.pixel_order == "tiles":
+            ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
         ctx.set_frames_per_pass(S)
 
         def step():
@@ -262,7 +269,7 @@ def main():
                         % (sc["triangles"], sc["bvh8_nodes"], W, H, args.path_length),
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, one RCCL gather per frame" % (world, TILE_ROWS),
             "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of %d frames" % S,
-            "frames_per_pass": S,
+            "frames_per_pass": S, "pixel_order": args.pixel_order,
             "host_bvh_build_s": round(sc["t_build"], 2),
         },
     }
@@ -300,7 +307,10 @@ def main():
             "simd": {"iters_per_ray_lane": round(64.0 * closest["waveIters"] / max(1, closest["rays"]), 2),
                      "active_frac": round(closest["lanesActive"] / max(1, 64 * closest["waveIters"]), 3),
                      "node_frac": round(closest["lanesNode"] / max(1, 64 * closest["waveIters"]), 3),
-                     "prim_frac": round(closest["lanesPrim"] / max(1, 64 * closest["waveIters"]), 3)},
+                     "prim_frac": round(closest["lanesPrim"] / max(1, 64 * closest["waveIters"]), 3),
+                     "cycle_share": dict(zip(["refill", "pop_retire", "node_fetch", "node_decode", "instance", "triangle"],
+                                             [round(c / max(1, sum(closest["cycles"])), 3) for c in closest["cycles"][:6]])),
+                     "cycles_per_wave_iter": round(sum(closest["cycles"]) / max(1, closest["waveIters"]), 1)},
             "mrays_per_s": round(closest["rays"] / (kt["trace"]["ms"] * 1e-3) / 1e6, 1) if kt["trace"]["ms"] > 0 else None,
             "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
                        "achieved_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"])) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
@@ -318,7 +328,13 @@ def main():
     if rank == 0 and args.png:
         from nexus_amd import imageio
 
-        img = ctx.read_full_rgba8() if world > 1 else ctx.read_rgba8()
+        if world > 1:
+            img = ctx.read_full_rgba8()
+        elif args.pixel_order == "tiles":
+            img = np.zeros(W * H, np.uint32)
+            img[multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)] = ctx.read_rgba8()
+        else:
+            img = ctx.read_rgba8()
         imageio.write_png(args.png, img, W, H)
 
     if rank == 0:

@@ -147,6 +147,9 @@ typedef struct nxhip_trace_stats {
     /* SIMD-efficiency diagnostics: traversal-loop iterations summed over waves, and the number of lanes that were
      * busy / took a node step / took a primitive step in them (ideal: 64 per iteration). */
     uint64_t waveIters, lanesActive, lanesNode, lanesPrim;
+    /* shader-clock cycles per loop section summed over waves: 0 refill, 1 pop/retire, 2 node select+fetch, 3 node
+     * decode, 4 instance entry, 5 triangle fetch+test, 6-7 unused */
+    uint64_t cycles[8];
 } nxhip_trace_stats;
 int nxhip_enable_trace_stats(nxhip_ctx *ctx, int enable);
 int nxhip_read_trace_stats(nxhip_ctx *ctx, nxhip_trace_stats *closest, nxhip_trace_stats *shadow, int reset);

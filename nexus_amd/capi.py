@@ -48,10 +48,12 @@ class QueueSizes(C.Structure):
 
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("instances", C.c_uint64),
-                ("waveIters", C.c_uint64), ("lanesActive", C.c_uint64), ("lanesNode", C.c_uint64), ("lanesPrim", C.c_uint64)]
+                ("waveIters", C.c_uint64), ("lanesActive", C.c_uint64), ("lanesNode", C.c_uint64), ("lanesPrim", C.c_uint64), ("cycles", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "cycles"}
+        d["cycles"] = [int(x) for x in self.cycles]
+        return d
 
 
 class KernelTimes(C.Structure):

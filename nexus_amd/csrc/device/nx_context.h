@@ -79,6 +79,7 @@ struct nxhip_ctx {
     nxd::DevBuf blasTable;
     nxd::DevBuf tlasNodes, tlasInstIdx, instTrav, instances;
     std::vector<nx_bvh_instance> hostInstances;
+    std::vector<uint32_t> hostInstIdx;  // TLAS leaf order
     nxd::DevBuf materials, lights;
     std::vector<nxd::TextureHost> diffuseMaps, emissiveMaps;
     nxd::TextureHost hdrMap;

@@ -63,12 +63,16 @@ struct BlasDev {
 };
 static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
 
+// Traversal record of one TLAS leaf, stored in TLAS *leaf order* (entry k belongs to tlasInstIdx[k]) so that entering an
+// instance is one 80-byte fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id.
 struct __attribute__((aligned(16))) InstTrav {
     float4 r0, r1, r2;  // rows 0..2 of invTransform
     const NX_G uint4* nodes;
     const NX_G float4* isect;
+    uint32_t instIdx;
+    uint32_t pad_[3];
 };
-static_assert(sizeof(InstTrav) == 64, "InstTrav layout");
+static_assert(sizeof(InstTrav) == 80, "InstTrav layout");
 
 struct TextureDev {
     const NX_G uint32_t* texels;  // RGBA8, row 0 first
@@ -116,6 +120,9 @@ struct TraceStatsDev {
     // SIMD-efficiency diagnostics of the counting variant: loop iterations per wave, and how many lanes were busy /
     // took the node step / took the primitive step in them
     unsigned long long waveIters, lanesActive, lanesNode, lanesPrim;
+    // shader-clock cycles per section of the traversal loop, summed over waves (counting variant only):
+    // 0 refill, 1 pop/retire, 2 node select+fetch, 3 node decode, 4 instance entry, 5 triangle fetch+test, 6 rest
+    unsigned long long cycles[8];
 };
 
 struct DeviceState {

@@ -11,9 +11,10 @@
 //     XCD and its private 4 MiB L2): waves of one XCD walk one band of the image / queue so the BVH
 //     subtrees they touch stay in that XCD's L2, and the head word is not hammered by 256 CUs; a wave
 //     whose shard runs dry steals from the next one;
-//   * every lane's loop iteration is "pop -> one node test -> one triangle test" so that the 64 lanes
-//     reconverge at the node test and at the triangle test in every iteration (the reference's
-//     `while (triangleEntry.y)` inner loop serialises lanes with long triangle lists on a 64-wide wave);
+//   * every lane's loop iteration is "pop if out of work -> fetch ONE record (node, instance or triangle) -> process
+//     it": the three fetch kinds of a wave are issued together and waited for once, so an iteration has a single
+//     memory round trip, and the 64 lanes reconverge at every stage (the reference's `while (triangleEntry.y)` inner
+//     loop serialises lanes with long triangle lists on a 64-wide wave).  Per-ray visiting order is unchanged;
 //   * nodes (80 B), triangle records (48 B) and instance records (64 B) are fetched COOPERATIVELY through LDS: the
 //     lanes that need a record publish its address, then the wave's 64 lanes issue direct-to-LDS loads
 //     (global_load_lds_dwordx4) of consecutive 16-byte chunks, so the chunks of one record sit in adjacent lanes
@@ -40,7 +41,10 @@ constexpr int kTraceBlock = 256;  // 4 waves
 constexpr int kLdsDepth = 8;      // stack entries per lane held in LDS (16 KiB per workgroup)
 constexpr int kSpillDepth = 24;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
 constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
-constexpr int kRefillBelow = 40;  // refill idle lanes when fewer than this many of the 64 are still traversing
+#ifndef NX_REFILL_BELOW
+#define NX_REFILL_BELOW 40
+#endif
+constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
 using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
 using GF4 = const NX_G float4*;
@@ -49,31 +53,43 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void g_cvoid;
 
-// Cooperative record fetch (see the header comment).  Must be reached by all lanes of the wave.  `need` lanes get the
-// CHUNKS*16 bytes at `addr` in out[]; waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
-template <int CHUNKS>
-NXD void coop_fetch(bool need, unsigned long long addr, lds_u64* waveAddr, lds_u32* waveStage, int lane, uint4 (&out)[CHUNKS])
+// Cooperative record fetch (see the header comment), ONE per loop iteration for all three record kinds.  Must be reached
+// by all lanes of the wave.  Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
+// publish `addr`; the wave's lanes then stream every requested record into waveStage with direct-to-LDS loads of
+// consecutive 16-byte chunks (5-chunk records first, then 3-chunk ones) and each requester reads its record back.
+// waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
+NXD void coop_fetch(bool kind5, bool kind3, unsigned long long addr, lds_u64* waveAddr, lds_u32* waveStage, int lane, uint4 (&out)[5])
 {
-    const unsigned long long mask = __ballot(need);
-    const int total = __popcll(mask) * CHUNKS;
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const unsigned long long mask5 = __ballot(kind5), mask3 = __ballot(kind3);
+    const int n5 = __popcll(mask5), n3 = __popcll(mask3);
+    const int rank5 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask5 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask5, 0u));
+    const int rank3 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask3, 0u));
+    const int total5 = n5 * 5, total = total5 + n3 * 3;
+    const int rec = kind5 ? rank5 : n5 + rank3;                       // slot in the address table
+    const int firstChunk = kind5 ? rank5 * 5 : total5 + rank3 * 3;    // where this lane's record lands
     // earlier ds_reads of the staging area must have returned before the DMA below may overwrite it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (need) waveAddr[rank] = addr;
+    if (kind5 || kind3) waveAddr[rec] = addr;
     for (int base = 0; base < total; base += kWave) {
         const int c = base + lane;
         if (c < total) {
-            const int r = c / CHUNKS, part = c - r * CHUNKS;
+            int r, part;
+            if (c < total5) { r = c / 5; part = c - r * 5; }
+            else { const int d = c - total5; const int q = d / 3; r = n5 + q; part = d - q * 3; }
             const unsigned long long a = waveAddr[r] + (unsigned long long)(part * 16);
             // lane L of this instruction lands at (waveStage + base*16 bytes) + L*16: chunk c at byte 16*c
             __builtin_amdgcn_global_load_lds((g_cvoid*)a, (lds_void*)(waveStage + base * 4), 16, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (need) {
-        const lds_u32* rec = waveStage + rank * (CHUNKS * 4);
+    if (kind5 || kind3) {
+        const lds_u32* p = waveStage + firstChunk * 4;
 #pragma unroll
-        for (int k = 0; k < CHUNKS; k++) out[k] = make_uint4(rec[4 * k + 0], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+        for (int k = 0; k < 3; k++) out[k] = make_uint4(p[4 * k + 0], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
+        if (kind5) {
+#pragma unroll
+            for (int k = 3; k < 5; k++) out[k] = make_uint4(p[4 * k + 0], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
+        }
     }
 }
 
@@ -161,7 +177,6 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
     GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
     GU4 tlasNodes = S->tlasNodes;
-    const NX_G uint32_t* tlasInstIdx = S->tlasInstIdx;
     const NX_G InstTrav* instTrav = S->instTrav;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -185,11 +200,15 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     uint32_t hitTri = 0xffffffffu, hitInst = 0xffffffffu;
     uint32_t rayIdx = 0, pixelBits = 0, instIdx = 0, invOct4 = 0;
     int instSp = -1;
+    bool xformed = false;  // the current instance's inverse transform is not the identity: the world ray must be restored on exit
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     GU4 nodes = tlasNodes;
     GF4 isect = nullptr;
     unsigned long long nNodes = 0, nTris = 0, nInst = 0, nRays = 0;
     unsigned long long wIters = 0, wActive = 0, wNode = 0, wPrim = 0;  // lane 0 only (STATS)
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tPrev = STATS ? (unsigned long long)clock64() : 0ull;
+#define NX_STAMP(k) do { if (STATS) { const unsigned long long tNow = (unsigned long long)clock64(); cyc[k] += tNow - tPrev; tPrev = tNow; } } while (0)
 
     for (;;) {
         // ---- refill idle lanes: one atomic per wave and shard
@@ -223,6 +242,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     tg = make_uint2(0u, 0u);
                     sp = 0;
                     instSp = -1;
+                    xformed = false;
                     nodes = tlasNodes;
                     if (STATS) nRays++;
                 }
@@ -233,6 +253,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             }
         }
         unsigned long long activeMask = __ballot(active);
+        NX_STAMP(0);
         if (activeMask == 0ull) break;
 
         // ---- traverse until too many lanes have run out of work
@@ -259,10 +280,12 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     }
                 } else {
                     if (sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
-                        const float4 o = rayO[rayIdx], d = rayD[rayIdx];
-                        org = mk3(o.x, o.y, o.z);
-                        dir = mk3(d.x, d.y, d.z);
-                        idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                        if (xformed) {
+                            const float4 o = rayO[rayIdx], d = rayD[rayIdx];
+                            org = mk3(o.x, o.y, o.z);
+                            dir = mk3(d.x, d.y, d.z);
+                            idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                        }
                         nodes = tlasNodes;
                         instSp = -1;
                     }
@@ -271,93 +294,92 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     else { tg = e; ng = make_uint2(0u, 0u); }
                 }
             }
-            // B: one node test
-            const bool doNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
-            if (STATS) wNode += __popcll(__ballot(doNode));
-            if (__ballot(doNode)) {
-                unsigned long long nodeAddr = 0ull;
-                if (doNode) {
-                    const int nodeOffset = 31 - __clz((int)ng.y);
-                    ng.y &= ~(1u << nodeOffset);
-                    if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
-                    const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
-                    const int rel = __popc(ng.y & ~(0xffffffffu << slot));
-                    nodeAddr = (unsigned long long)(nodes + (size_t)(ng.x + (uint32_t)rel) * (unsigned)kNodeStride);
-                }
-                uint4 nd[5];
-                coop_fetch<5>(doNode, nodeAddr, waveAddr, waveStage, lane, nd);
-                if (doNode) {
-                    child_trace(nd, org, dir, idir, invOct4, hitT, ng, tg);
-                    if (STATS) nNodes++;
-                }
+            NX_STAMP(1);
+            // Every busy lane now needs exactly one record: a node (its node group has unvisited children and no leaf
+            // work is pending), an instance record (pending TLAS leaf) or a triangle record (pending BLAS leaf).
+            const bool wantNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
+            const bool wantInst = active && tg.y != 0u && instSp < 0;
+            const bool wantTri = active && tg.y != 0u && instSp >= 0;
+            if (STATS) {
+                wNode += __popcll(__ballot(wantNode));
+                wPrim += __popcll(__ballot(wantInst || wantTri));
             }
-            // C: one leaf primitive: an instance (TLAS) or a triangle (BLAS)
-            const bool doPrim = active && tg.y != 0u;
-            const bool doInst = doPrim && instSp < 0, doTri = doPrim && instSp >= 0;
-            if (STATS) wPrim += __popcll(__ballot(doPrim));
-            if (__ballot(doInst)) {
-                unsigned long long recAddr = 0ull;
-                if (doInst) {
-                    const int off = 31 - __clz((int)tg.y);
-                    tg.y &= ~(1u << off);
-                    instIdx = tlasInstIdx[tg.x + (uint32_t)off];
-                    if (tg.y) stack_push(stackLds, stackSpill, sp, tg);
-                    if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
-                    instSp = sp;
-                    recAddr = (unsigned long long)&instTrav[instIdx];
-                }
-                uint4 rec[4];
-                coop_fetch<4>(doInst, recAddr, waveAddr, waveStage, lane, rec);
-                if (doInst) {
-                    const float4 r0 = make_float4(__uint_as_float(rec[0].x), __uint_as_float(rec[0].y), __uint_as_float(rec[0].z), __uint_as_float(rec[0].w));
-                    const float4 r1 = make_float4(__uint_as_float(rec[1].x), __uint_as_float(rec[1].y), __uint_as_float(rec[1].z), __uint_as_float(rec[1].w));
-                    const float4 r2 = make_float4(__uint_as_float(rec[2].x), __uint_as_float(rec[2].y), __uint_as_float(rec[2].z), __uint_as_float(rec[2].w));
-                    nodes = (GU4)(((unsigned long long)rec[3].y << 32) | rec[3].x);
-                    isect = (GF4)(((unsigned long long)rec[3].w << 32) | rec[3].z);
-                    ng = make_uint2(0u, 0x80000000u);
-                    tg = make_uint2(0u, 0u);
-                    // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264)
+            unsigned long long recAddr = 0ull;
+            if (wantNode) {
+                const int nodeOffset = 31 - __clz((int)ng.y);
+                ng.y &= ~(1u << nodeOffset);
+                if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+                const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
+                const int rel = __popc(ng.y & ~(0xffffffffu << slot));
+                recAddr = (unsigned long long)(nodes + (size_t)(ng.x + (uint32_t)rel) * (unsigned)kNodeStride);
+            } else if (wantInst) {
+                const int off = 31 - __clz((int)tg.y);
+                tg.y &= ~(1u << off);
+                recAddr = (unsigned long long)&instTrav[tg.x + (uint32_t)off];
+                if (tg.y) stack_push(stackLds, stackSpill, sp, tg);
+                if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+                instSp = sp;
+            } else if (wantTri) {
+                const int off = 31 - __clz((int)tg.y);
+                tg.y &= ~(1u << off);
+                recAddr = (unsigned long long)(isect + (size_t)(tg.x + (uint32_t)off) * (unsigned)kTriStride);
+            }
+            uint4 rc[5];
+            coop_fetch(wantNode || wantInst, wantTri, recAddr, waveAddr, waveStage, lane, rc);
+            NX_STAMP(2);
+            if (wantNode) {
+                child_trace(rc, org, dir, idir, invOct4, hitT, ng, tg);
+                if (STATS) nNodes++;
+            }
+            NX_STAMP(3);
+            if (wantInst) {
+                const float4 r0 = make_float4(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z), __uint_as_float(rc[0].w));
+                const float4 r1 = make_float4(__uint_as_float(rc[1].x), __uint_as_float(rc[1].y), __uint_as_float(rc[1].z), __uint_as_float(rc[1].w));
+                const float4 r2 = make_float4(__uint_as_float(rc[2].x), __uint_as_float(rc[2].y), __uint_as_float(rc[2].z), __uint_as_float(rc[2].w));
+                nodes = (GU4)(((unsigned long long)rc[3].y << 32) | rc[3].x);
+                isect = (GF4)(((unsigned long long)rc[3].w << 32) | rc[3].z);
+                instIdx = rc[4].x;
+                ng = make_uint2(0u, 0x80000000u);
+                tg = make_uint2(0u, 0u);
+                // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
+                // An identity inverse transform maps the ray onto itself bit for bit (1*x, fma(0,y,x), +0), so the
+                // transform, the three divisions and the restore on exit are skipped for such instances.
+                xformed = !(r0.x == 1.0f && r0.y == 0.0f && r0.z == 0.0f && r0.w == 0.0f && r1.x == 0.0f && r1.y == 1.0f && r1.z == 0.0f && r1.w == 0.0f &&
+                            r2.x == 0.0f && r2.y == 0.0f && r2.z == 1.0f && r2.w == 0.0f);
+                if (xformed) {
                     org = mat_point(r0, r1, r2, org);
                     dir = mat_vec(r0, r1, r2, dir);
                     idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-                    if (STATS) nInst++;
                 }
+                if (STATS) nInst++;
             }
-            if (__ballot(doTri)) {
-                unsigned long long triAddr = 0ull;
-                if (doTri) {
-                    const int off = 31 - __clz((int)tg.y);
-                    tg.y &= ~(1u << off);
-                    triAddr = (unsigned long long)(isect + (size_t)(tg.x + (uint32_t)off) * (unsigned)kTriStride);
-                }
-                uint4 tr[3];
-                coop_fetch<3>(doTri, triAddr, waveAddr, waveStage, lane, tr);
-                if (doTri) {
-                    // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
-                    const f3 p0 = mk3(__uint_as_float(tr[0].x), __uint_as_float(tr[0].y), __uint_as_float(tr[0].z));
-                    const f3 edge0 = mk3(__uint_as_float(tr[1].x), __uint_as_float(tr[1].y), __uint_as_float(tr[1].z));
-                    const f3 edge1 = mk3(__uint_as_float(tr[2].x), __uint_as_float(tr[2].y), __uint_as_float(tr[2].z));
-                    const f3 rayCrossEdge1 = cross3(dir, edge1);
-                    const float det = dot3(edge0, rayCrossEdge1);
-                    const float invDet = 1.0f / det;
-                    const f3 s = org - p0;
-                    const float u = invDet * dot3(s, rayCrossEdge1);
-                    const f3 sCrossEdge0 = cross3(s, edge0);
-                    const float v = invDet * dot3(dir, sCrossEdge0);
-                    const float t = invDet * dot3(edge1, sCrossEdge0);
-                    const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0f && t < hitT);
-                    if (STATS) nTris++;
-                    if (hit) {
-                        if (ANY_HIT) {
-                            active = false;  // occluded: nothing to add
-                        } else {
-                            hitT = t; hitU = u; hitV = v;
-                            hitTri = tr[0].w;
-                            hitInst = instIdx;
-                        }
+            NX_STAMP(4);
+            if (wantTri) {
+                // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
+                const f3 p0 = mk3(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z));
+                const f3 edge0 = mk3(__uint_as_float(rc[1].x), __uint_as_float(rc[1].y), __uint_as_float(rc[1].z));
+                const f3 edge1 = mk3(__uint_as_float(rc[2].x), __uint_as_float(rc[2].y), __uint_as_float(rc[2].z));
+                const f3 rayCrossEdge1 = cross3(dir, edge1);
+                const float det = dot3(edge0, rayCrossEdge1);
+                const float invDet = 1.0f / det;
+                const f3 s = org - p0;
+                const float u = invDet * dot3(s, rayCrossEdge1);
+                const f3 sCrossEdge0 = cross3(s, edge0);
+                const float v = invDet * dot3(dir, sCrossEdge0);
+                const float t = invDet * dot3(edge1, sCrossEdge0);
+                const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0f && t < hitT);
+                if (STATS) nTris++;
+                if (hit) {
+                    if (ANY_HIT) {
+                        active = false;  // occluded: nothing to add
+                    } else {
+                        hitT = t; hitU = u; hitV = v;
+                        hitTri = rc[0].w;
+                        hitInst = instIdx;
                     }
                 }
             }
+            NX_STAMP(5);
             activeMask = __ballot(active);
         } while (activeMask != 0ull && (exhausted || __popcll(activeMask) >= kRefillBelow));
     }
@@ -380,6 +402,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             atomicAdd(&ts->lanesActive, wActive);
             atomicAdd(&ts->lanesNode, wNode);
             atomicAdd(&ts->lanesPrim, wPrim);
+            for (int k = 0; k < 8; k++) atomicAdd(&ts->cycles[k], cyc[k]);
         }
     }
 }

@@ -321,18 +321,21 @@ static int refresh_blas_table(nxhip_ctx* c)
 
 static int refresh_inst_trav(nxhip_ctx* c)
 {
-    const size_t n = c->hostInstances.size();
+    // one record per TLAS leaf, in leaf order
+    const size_t n = c->hostInstIdx.size();
     std::vector<InstTrav> trav(std::max<size_t>(1, n));
     std::memset(trav.data(), 0, trav.size() * sizeof(InstTrav));
-    for (size_t i = 0; i < n; i++) {
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t i = c->hostInstIdx[k];
         const nx_bvh_instance& inst = c->hostInstances[i];
         if (inst.bvhIdx >= c->blas.size()) return fail_invalid("instance refers to a BLAS id that has not been uploaded");
         const float* m = inst.invTransform.cell;
-        trav[i].r0 = make_float4(m[0], m[1], m[2], m[3]);
-        trav[i].r1 = make_float4(m[4], m[5], m[6], m[7]);
-        trav[i].r2 = make_float4(m[8], m[9], m[10], m[11]);
-        trav[i].nodes = c->blas[inst.bvhIdx].nodes.as<uint4>();
-        trav[i].isect = c->blas[inst.bvhIdx].isect.as<float4>();
+        trav[k].r0 = make_float4(m[0], m[1], m[2], m[3]);
+        trav[k].r1 = make_float4(m[4], m[5], m[6], m[7]);
+        trav[k].r2 = make_float4(m[8], m[9], m[10], m[11]);
+        trav[k].nodes = c->blas[inst.bvhIdx].nodes.as<uint4>();
+        trav[k].isect = c->blas[inst.bvhIdx].isect.as<float4>();
+        trav[k].instIdx = i;
     }
     NX_HIP(hipStreamSynchronize(c->stream));
     NX_ALLOC(c->instTrav, trav.size() * sizeof(InstTrav));
@@ -400,6 +403,7 @@ int nxhip_clear_blas(nxhip_ctx* c)
     NX_HIP(hipStreamSynchronize(c->stream));
     c->blas.clear();
     c->hostInstances.clear();
+    c->hostInstIdx.clear();
     c->h.tlasNodes = nullptr;
     c->h.instanceCount = 0;
     return refresh_blas_table(c);
@@ -434,6 +438,7 @@ int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, 
     NX_HIP(hipMemcpy(c->tlasInstIdx.p, instanceIdx, (size_t)instanceCount * 4, hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(c->instances.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
     c->hostInstances.assign(instances, instances + instanceCount);
+    c->hostInstIdx.assign(instanceIdx, instanceIdx + instanceCount);
     c->h.tlasNodes = c->tlasNodes.as<uint4>();
     c->h.tlasInstIdx = c->tlasInstIdx.as<uint32_t>();
     c->h.instances = c->instances.as<nx_bvh_instance>();
@@ -1039,8 +1044,9 @@ int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace
     NX_HIP(hipStreamSynchronize(c->stream));
     TraceStatsDev h[2];
     NX_HIP(hipMemcpy(h, c->traceStats.p, sizeof h, hipMemcpyDeviceToHost));
-    if (closest) *closest = nxhip_trace_stats{h[0].rays, h[0].nodes, h[0].tris, h[0].instances, h[0].waveIters, h[0].lanesActive, h[0].lanesNode, h[0].lanesPrim};
-    if (shadow) *shadow = nxhip_trace_stats{h[1].rays, h[1].nodes, h[1].tris, h[1].instances, h[1].waveIters, h[1].lanesActive, h[1].lanesNode, h[1].lanesPrim};
+    static_assert(sizeof(nxhip_trace_stats) == sizeof(TraceStatsDev), "stats layouts must match");
+    if (closest) std::memcpy(closest, &h[0], sizeof h[0]);
+    if (shadow) std::memcpy(shadow, &h[1], sizeof h[1]);
     if (reset) NX_HIP(hipMemset(c->traceStats.p, 0, sizeof h));
     return NXHIP_OK;
 }

@@ -41,3 +41,17 @@ def running_mean(acc, radiance, frame):
     if frame == 1:
         return radiance.astype(np.float32).copy()
     return (acc + (radiance - acc) / np.float32(frame)).astype(np.float32)
+
+
+def tiled_order(pixel_map, width, tile_w=8, tile_h=8):
+    """Reorder a rank's pixels tile by tile (tile_w x tile_h blocks of the image, row-major inside a tile) so that the 64
+    rays a wave fetches together are a compact block of the image instead of a 64 x 1 strip.  Any order is legal: the
+    pixel map is what tells the device which global pixel a path belongs to, and with the pixel-keyed RNG the image does
+    not depend on it."""
+    pm = np.asarray(pixel_map, dtype=np.int64)
+    y, x = pm // width, pm % width
+    # rows of one rank are not contiguous under the interleaved split: tile over the rank-local row index
+    rows = np.unique(y)
+    local_row = np.searchsorted(rows, y)
+    key = ((local_row // tile_h) * ((width + tile_w - 1) // tile_w) + (x // tile_w)) * (tile_w * tile_h) + (local_row % tile_h) * tile_w + (x % tile_w)
+    return pm[np.argsort(key, kind="stable")].astype(np.uint32)
