@@ -5,8 +5,8 @@
 //  Cuda/BVH/BVH8Traversal.cuh:55-146 ChildTrace, :148-322 BVH8Trace, :326-518 BVH8TraceShadow,
 //  Cuda/Geometry/Triangle.cuh:53-118 Moeller-Trumbore): per ray the same nodes are visited in the same
 // order and the same hit record results.  How it is organised is CDNA4-first:
-//   * one ray per lane of a 64-wide wave; persistent workgroups; rays are fetched a wave at a time with
-//     ONE atomic per refill (ballot + popcount ranks) instead of one atomic per lane;
+//   * one ray per lane of a 64-wide wave; persistent workgroups; a wave reserves 128 rays with ONE atomic and hands them
+//     to idle lanes by ballot + popcount rank (the reference does one atomicAdd per ray);
 //   * the ray queue is cut into 8 contiguous shards, one fetch head per XCD group (blockIdx % 8 share an
 //     XCD and its private 4 MiB L2): waves of one XCD walk one band of the image / queue so the BVH
 //     subtrees they touch stay in that XCD's L2, and the head word is not hammered by 256 CUs; a wave
@@ -41,6 +41,10 @@ constexpr int kTraceBlock = 256;  // 4 waves
 constexpr int kLdsDepth = 8;      // stack entries per lane held in LDS (16 KiB per workgroup)
 constexpr int kSpillDepth = 24;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
 constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
+#ifndef NX_RESERVE
+#define NX_RESERVE 128
+#endif
+constexpr int kReserve = NX_RESERVE;  // rays reserved per fetch atomic
 #ifndef NX_REFILL_BELOW
 #define NX_REFILL_BELOW 40
 #endif
@@ -186,6 +190,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     int shard = blockIdx.x & (kXcds - 1);
     int shardsTried = 0;
     bool exhausted = false;
+    int rngCur = 0, rngEnd = 0;  // rays of the current shard reserved by this wave and not handed to a lane yet
 
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -211,21 +216,35 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 #define NX_STAMP(k) do { if (STATS) { const unsigned long long tNow = (unsigned long long)clock64(); cyc[k] += tNow - tPrev; tPrev = tNow; } } while (0)
 
     for (;;) {
-        // ---- refill idle lanes: one atomic per wave and shard
-        if (!exhausted) {
+        // ---- refill idle lanes from the wave's reserved range; one atomic reserves kReserve rays of a shard at a time
+        //      (a returning atomic on a contended head costs microseconds during which the whole wave stalls, so it
+        //      must not be paid per refill)
+        if (!exhausted || rngCur < rngEnd) {
             bool need = !active;
-            while (!exhausted) {
+            for (;;) {
                 const unsigned long long needMask = __ballot(need);
                 if (needMask == 0ull) break;
-                const int n = __popcll(needMask);
-                const int leader = __ffsll((long long)needMask) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&heads[shard], n);
-                base = __shfl(base, leader);
-                const int shardBegin = shard * chunk;
-                const int shardEnd = min(size, shardBegin + chunk);
-                const int idx = shardBegin + base + __popcll(needMask & laneLt);
-                if (need && idx < shardEnd) {
+                if (rngCur >= rngEnd) {
+                    if (exhausted) break;
+                    const int leader = __ffsll((long long)needMask) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&heads[shard], kReserve);
+                    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+                    const int shardBegin = shard * chunk;
+                    const int shardEnd = min(size, shardBegin + chunk);
+                    rngCur = shardBegin + base;
+                    rngEnd = min(shardEnd, rngCur + kReserve);
+                    if (rngCur >= shardEnd) {  // this shard is dry: steal from the next XCD's
+                        rngCur = rngEnd = 0;
+                        shard = (shard + 1) & (kXcds - 1);
+                        if (++shardsTried == kXcds) exhausted = true;
+                        continue;
+                    }
+                }
+                const int avail = rngEnd - rngCur;
+                const int rank = __popcll(needMask & laneLt);
+                if (need && rank < avail) {
+                    const int idx = rngCur + rank;
                     need = false;
                     active = true;
                     rayIdx = (uint32_t)idx;
@@ -246,10 +265,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     nodes = tlasNodes;
                     if (STATS) nRays++;
                 }
-                if (shardBegin + base + n >= shardEnd) {  // this shard is dry: steal from the next XCD's
-                    shard = (shard + 1) & (kXcds - 1);
-                    if (++shardsTried == kXcds) exhausted = true;
-                }
+                rngCur += min(__popcll(needMask), avail);
             }
         }
         unsigned long long activeMask = __ballot(active);
