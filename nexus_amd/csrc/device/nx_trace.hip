@@ -15,13 +15,8 @@
 //     it": the three fetch kinds of a wave are issued together and waited for once, so an iteration has a single
 //     memory round trip, and the 64 lanes reconverge at every stage (the reference's `while (triangleEntry.y)` inner
 //     loop serialises lanes with long triangle lists on a 64-wide wave).  Per-ray visiting order is unchanged;
-//   * nodes (80 B), triangle records (48 B) and instance records (64 B) are fetched COOPERATIVELY through LDS: the
-//     lanes that need a record publish its address, then the wave's 64 lanes issue direct-to-LDS loads
-//     (global_load_lds_dwordx4) of consecutive 16-byte chunks, so the chunks of one record sit in adjacent lanes
-//     and coalesce into one or two cache-line requests; each owner then reads its record back with ds_read_b128
-//     (bank-conflict free at an 80-byte stride).  A per-lane "5 x dwordx4 from my own node" costs one L1 lookup per
-//     lane and chunk — measured: the trace kernel ran at one VMEM wave-instruction per ~63 cycles per CU whatever the
-//     occupancy, i.e. bound by L1/TA lookups, not by HBM or latency — the cooperative form needs 2-3x fewer;
+//   * a record is an 80-byte node (five 16-byte loads), a 48-byte triangle record or an 80-byte instance record; each
+//     lane loads its own (a cooperative LDS-staged fetch exists behind -DNX_COOP_FETCH and measured slower);
 //   * quantised bounds are converted with v_cvt_f32_ubyteN and the slab test is 6 v_fma per child + integer
 //     max3/min3 on the float bit patterns (identical ordering to the reference's vmax.s32/vmin.s32 PTX, including
 //     its NaN behaviour);
@@ -57,13 +52,24 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void g_cvoid;
 
-// Cooperative record fetch (see the header comment), ONE per loop iteration for all three record kinds.  Must be reached
-// by all lanes of the wave.  Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
+// Record fetch, ONE per loop iteration for all three record kinds.  Must be reached by all lanes of the wave.
+// Two forms.  Default (measured faster: 5.2 vs 3.9 Grays/s on the 1M-triangle bench): each lane issues its own 16-byte
+// global loads.  -DNX_COOP_FETCH: the cooperative LDS-staged form described next, kept for comparison — it needs 2-3x
+// fewer L1 lookups but pays two LDS round trips and a direct-to-LDS load per iteration, and 22 KiB more LDS per workgroup.  Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
 // publish `addr`; the wave's lanes then stream every requested record into waveStage with direct-to-LDS loads of
 // consecutive 16-byte chunks (5-chunk records first, then 3-chunk ones) and each requester reads its record back.
 // waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
 NXD void coop_fetch(bool kind5, bool kind3, unsigned long long addr, lds_u64* waveAddr, lds_u32* waveStage, int lane, uint4 (&out)[5])
 {
+#ifndef NX_COOP_FETCH
+    // default: every lane loads its own record with 16-byte global loads (3 or 5 in flight per lane)
+    if (kind5 || kind3) {
+        GU4 p = (GU4)addr;
+        out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+        if (kind5) { out[3] = p[3]; out[4] = p[4]; }
+    }
+    return;
+#endif
     const unsigned long long mask5 = __ballot(kind5), mask3 = __ballot(kind3);
     const int n5 = __popcll(mask5), n3 = __popcll(mask3);
     const int rank5 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask5 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask5, 0u));
@@ -171,8 +177,10 @@ template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
+#ifdef NX_COOP_FETCH
     __shared__ unsigned long long ldsAddr[kTraceBlock];
     __shared__ __attribute__((aligned(16))) uint32_t ldsStage[kTraceBlock * kMaxChunks * 4];
+#endif
 
     NX_G Counters* C = S->counters;
     const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
@@ -193,9 +201,14 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     int rngCur = 0, rngEnd = 0;  // rays of the current shard reserved by this wave and not handed to a lane yet
 
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
+#ifdef NX_COOP_FETCH
     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     lds_u64* const waveAddr = (lds_u64*)&ldsAddr[waveInBlock * kWave];
     lds_u32* const waveStage = (lds_u32*)&ldsStage[waveInBlock * kWave * kMaxChunks * 4];
+#else
+    lds_u64* const waveAddr = nullptr;
+    lds_u32* const waveStage = nullptr;
+#endif
     uint2 stackSpill[kSpillDepth];
     int sp = 0;
 
