@@ -6,12 +6,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one frame = one primary sample per pixel through the whole hot path (generate, trace, then pathLength x
-(logic, shade x4 + NEE, trace || shadow trace), accumulate), replayed as one hipGraph per frame.  Msamples/s is the
+(logic, shade x4 + NEE, trace || shadow trace), accumulate).  Frames are rendered in passes of up to --frames-per-pass
+frames (one hipGraph replay per pass; each frame keeps its own frame number and RNG streams and the result is
+bit-identical to rendering them one by one); exactly K frames are timed, the last pass being shorter if need be.  Msamples/s is the
 reference viewer's "Megarays/sec": width * height * frames / seconds / 1e6
 (/root/reference/Nexus/src/Renderer/Panels/MetricsPanel.cpp:28,35,56).  Scene and BVH live in HBM before the timed
-region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every rank renders its tiles with the scene
-replicated, and the radiance tiles are gathered to rank 0 with ONE RCCL gather per frame, where they are
-de-interleaved, accumulated and tonemapped.  Total work per step is fixed (one 1080p frame): strong scaling.
+region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every rank renders AND accumulates its tiles with
+the scene replicated, and the accumulated tiles (16 B per pixel) are gathered to rank 0 with ONE RCCL gather per pass,
+where they are scattered into the full image and tonemapped; the image is bit-identical to the 1-GPU one.  Total work
+per step is fixed (one 1080p frame): strong scaling.
 
 Rank 0 prints ONE JSON line.  It also carries
   roofline     : the trace kernel (closest hit) — algorithmic bytes per launch (SURVEY.md section 8d:
@@ -118,14 +121,15 @@ def cpu_baseline(sc, width, height, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--path-length", type=int, default=8)
     ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
     ap.add_argument("--nv", type=int, default=512)
-    ap.add_argument("--frames-per-pass", type=int, default=4, help="frames batched into one wavefront pass (steps must be a multiple)")
+    ap.add_argument("--frames-per-pass", type=int, default=32,
+                    help="frames batched into one wavefront pass; a step budget that is not a multiple ends with one shorter pass")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -148,9 +152,14 @@ def main():
         import torch.distributed  # noqa: F401
 
     W, H = args.width, args.height
-    S = max(1, args.frames_per_pass)
-    if args.steps % S or args.warmup % S:
-        raise SystemExit("--steps and --warmup must be multiples of --frames-per-pass (%d)" % S)
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    S = max(1, min(args.frames_per_pass, 64, args.steps))
+
+    def schedule(frames):
+        """pass sizes that render exactly `frames` frames"""
+        return [S] * (frames // S) + ([frames % S] if frames % S else [])
+
     sc = build_config2(W, H, args.nu, args.nv, args.path_length)
 
     dist = None
@@ -186,10 +195,17 @@ def main():
         ctx.set_pixel_map(pm)
         ctx.set_frames_per_pass(S)
         n_local = len(pm)
-        rad = torch.zeros((S * n_local, 4), dtype=torch.float32, device="cuda")
-        ctx.bind_radiance(rad.data_ptr(), S * n_local)
+
+        class _DeviceArray:  # zero-copy torch view of the context's accumulation tile (float4 per local pixel)
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+        acc_tile = torch.as_tensor(_DeviceArray(ctx.accumulation_device_ptr(), (n_local, 4)), device="cuda")
+        assert acc_tile.data_ptr() == int(ctx.accumulation_device_ptr())
         if rank == 0:
-            gathered = [torch.zeros((S * n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
+            gathered = [torch.zeros((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
+            full_acc = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+            full_rgba = torch.zeros((W * H,), dtype=torch.int32, device="cuda")
             maps_dev = []
             seen = np.zeros(W * H, dtype=bool)
             for r in range(world):
@@ -200,17 +216,19 @@ def main():
                 seen[m] = True
                 maps_dev.append(torch.from_numpy(m.astype(np.int64)).to("cuda").to(torch.int32))
             assert seen.all()
-        frame_counter = [0]
 
-        def step():
+        def step(n):
+            # every rank path-traces and accumulates its own tiles (the exact per-frame running mean of the 1-GPU path) ...
+            if ctx.frames_per_pass != n:
+                ctx.set_frames_per_pass(n)
             ctx.render_frame()
-            first = frame_counter[0] + 1
-            frame_counter[0] += S
-            # the one collective of the path: radiance tiles -> rank 0 over xGMI
+            ctx.accumulate()
+            # ... and the one collective of the path moves the accumulated tiles (16 B per pixel, once per pass) to rank 0
+            # over xGMI, which scatters them into the full image and tonemaps
             if backend == "nccl":
-                dist.gather(rad, gathered if rank == 0 else None, dst=0)
+                dist.gather(acc_tile, gathered if rank == 0 else None, dst=0)
             else:
-                host = rad.cpu()
+                host = acc_tile.cpu()
                 parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, parts, dst=0)
                 if rank == 0:
@@ -218,7 +236,7 @@ def main():
                         gathered[r].copy_(parts[r])
             if rank == 0:
                 for r in range(world):
-                    ctx.accumulate_external(gathered[r].data_ptr(), n_local, first, maps_dev[r].data_ptr(), slices=S, slice_stride=n_local)
+                    ctx.compose_tiles(gathered[r].data_ptr(), n_local, maps_dev[r].data_ptr(), full_acc.data_ptr(), full_rgba.data_ptr())
 
         def sync():
             torch.cuda.synchronize()
@@ -229,20 +247,22 @@ def main():
             ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
         ctx.set_frames_per_pass(S)
 
-        def step():
+        def step(n):
+            if ctx.frames_per_pass != n:
+                ctx.set_frames_per_pass(n)
             ctx.render_frame()
             ctx.accumulate()
 
         def sync():
             ctx.sync()
 
-    # one step = one frame; a pass renders S frames
-    for _ in range(args.warmup // S):
-        step()
+    # one step = one frame; a pass renders up to S frames
+    for n in schedule(args.warmup):
+        step(n)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps // S):
-        step()
+    for n in schedule(args.steps):
+        step(n)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -267,8 +287,8 @@ def main():
         "config": {
             "workload": "configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
                         % (sc["triangles"], sc["bvh8_nodes"], W, H, args.path_length),
-            "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, one RCCL gather per frame" % (world, TILE_ROWS),
-            "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of %d frames" % S,
+            "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, per-rank accumulation, one RCCL gather of accumulated tiles per pass" % (world, TILE_ROWS),
+            "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of up to %d frames" % S,
             "frames_per_pass": S, "pixel_order": args.pixel_order,
             "host_bvh_build_s": round(sc["t_build"], 2),
         },
@@ -276,7 +296,9 @@ def main():
 
     # ---- roofline of the dominant kernel (closest-hit trace), rank 0 / single GPU only
     if rank == 0 and world == 1 and not args.no_roofline:
-        passes = max(1, min(args.steps // S, 8))
+        if ctx.frames_per_pass != S:
+            ctx.set_frames_per_pass(S)
+        passes = max(1, min(args.steps // S, 4))
         frames = passes * S
         # (a) units: the counting variant of the same kernel over `frames` frames
         ctx.enable_trace_stats(True)
@@ -329,7 +351,7 @@ def main():
         from nexus_amd import imageio
 
         if world > 1:
-            img = ctx.read_full_rgba8()
+            img = full_rgba.cpu().numpy().view(np.uint32)
         elif args.pixel_order == "tiles":
             img = np.zeros(W * H, np.uint32)
             img[multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)] = ctx.read_rgba8()

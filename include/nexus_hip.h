@@ -76,7 +76,8 @@ int nxhip_set_pixel_map(nxhip_ctx *ctx, const uint32_t *pixelMap, uint32_t local
  * Render()).  Every queue then holds localCount * frames paths, so each kernel launch carries `frames` times the work:
  * the latency tail of a trace launch (its slowest ray) and the per-launch overheads are amortised, at the price of
  * HBM capacity (about 0.3 KB per path).  Each frame keeps its own frame number / RNG streams; the accumulate step
- * applies the frames' running-mean updates in order.  Re-allocates the queues and resets the frame number. */
+ * applies the frames' running-mean updates in order.  The queues grow when needed and are kept when `frames` shrinks
+ * (a shorter last pass of a frame budget costs no allocation); the frame number and the accumulation are untouched. */
 int nxhip_set_frames_per_pass(nxhip_ctx *ctx, uint32_t frames);
 
 /* ---- rendering ----------------------------------------------------------------------------------- */
@@ -91,7 +92,8 @@ uint32_t nxhip_frame_number(nxhip_ctx *ctx);
 int nxhip_render_frame(nxhip_ctx *ctx);
 /* AccumulateKernel — Cuda/PathTracer/PathTracer.cu:480-496, PathTracer.cpp:278.  Asynchronous. */
 int nxhip_accumulate(nxhip_ctx *ctx);
-/* nxhip_render_frame + nxhip_accumulate `frames` times (one graph replay per frame). */
+/* `frames` frames: passes of frames-per-pass frames (render + accumulate), the last one shorter if `frames` is not a
+ * multiple. */
 int nxhip_render(nxhip_ctx *ctx, uint32_t frames);
 
 /* Read-back (synchronises).  radiance: localCount * framesPerPass x 3 floats (frame slices one after the other);
@@ -114,6 +116,13 @@ int nxhip_bind_radiance(nxhip_ctx *ctx, void *radianceDevice, uint32_t capacity)
  * width*height pixels. */
 int nxhip_accumulate_external(nxhip_ctx *ctx, const void *srcRadianceDevice, uint32_t count, uint32_t slices, uint32_t sliceStride,
                               uint32_t firstFrame, const void *srcPixelMapDevice);
+/* Root-side image assembly when every rank accumulates its own tiles (nxhip_accumulate with a pixel map) and only the
+ * accumulated tiles travel: element k (< count) of srcAccumulationDevice (device float4[count], a rank's local-order
+ * accumulation) is copied to dstAccumulationDevice[srcPixelMapDevice[k]] (device float4[width*height], caller-owned) and,
+ * if dstRgba8Device is not NULL, tonemapped into dstRgba8Device[...] (device uint32[width*height]).  No arithmetic is
+ * applied to the accumulated values, so the assembled image is bit-identical to a single-GPU accumulation. */
+int nxhip_compose_tiles(nxhip_ctx *ctx, const void *srcAccumulationDevice, uint32_t count, const void *srcPixelMapDevice,
+                        void *dstAccumulationDevice, void *dstRgba8Device);
 /* Read-back of the full width*height accumulation / RGBA8 image (after nxhip_accumulate_external). */
 int nxhip_read_full_accumulation(nxhip_ctx *ctx, float *dst);
 int nxhip_read_full_rgba8(nxhip_ctx *ctx, uint32_t *dst);

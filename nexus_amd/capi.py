@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "nxhip_upload_texture", "nxhip_clear_textures", "nxhip_set_camera", "nxhip_set_render_settings", "nxhip_set_modes",
     "nxhip_set_pixel_map", "nxhip_set_frames_per_pass", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
     "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
-    "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external",
+    "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
@@ -106,6 +106,7 @@ def lib():
     L.nxhip_accumulation_device_ptr.argtypes = [vp]
     L.nxhip_accumulation_device_ptr.restype = vp
     L.nxhip_accumulate_external.argtypes = [vp, vp, u32, u32, u32, u32, vp]
+    L.nxhip_compose_tiles.argtypes = [vp, vp, u32, vp, vp, vp]
     L.nxhip_set_frames_per_pass.argtypes = [vp, u32]
     L.nxhip_bind_radiance.argtypes = [vp, vp, u32]
     L.nxhip_read_full_accumulation.argtypes = [vp, vp]
@@ -379,6 +380,10 @@ class Context:
     def accumulate_external(self, dev_ptr, count, first_frame, pixel_map_dev_ptr=None, slices=1, slice_stride=None):
         check(self.L.nxhip_accumulate_external(self.h, C.c_void_p(dev_ptr), count, slices, slice_stride if slice_stride is not None else count,
                                                first_frame, C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None), "nxhip_accumulate_external")
+
+    def compose_tiles(self, src_accum_dev_ptr, count, pixel_map_dev_ptr, dst_accum_dev_ptr, dst_rgba8_dev_ptr=None):
+        check(self.L.nxhip_compose_tiles(self.h, C.c_void_p(src_accum_dev_ptr), count, C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None,
+                                         C.c_void_p(dst_accum_dev_ptr), C.c_void_p(dst_rgba8_dev_ptr) if dst_rgba8_dev_ptr else None), "nxhip_compose_tiles")
 
     def set_frames_per_pass(self, frames):
         check(self.L.nxhip_set_frames_per_pass(self.h, frames), "nxhip_set_frames_per_pass")

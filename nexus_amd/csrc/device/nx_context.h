@@ -69,6 +69,8 @@ struct nxhip_ctx {
 
     uint32_t width = 0, height = 0, localCount = 0;
     uint32_t framesPerPass = 1, pathCount = 0;
+    size_t pathCapacity = 0;           // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
+    size_t radianceBoundCapacity = 0;  // float4 capacity of an externally bound radiance buffer, 0 = own buffer
 
     nxd::DeviceState h{};  // host mirror, uploaded to dState when dirty
     nxd::DevBuf dState;

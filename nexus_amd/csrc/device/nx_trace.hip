@@ -21,7 +21,7 @@
 //     max3/min3 on the float bit patterns (identical ordering to the reference's vmax.s32/vmin.s32 PTX, including
 //     its NaN behaviour);
 //   * triangles come from a leaf-ordered 48-byte stream (p0|id, e0, e1) built at upload: no triangleIdx
-//     indirection; instances from a 64-byte traversal record;
+//     indirection; instances from an 80-byte leaf-ordered traversal record;
 //   * the traversal stack lives in LDS, entry-major ([depth][lane]) so ds_read/write_b64 are
 //     conflict-free, with a scratch overflow; the world-space ray is re-read from the queue when an
 //     instance is left instead of being kept in 6 VGPRs.
@@ -35,7 +35,9 @@ namespace nxd {
 constexpr int kTraceBlock = 256;  // 4 waves
 constexpr int kLdsDepth = 8;      // stack entries per lane held in LDS (16 KiB per workgroup)
 constexpr int kSpillDepth = 24;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
+#ifdef NX_COOP_FETCH
 constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
+#endif
 #ifndef NX_RESERVE
 #define NX_RESERVE 128
 #endif
@@ -55,7 +57,8 @@ typedef __attribute__((address_space(1))) const void g_cvoid;
 // Record fetch, ONE per loop iteration for all three record kinds.  Must be reached by all lanes of the wave.
 // Two forms.  Default (measured faster: 5.2 vs 3.9 Grays/s on the 1M-triangle bench): each lane issues its own 16-byte
 // global loads.  -DNX_COOP_FETCH: the cooperative LDS-staged form described next, kept for comparison — it needs 2-3x
-// fewer L1 lookups but pays two LDS round trips and a direct-to-LDS load per iteration, and 22 KiB more LDS per workgroup.  Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
+// fewer L1 lookups but pays two LDS round trips and a direct-to-LDS load per iteration, and 22 KiB more LDS per workgroup.
+// Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
 // publish `addr`; the wave's lanes then stream every requested record into waveStage with direct-to-LDS loads of
 // consecutive 16-byte chunks (5-chunk records first, then 3-chunk ones) and each requester reads its record back.
 // waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
@@ -326,9 +329,29 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             NX_STAMP(1);
             // Every busy lane now needs exactly one record: a node (its node group has unvisited children and no leaf
             // work is pending), an instance record (pending TLAS leaf) or a triangle record (pending BLAS leaf).
-            const bool wantNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
+            bool wantNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
             const bool wantInst = active && tg.y != 0u && instSp < 0;
-            const bool wantTri = active && tg.y != 0u && instSp >= 0;
+            bool wantTri = active && tg.y != 0u && instSp >= 0;
+#if defined(NX_POSTPONE_TRI) || defined(NX_POSTPONE_NODE)
+            {
+                // vote: a record kind wanted by only a few lanes waits (those lanes idle this iteration) while the other
+                // kind has work, so that each of the two long code blocks runs with more of its lanes enabled.  The order
+                // in which a ray visits its records does not change.
+                const int cN = __popcll(__ballot(wantNode)), cT = __popcll(__ballot(wantTri));
+#ifdef NX_POSTPONE_TRI
+                const bool holdTri = cT < NX_POSTPONE_TRI && cN > 0 && cN >= cT;
+#else
+                const bool holdTri = false;
+#endif
+#ifdef NX_POSTPONE_NODE
+                const bool holdNode = !holdTri && cN < NX_POSTPONE_NODE && cT > cN;
+#else
+                const bool holdNode = false;
+#endif
+                if (holdTri) wantTri = false;
+                if (holdNode) wantNode = false;
+            }
+#endif
             if (STATS) {
                 wNode += __popcll(__ballot(wantNode));
                 wPrim += __popcll(__ballot(wantInst || wantTri));

@@ -500,6 +500,19 @@ __global__ void __launch_bounds__(kWideBlock) accumulate_kernel(const DeviceStat
     }
 }
 
+// Multi-GPU image assembly on the root: element k of a rank's local-order accumulation tile belongs to full-image pixel
+// dstMap[k] (nullptr: k).  A copy and a tonemap, no arithmetic on the accumulated values.
+__global__ void __launch_bounds__(kWideBlock) compose_kernel(const float4* __restrict__ src, const uint32_t count, const uint32_t* __restrict__ dstMap,
+                                                              float4* __restrict__ dstAccum, uint32_t* __restrict__ dstRgba8)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const uint32_t i = dstMap ? dstMap[k] : k;
+        const float4 a = src[k];
+        dstAccum[i] = a;
+        if (dstRgba8) dstRgba8[i] = tonemap_rgba8(mk3(a.x, a.y, a.z));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 
 const void* logic_kernel_ptr(bool ordered) { return ordered ? (const void*)logic_kernel<true> : (const void*)logic_kernel<false>; }
@@ -516,5 +529,6 @@ const void* shade_kernel_ptr(int type, bool ordered)
 const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
 const void* generate_kernel_ptr() { return (const void*)generate_kernel; }
 const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }
+const void* compose_kernel_ptr() { return (const void*)compose_kernel; }
 
 }  // namespace nxd

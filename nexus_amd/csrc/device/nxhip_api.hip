@@ -20,6 +20,7 @@ const void* shade_kernel_ptr(int type, bool ordered);
 const void* begin_frame_kernel_ptr();
 const void* generate_kernel_ptr();
 const void* accumulate_kernel_ptr();
+const void* compose_kernel_ptr();
 
 static thread_local std::string g_lastError;
 
@@ -96,15 +97,12 @@ static int upload_state(nxhip_ctx* c)
     return NXHIP_OK;
 }
 
-static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
+// Queue / path-state buffers for n paths (contents undefined), and the device-state pointers to them.
+static int alloc_queues(nxhip_ctx* c, size_t n)
 {
-    const size_t n = (size_t)std::max<uint32_t>(localCount, 1u) * c->framesPerPass;
-    const size_t full = std::max<size_t>((size_t)c->width * c->height, localCount);
     NX_ALLOC(c->throughputPdf, n * 16);
     NX_ALLOC(c->radiance, n * 16);
     NX_ALLOC(c->rayOrigin, n * 16);
-    NX_ALLOC(c->accumulation, full * 16);
-    NX_ALLOC(c->rgba8, full * 4);
     NX_ALLOC(c->trRayO, n * 16);
     NX_ALLOC(c->trRayD, n * 16);
     NX_ALLOC(c->trHit, n * 16);
@@ -117,23 +115,39 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
         NX_ALLOC(c->mqDirInst[m], n * 16);
         NX_ALLOC(c->mqPixel[m], n * 4);
     }
+    NX_HIP(hipMemsetAsync(c->radiance.p, 0, n * 16, c->stream));
+    c->pathCapacity = n;
+    c->radianceBoundCapacity = 0;
+    DeviceState& h = c->h;
+    h.throughputPdf = c->throughputPdf.as<float4>();
+    h.radiance = c->radiance.as<float4>();
+    h.rayOrigin = c->rayOrigin.as<float4>();
+    h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
+    h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
+    for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+// Everything sized by the pixel set of this context: queues for localCount * framesPerPass paths and a zeroed image.
+static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
+{
+    const size_t n = (size_t)std::max<uint32_t>(localCount, 1u) * c->framesPerPass;
+    const size_t full = std::max<size_t>((size_t)c->width * c->height, localCount);
+    const int rc = alloc_queues(c, n);
+    if (rc != NXHIP_OK) return rc;
+    NX_ALLOC(c->accumulation, full * 16);
+    NX_ALLOC(c->rgba8, full * 4);
     NX_HIP(hipMemsetAsync(c->accumulation.p, 0, full * 16, c->stream));
     NX_HIP(hipMemsetAsync(c->rgba8.p, 0, full * 4, c->stream));
-    NX_HIP(hipMemsetAsync(c->radiance.p, 0, n * 16, c->stream));
     c->localCount = localCount;
     c->pathCount = localCount * c->framesPerPass;
     DeviceState& h = c->h;
     h.localCount = localCount;
     h.framesPerPass = c->framesPerPass;
     h.pathCount = c->pathCount;
-    h.throughputPdf = c->throughputPdf.as<float4>();
-    h.radiance = c->radiance.as<float4>();
-    h.rayOrigin = c->rayOrigin.as<float4>();
     h.accumulation = c->accumulation.as<float4>();
     h.rgba8 = c->rgba8.as<uint32_t>();
-    h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
-    h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
-    for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
     c->stateDirty = true;
     invalidate_graph(c);
     return NXHIP_OK;
@@ -795,10 +809,27 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
     if ((uint64_t)c->localCount * frames > 0x7fffffffull) return fail_invalid("nxhip_set_frames_per_pass: more than 2^31 paths");
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)std::max<uint32_t>(c->localCount, 1u) * frames;
+    if (c->radianceBoundCapacity != 0 && n > c->radianceBoundCapacity)
+        return fail_invalid("nxhip_set_frames_per_pass: the bound radiance buffer is too small for this many frames; rebind first");
+    if (n > c->pathCapacity) {
+        // grow only: a later, smaller pass (e.g. the remainder of a frame budget) reuses the buffers.  The frame counter
+        // and the accumulation are left alone: a pass size is a scheduling choice, not a new image.
+        float4* const boundPtr = c->h.radiance;
+        const size_t boundCap = c->radianceBoundCapacity;
+        const int rc = alloc_queues(c, n);
+        if (rc != NXHIP_OK) return rc;
+        if (boundCap != 0) {  // an external radiance binding survives the growth
+            c->h.radiance = boundPtr;
+            c->radianceBoundCapacity = boundCap;
+        }
+    }
     c->framesPerPass = frames;
-    const int rc = alloc_paths(c, c->localCount);
-    if (rc != NXHIP_OK) return rc;
-    return set_frame_number_device(c, 0);
+    c->pathCount = c->localCount * frames;
+    c->h.framesPerPass = frames;
+    c->h.pathCount = c->pathCount;
+    c->stateDirty = true;
+    return NXHIP_OK;
 }
 
 int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
@@ -809,8 +840,10 @@ int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
     if (radianceDevice) {
         if (capacity < c->pathCount) return fail_invalid("nxhip_bind_radiance: buffer smaller than localCount * framesPerPass");
         c->h.radiance = static_cast<float4*>(radianceDevice);
+        c->radianceBoundCapacity = capacity;
     } else {
         c->h.radiance = c->radiance.as<float4>();
+        c->radianceBoundCapacity = 0;
     }
     c->stateDirty = true;
     return NXHIP_OK;
@@ -844,17 +877,37 @@ int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uin
     return launch_accumulate(c, static_cast<const float4*>(src), count, slices, sliceStride, firstFrame, static_cast<const uint32_t*>(srcPixelMapDevice));
 }
 
+int nxhip_compose_tiles(nxhip_ctx* c, const void* srcAccumulation, uint32_t count, const void* srcPixelMapDevice, void* dstAccumulationDevice,
+                        void* dstRgba8Device)
+{
+    NX_CHECK_CTX(c);
+    if (!srcAccumulation || !dstAccumulationDevice || count == 0 || count > c->width * c->height) return fail_invalid("nxhip_compose_tiles: bad arguments");
+    NX_HIP(hipSetDevice(c->device));
+    const float4* src = static_cast<const float4*>(srcAccumulation);
+    const uint32_t* map = static_cast<const uint32_t*>(srcPixelMapDevice);
+    float4* dstA = static_cast<float4*>(dstAccumulationDevice);
+    uint32_t* dstP = static_cast<uint32_t*>(dstRgba8Device);
+    void* args[5] = {(void*)&src, (void*)&count, (void*)&map, (void*)&dstA, (void*)&dstP};
+    NX_HIP(hipLaunchKernel(compose_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
+    return NXHIP_OK;
+}
+
 int nxhip_render(nxhip_ctx* c, uint32_t frames)
 {
     NX_CHECK_CTX(c);
-    if (frames % c->framesPerPass) return fail_invalid("nxhip_render: frames must be a multiple of frames-per-pass");
-    for (uint32_t f = 0; f < frames; f += c->framesPerPass) {
-        int rc = nxhip_render_frame(c);
-        if (rc != NXHIP_OK) return rc;
-        rc = nxhip_accumulate(c);
-        if (rc != NXHIP_OK) return rc;
+    const uint32_t S = c->framesPerPass;
+    int rc = NXHIP_OK;
+    for (uint32_t f = 0; f < frames && rc == NXHIP_OK; f += S) {
+        const uint32_t n = std::min(S, frames - f);  // the last pass may be shorter
+        if (n != c->framesPerPass) rc = nxhip_set_frames_per_pass(c, n);
+        if (rc == NXHIP_OK) rc = nxhip_render_frame(c);
+        if (rc == NXHIP_OK) rc = nxhip_accumulate(c);
     }
-    return NXHIP_OK;
+    if (c->framesPerPass != S) {
+        const int rc2 = nxhip_set_frames_per_pass(c, S);
+        if (rc == NXHIP_OK) rc = rc2;
+    }
+    return rc;
 }
 
 static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, float* dst)
