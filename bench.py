@@ -19,9 +19,9 @@ per step is fixed (one 1080p frame): strong scaling.
 Rank 0 prints ONE JSON line.  It also carries
   roofline     : the trace kernel (closest hit) — algorithmic bytes per launch (SURVEY.md section 8d:
                  44 B/ray + 80 B/node visit + 40 B/triangle test + 104 B/instance entry, visits counted by the
-                 kernel's own counting variant on the same frames) / average launch duration from hipEvents around
-                 every launch of that kernel (second pass over the same K frames, launched kernel by kernel on the
-                 context's stream), against 8 TB/s HBM peak.
+                 kernel's own counting variant on the same frames) / average launch duration from hipEvents recorded
+                 by event nodes placed around every kernel node of the production hipGraph (a second run over the same
+                 frames on the context's stream), against 8 TB/s HBM peak.
   cpu_baseline : the CPU oracle (port of the reference algorithm) on one full frame of the same scene, timed on the
                  host cores of this box.  A reported baseline, not a target.
 """
@@ -308,8 +308,9 @@ def main():
         closest, shadow = ctx.read_trace_stats(reset=True)
         ctx.enable_trace_stats(False)
         q = ctx.read_queue_sizes()
-        # (b) durations: hipEvent pair around every launch, same frames again
-        ctx.enable_kernel_timing(True)
+        # (b) durations: hipEvent pair around every kernel of the production graph (event-record nodes inside the hipGraph, so
+        # the closest-hit and shadow traces of a bounce overlap exactly as in the timed region), same frames again
+        ctx.enable_kernel_timing(True, in_graph=True)
         ctx.read_kernel_times(reset=True)
         for _ in range(passes):
             ctx.render_frame()
@@ -320,9 +321,20 @@ def main():
         avg_ms = kt["trace"]["ms"] / max(1, launches)
         bytes_per_launch = trace_algorithmic_bytes(closest) / max(1, launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side traffic per launch cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes
+        # over this same workload (profiles/r01_b_traffic.json), and is reported only when the workload matches
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            tw = tj.get("workload", {})
+            if (tw.get("width"), tw.get("height"), tw.get("nu"), tw.get("nv"), tw.get("path_length"), tw.get("frames_per_pass")) == \
+                    (W, H, args.nu, args.nv, args.path_length, S):
+                traffic = int(tj["kernels"]["trace_closest"]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/r01_b_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of MI355X_MICROARCH.md)"
         out["roofline"] = {
             "bound": "hbm", "kernel": "trace_kernel<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),

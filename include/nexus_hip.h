@@ -163,9 +163,11 @@ typedef struct nxhip_trace_stats {
 int nxhip_enable_trace_stats(nxhip_ctx *ctx, int enable);
 int nxhip_read_trace_stats(nxhip_ctx *ctx, nxhip_trace_stats *closest, nxhip_trace_stats *shadow, int reset);
 
-/* Per-kernel-class device time.  When enabled, frames are launched kernel by kernel on the context's stream
- * with a hipEvent pair around every launch (no graph).  Classes: 0 generate, 1 trace, 2 shadow, 3 logic,
- * 4 shade, 5 accumulate. */
+/* Per-kernel-class device time.  enable = 1: frames are launched kernel by kernel on the context's stream with a
+ * hipEvent pair around every launch (no graph, no overlap between the trace and shadow-trace kernels).  enable = 2: the
+ * frame graph is rebuilt with an event-record node before and after every kernel node, so each kernel is timed under the
+ * conditions of the production replay (closest-hit and shadow traces of a bounce run concurrently); the events are read
+ * after every replay.  0: off.  Classes: 0 generate, 1 trace, 2 shadow, 3 logic, 4 shade, 5 accumulate. */
 enum { NXHIP_K_GENERATE = 0, NXHIP_K_TRACE = 1, NXHIP_K_SHADOW = 2, NXHIP_K_LOGIC = 3, NXHIP_K_SHADE = 4, NXHIP_K_ACCUMULATE = 5, NXHIP_K_COUNT = 6 };
 typedef struct nxhip_kernel_times {
     double ms[NXHIP_K_COUNT];

@@ -464,8 +464,10 @@ class Context:
         check(self.L.nxhip_read_trace_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0), "nxhip_read_trace_stats")
         return a.as_dict(), b.as_dict()
 
-    def enable_kernel_timing(self, on=True):
-        check(self.L.nxhip_enable_kernel_timing(self.h, 1 if on else 0), "nxhip_enable_kernel_timing")
+    def enable_kernel_timing(self, on=True, in_graph=False):
+        """on: hipEvent pair per kernel launch; in_graph: keep the hipGraph (and its trace || shadow overlap) and time with
+        event-record nodes inside it, otherwise launch kernel by kernel"""
+        check(self.L.nxhip_enable_kernel_timing(self.h, (2 if in_graph else 1) if on else 0), "nxhip_enable_kernel_timing")
 
     def read_kernel_times(self, reset=False):
         t = KernelTimes()

@@ -96,6 +96,9 @@ struct nxhip_ctx {
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
     bool statsEnabled = false;
     bool timingEnabled = false;
+    int timingMode = 0;  // 0 off, 1 eager launches with an event pair each, 2 event-record nodes inside the frame graph
+    std::vector<nxd::KernelTimer> graphTimers;
+    std::vector<int> graphTimerClass;
     nxhip_kernel_times times{};
     std::vector<nxd::KernelTimer> timerPool;
     std::vector<int> timerClass;  // kernel class of timerPool[i]

@@ -83,6 +83,12 @@ static void invalidate_graph(nxhip_ctx* c)
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     c->graphExec = nullptr;
+    for (auto& t : c->graphTimers) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    c->graphTimers.clear();
+    c->graphTimerClass.clear();
     c->graph = nullptr;
     c->graphValid = false;
 }
@@ -719,6 +725,7 @@ static int build_graph(nxhip_ctx* c)
 {
     invalidate_graph(c);
     NX_HIP(hipGraphCreate(&c->graph, 0));
+    const bool timed = c->timingMode == 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
     auto levels = frame_levels(c);
     std::vector<hipGraphNode_t> prev;
     for (auto& level : levels) {
@@ -735,8 +742,21 @@ static int build_graph(nxhip_ctx* c)
             p.kernelParams = args;
             p.extra = nullptr;
             hipGraphNode_t node;
-            NX_HIP(hipGraphAddKernelNode(&node, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
-            cur.push_back(node);
+            if (timed) {
+                c->graphTimers.emplace_back();
+                KernelTimer& t = c->graphTimers.back();
+                c->graphTimerClass.push_back(l.klass);
+                NX_HIP(hipEventCreate(&t.start));
+                NX_HIP(hipEventCreate(&t.stop));
+                hipGraphNode_t before, after;
+                NX_HIP(hipGraphAddEventRecordNode(&before, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start));
+                NX_HIP(hipGraphAddKernelNode(&node, c->graph, &before, 1, &p));
+                NX_HIP(hipGraphAddEventRecordNode(&after, c->graph, &node, 1, t.stop));
+                cur.push_back(after);
+            } else {
+                NX_HIP(hipGraphAddKernelNode(&node, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
+                cur.push_back(node);
+            }
         }
         prev.swap(cur);
     }
@@ -755,7 +775,7 @@ int nxhip_render_frame(nxhip_ctx* c)
     if (rc != NXHIP_OK) return rc;
     rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    if (c->timingEnabled) {
+    if (c->timingEnabled && c->timingMode == 1) {
         // eager path: one event pair per launch, launches strictly in level order on one stream
         auto levels = frame_levels(c);
         for (auto& level : levels)
@@ -771,6 +791,16 @@ int nxhip_render_frame(nxhip_ctx* c)
             if (rc != NXHIP_OK) return rc;
         }
         NX_HIP(hipGraphLaunch(c->graphExec, c->stream));
+        if (c->timingMode == 2) {
+            // the graph's events are re-recorded by the next replay: read them now (timing mode is not the fast path)
+            NX_HIP(hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < c->graphTimers.size(); i++) {
+                float ms = 0.0f;
+                NX_HIP(hipEventElapsedTime(&ms, c->graphTimers[i].start, c->graphTimers[i].stop));
+                c->times.ms[c->graphTimerClass[i]] += ms;
+                c->times.launches[c->graphTimerClass[i]]++;
+            }
+        }
     }
     c->frameNumber += c->framesPerPass;
     return NXHIP_OK;
@@ -1107,6 +1137,9 @@ int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace
 int nxhip_enable_kernel_timing(nxhip_ctx* c, int enable)
 {
     NX_CHECK_CTX(c);
+    if (enable < 0 || enable > 2) return fail_invalid("nxhip_enable_kernel_timing: mode must be 0, 1 or 2");
+    if (enable != c->timingMode) invalidate_graph(c);
+    c->timingMode = enable;
     c->timingEnabled = enable != 0;
     return NXHIP_OK;
 }

@@ -270,3 +270,22 @@ def test_short_last_pass_and_compose_tiles(gpu_ctx_factory):
         hip.hipFree(d_rgba)
     assert np.array_equal(acc[:, :3].view(np.uint32), acc_ref.reshape(-1, 3).view(np.uint32))
     assert np.array_equal(rgba, rgba_ref.reshape(-1))
+
+
+def test_kernel_timing_modes_do_not_change_results(gpu_ctx_factory):
+    W, H = 64, 48
+    scene = SH.material_zoo_scene(W, H, path_length=3)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    want = _render_gpu(ctx, 2)[-1]
+    for in_graph in (False, True):
+        ctx.enable_kernel_timing(True, in_graph=in_graph)
+        ctx.read_kernel_times(reset=True)
+        got = _render_gpu(ctx, 2)[-1]
+        kt = ctx.read_kernel_times(reset=True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert kt["trace"]["launches"] == 2 * 4 and kt["shadow"]["launches"] == 2 * 3 and kt["accumulate"]["launches"] == 2
+        assert all(v["ms"] > 0 for k, v in kt.items() if v["launches"])
+    ctx.enable_kernel_timing(False)
+    assert np.array_equal(_render_gpu(ctx, 2)[-1].view(np.uint32), want.view(np.uint32))
