@@ -11,7 +11,8 @@ import numpy as np
 from . import pod
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnexus_amd.so")
+# NEXUS_AMD_LIB: another build of the same library (tools/ab_bench.sh compares kernel variants); still no fallback
+LIB_PATH = os.environ.get("NEXUS_AMD_LIB") or os.path.join(_HERE, "lib", "libnexus_amd.so")
 
 # every symbol include/nexus_hip.h and include/nexus_host.h declare
 HIP_SYMBOLS = [
