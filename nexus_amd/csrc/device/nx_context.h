@@ -81,6 +81,8 @@ struct nxhip_ctx {
     nxd::DevBuf blasTable;
     nxd::DevBuf tlasNodes, tlasInstIdx, instTrav, instances;
     std::vector<nx_bvh_instance> hostInstances;
+    std::vector<nx_material> hostMaterials;  // kept for the cross-table index check before a render
+    std::vector<nx_light> hostLights;
     std::vector<uint32_t> hostInstIdx;  // TLAS leaf order
     nxd::DevBuf materials, lights;
     std::vector<nxd::TextureHost> diffuseMaps, emissiveMaps;

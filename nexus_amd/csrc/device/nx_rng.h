@@ -71,7 +71,13 @@ NXD f2 unit_disk(uint32_t& rng)
 }
 NXD bool pdf_valid(float pdf) { return isfinite(pdf) && pdf > 1.0e-4f; }
 NXD float power_heuristic(float a, float b) { return a * a / (a * a + b * b); }
-NXD uint32_t uniform_index(uint32_t max, uint32_t& rng) { return (uint32_t)floorf(rng_next(rng) * (float)max); }
+// Sampler.cuh UniformSample*: floor(rand * max).  rand < 1, but rand * max can round up to max when max > 2^23: the
+// reference then reads one element past the end; the index is clamped to max - 1 here (and in the oracle).
+NXD uint32_t uniform_index(uint32_t max, uint32_t& rng)
+{
+    const uint32_t i = (uint32_t)floorf(rng_next(rng) * (float)max);
+    return (max != 0u && i >= max) ? max - 1u : i;
+}
 NXD f2 uniform_triangle(uint32_t& rng)
 {
     const float a = rng_next(rng);

@@ -266,6 +266,9 @@ template <int TYPE>
 NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp, f3 hitPoint, f3 normal, f3 hitGNormal, f3 throughput,
                                uint32_t& rng, ShadowPayload& out)
 {
+    // no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
+    // drawn", identically in the oracle
+    if (S->lightCount == 0u) return false;
     const nx_light light = S->lights[uniform_index(S->lightCount, rng)];
     if (light.type != NX_LIGHT_MESH) return false;
     const nx_bvh_instance* inst = &S->instances[light.mesh.meshId];

@@ -475,6 +475,7 @@ int nxhip_set_materials(nxhip_ctx* c, const nx_material* materials, uint32_t cou
     NX_HIP(hipStreamSynchronize(c->stream));
     NX_ALLOC(c->materials, (size_t)count * sizeof(nx_material));
     NX_HIP(hipMemcpy(c->materials.p, materials, (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
+    c->hostMaterials.assign(materials, materials + count);
     c->h.materials = c->materials.as<nx_material>();
     c->stateDirty = true;
     return NXHIP_OK;
@@ -487,6 +488,7 @@ int nxhip_set_lights(nxhip_ctx* c, const nx_light* lights, uint32_t count)
     NX_HIP(hipStreamSynchronize(c->stream));
     NX_ALLOC(c->lights, std::max<size_t>(1, count) * sizeof(nx_light));
     if (count) NX_HIP(hipMemcpy(c->lights.p, lights, (size_t)count * sizeof(nx_light), hipMemcpyHostToDevice));
+    c->hostLights.assign(lights, lights + (lights ? count : 0));
     c->h.lights = c->lights.as<nx_light>();
     c->h.lightCount = count;
     c->stateDirty = true;
@@ -624,6 +626,16 @@ static int check_scene_ready(nxhip_ctx* c)
 {
     if (!c->h.tlasNodes || c->h.instanceCount == 0) return fail_invalid("no TLAS has been set");
     if (!c->h.materials) return fail_invalid("no materials have been set");
+    // Indices that cross tables are followed by the shading kernels without a bounds test (as in the reference): a bad one
+    // is a wild device read, so they are checked here, on the host copies, before anything is launched.
+    for (const nx_bvh_instance& inst : c->hostInstances)
+        if (inst.materialId < 0 || (size_t)inst.materialId >= c->hostMaterials.size()) return fail_invalid("an instance refers to a material id that has not been set");
+    for (const nx_material& m : c->hostMaterials) {
+        if (m.diffuseMapId < -1 || (m.diffuseMapId >= 0 && (size_t)m.diffuseMapId >= c->diffuseMaps.size())) return fail_invalid("a material refers to a diffuse map that has not been uploaded");
+        if (m.emissiveMapId < -1 || (m.emissiveMapId >= 0 && (size_t)m.emissiveMapId >= c->emissiveMaps.size())) return fail_invalid("a material refers to an emissive map that has not been uploaded");
+    }
+    for (const nx_light& l : c->hostLights)
+        if (l.type == NX_LIGHT_MESH && l.mesh.meshId >= c->hostInstances.size()) return fail_invalid("a mesh light refers to an instance that does not exist");
     return NXHIP_OK;
 }
 

@@ -93,7 +93,13 @@ f2 orc_unit_disk(uint32_t *rng)
 /* Sampler.cuh */
 int orc_pdf_valid(float pdf) { return isfinite(pdf) && pdf > 1.0e-4f; }
 float orc_power_heuristic(float a, float b) { return a * a / (a * a + b * b); }
-uint32_t orc_uniform(uint32_t max, uint32_t *rng) { return (uint32_t)floorf(orc_rand(rng) * (float)max); }
+/* Sampler.cuh UniformSample*: floor(rand * max).  rand < 1, but rand * max can round up to max when max > 2^23: the
+ * reference then reads one element past the end; here (and in the device code) the index is clamped to max - 1. */
+uint32_t orc_uniform(uint32_t max, uint32_t *rng)
+{
+    const uint32_t i = (uint32_t)floorf(orc_rand(rng) * (float)max);
+    return (max != 0u && i >= max) ? max - 1u : i;
+}
 f2 orc_uniform_triangle(uint32_t *rng)
 {
     const float a = orc_rand(rng);

@@ -240,6 +240,9 @@ static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *mat
                 f3 hitGNormal, f3 throughput, uint32_t pixelIdx, uint32_t *rng)
 {
     const orc_scene *s = w->scene;
+    /* no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
+     * drawn", identically in the device code */
+    if (s->lightCount == 0u) return;
     const nx_light light = s->lights[orc_uniform(s->lightCount, rng)];
     if (light.type != NX_LIGHT_MESH) return;
 

@@ -8,12 +8,12 @@ from tests import oracle_lib as O
 
 class BuiltScene:
     def __init__(self, meshes, placements, materials=None, lights=None, camera=None, settings=None, diffuse_maps=(), emissive_maps=(),
-                 hdr_map=None):
-        """meshes: list of TRI_DT arrays; placements: list of (meshIdx, materialId, transform16)."""
+                 hdr_map=None, build_threads=4):
+        """meshes: list of TRI_DT arrays; placements: list of (meshIdx, materialId, transform16); build_threads 0 = all cores."""
         self.meshes = [np.ascontiguousarray(m, dtype=pod.TRI_DT) for m in meshes]
         self.blas = []
         for m in self.meshes:
-            nodes, idx = capi.bvh8_build(m, threads=4)
+            nodes, idx = capi.bvh8_build(m, threads=build_threads)
             self.blas.append((nodes, m, idx))
         insts = []
         for mesh_idx, mat_id, xf in placements:

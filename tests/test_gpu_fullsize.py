@@ -1,0 +1,111 @@
+"""GPU parity at BASELINE.json's full sizes (configs[1], [3], [4]): the oracle cannot render whole frames of these in
+seconds, so it renders a seeded subset of the pixels (pixel-keyed RNG makes a pixel's path independent of the other
+pixels) and traces seeded ray batches; on top of that come size-independent properties: closest-hit / any-hit
+consistency, brute force on a handful of rays, bitwise reproducibility."""
+import numpy as np
+import pytest
+
+from nexus_amd import pod, scenegen
+from tests import config_scenes as CS
+from tests import oracle_lib as O
+from tests import scene_helpers as SH
+
+pytestmark = pytest.mark.gpu
+
+PIXEL_TOL = 1e-3
+
+
+def _subset(width, height, n, seed):
+    return np.sort(np.random.RandomState(seed).choice(width * height, n, replace=False)).astype(np.uint32)
+
+
+def _camera_like_rays(scene, n, seed, extent, radius):
+    a = scenegen.random_rays(n // 2, seed=seed, radius=radius, target_extent=extent)
+    b = scenegen.interior_rays(n - n // 2, seed=seed + 1, extent=extent)
+    return np.concatenate([a, b])
+
+
+def _check_trace_level(ctx, scene, rays, brute=48):
+    orc = scene.oracle()
+    got = ctx.trace_batch(rays)
+    want = orc.trace_closest(rays, threads=8)
+    hit = want["hitDistance"] < 1e29
+    assert hit.mean() > 0.05, "the ray batch must hit the scene"
+    assert SH.hit_records_equal(got, want), "GPU hit records differ from the oracle's"
+    # closest hit <-> any hit: occluded just beyond the closest hit, free just short of it
+    rng = np.random.RandomState(5)
+    side = rng.choice([0.999, 1.001], len(rays))
+    tmax = np.where(hit, want["hitDistance"] * side, 50.0).astype(np.float32)
+    occ = ctx.trace_shadow_batch(rays, tmax)
+    assert np.array_equal(occ[hit], (side[hit] > 1.0)), "any-hit disagrees with the closest hit distance"
+    assert not occ[~hit].any()
+    # ground truth without any BVH on a few rays
+    sub = np.flatnonzero(hit)[:brute]
+    bf = orc.brute_closest(rays[sub])
+    assert np.array_equal(got["hitDistance"][sub].view(np.uint32), bf["hitDistance"].view(np.uint32))
+
+
+def _check_frames(ctx, scene, width, height, n_pixels, frames, min_agree):
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    pm = _subset(width, height, n_pixels, seed=17)
+    w = O.Wavefront(scene.oracle(), len(pm), pm, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
+    ctx.reset_frame_number()
+    first = None
+    for f in range(1, frames + 1):
+        ctx.render_frame()
+        ctx.accumulate()
+        rad = ctx.read_radiance()
+        assert np.isfinite(rad).all()
+        if first is None:
+            first = rad
+        w.render(f, threads=8)
+        w.accumulate(f)
+        want = w.radiance()
+        assert want.max() > 0.0, "the pixel subset must see light"
+        agree = SH.image_agreement(rad[pm], want, PIXEL_TOL)
+        assert agree >= min_agree, (f, agree)
+    acc = ctx.read_accumulation()
+    assert SH.image_agreement(acc[pm], w.accumulation(), PIXEL_TOL) >= min_agree
+    # primary rays see no transcendental function: the first trace queue is exact
+    q = ctx.read_queue_sizes()
+    assert q["traceSize"][0] == width * height
+    # idempotence: the same frames again, bit for bit
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    assert np.array_equal(ctx.read_radiance().view(np.uint32), first.view(np.uint32))
+    return w
+
+
+def test_config2_one_million_triangles_1080p(gpu_ctx_factory):
+    W, H = 1920, 1080
+    scene = CS.config2(W, H)
+    assert sum(len(b[1]) for b in scene.blas) == 1048576 + 4
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    _check_trace_level(ctx, scene, _camera_like_rays(scene, 200000, 3, extent=1.6, radius=6.0))
+    _check_frames(ctx, scene, W, H, n_pixels=8192, frames=2, min_agree=0.99)
+
+
+def test_config4_thousand_instances_dielectric_environment(gpu_ctx_factory):
+    W, H = 1920, 1080
+    scene = CS.config4(W, H)
+    assert len(scene.instances) == 1000 and len(scene.blas[0][1]) == 100000
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    _check_trace_level(ctx, scene, _camera_like_rays(scene, 100000, 7, extent=8.0, radius=25.0), brute=8)
+    _check_frames(ctx, scene, W, H, n_pixels=4096, frames=2, min_agree=0.97)
+
+
+def test_config5_ten_million_triangles_4k_path16(gpu_ctx_factory):
+    W, H = 3840, 2160
+    scene = CS.config5(W, H)
+    assert sum(len(b[1]) for b in scene.blas) > 9_900_000
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    _check_trace_level(ctx, scene, _camera_like_rays(scene, 100000, 9, extent=5.0, radius=12.0), brute=4)
+    w = _check_frames(ctx, scene, W, H, n_pixels=4096, frames=1, min_agree=0.97)
+    # every material queue is exercised at this size
+    q = ctx.read_queue_sizes()
+    for k in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize"):
+        assert q[k][1] > 0, k
+    assert q["traceShadowSize"][1] > 0

@@ -289,3 +289,37 @@ def test_kernel_timing_modes_do_not_change_results(gpu_ctx_factory):
         assert all(v["ms"] > 0 for k, v in kt.items() if v["launches"])
     ctx.enable_kernel_timing(False)
     assert np.array_equal(_render_gpu(ctx, 2)[-1].view(np.uint32), want.view(np.uint32))
+
+
+def test_cross_table_indices_are_validated_before_launch(gpu_ctx_factory):
+    """Indices the kernels follow without a bounds test (instance -> material, material -> texture, light -> instance) are
+    checked on the host; a scene without lights renders (NEE is skipped) instead of indexing an empty light table."""
+    from nexus_amd.capi import NexusError
+
+    W, H = 48, 32
+    scene = SH.material_zoo_scene(W, H, path_length=3)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.render_frame()
+    bad = scene.materials.copy()
+    bad["diffuseMapId"][1] = 7
+    ctx.set_materials(bad)
+    with pytest.raises(NexusError):
+        ctx.render_frame()
+    ctx.set_materials(scene.materials[:2])  # instances refer to materials 0..5
+    with pytest.raises(NexusError):
+        ctx.render_frame()
+    ctx.set_materials(scene.materials)
+    lights = scene.lights.copy()
+    lights["meshId"][0] = len(scene.instances)
+    ctx.set_lights(lights)
+    with pytest.raises(NexusError):
+        ctx.render_frame()
+    # no lights at all: defined behaviour, identical in the oracle
+    ctx.set_lights(np.zeros(0, pod.LIGHT_DT))
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    got = _render_gpu(ctx, 1)[-1]
+    scene.lights = np.zeros(0, pod.LIGHT_DT)
+    _, want = _render_oracle(scene, W * H, 1, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
+    assert np.isfinite(got).all() and SH.image_agreement(got, want[-1], PIXEL_TOL) >= 0.99
+    assert ctx.read_queue_sizes()["traceShadowSize"][1] == 0
