@@ -394,13 +394,16 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 ng = make_uint2(0u, 0x80000000u);
                 tg = make_uint2(0u, 0u);
                 // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
-                // An identity inverse transform maps the ray onto itself bit for bit (1*x, fma(0,y,x), +0), so the
-                // transform, the three divisions and the restore on exit are skipped for such instances.
-                xformed = !(r0.x == 1.0f && r0.y == 0.0f && r0.z == 0.0f && r0.w == 0.0f && r1.x == 0.0f && r1.y == 1.0f && r1.z == 0.0f && r1.w == 0.0f &&
-                            r2.x == 0.0f && r2.y == 0.0f && r2.z == 1.0f && r2.w == 0.0f);
+                // A transform that maps this ray onto itself bit for bit (in practice: the identity) leaves 1/dir as it
+                // is, so the three divisions here and the reload + three divisions on exit are skipped.  Compared as bit
+                // patterns: a zero component whose sign the transform flips (-0 -> +0) counts as changed.
+                const f3 o2 = mat_point(r0, r1, r2, org);
+                const f3 d2 = mat_vec(r0, r1, r2, dir);
+                xformed = ((__float_as_uint(o2.x) ^ __float_as_uint(org.x)) | (__float_as_uint(o2.y) ^ __float_as_uint(org.y)) | (__float_as_uint(o2.z) ^ __float_as_uint(org.z)) |
+                           (__float_as_uint(d2.x) ^ __float_as_uint(dir.x)) | (__float_as_uint(d2.y) ^ __float_as_uint(dir.y)) | (__float_as_uint(d2.z) ^ __float_as_uint(dir.z))) != 0u;
                 if (xformed) {
-                    org = mat_point(r0, r1, r2, org);
-                    dir = mat_vec(r0, r1, r2, dir);
+                    org = o2;
+                    dir = d2;
                     idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                 }
                 if (STATS) nInst++;
