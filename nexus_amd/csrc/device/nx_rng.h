@@ -72,7 +72,7 @@ NXD f2 unit_disk(uint32_t& rng)
 NXD bool pdf_valid(float pdf) { return isfinite(pdf) && pdf > 1.0e-4f; }
 NXD float power_heuristic(float a, float b) { return a * a / (a * a + b * b); }
 // Sampler.cuh UniformSample*: floor(rand * max).  rand < 1, but rand * max can round up to max when max > 2^23: the
-// reference then reads one element past the end; the index is clamped to max - 1 here (and in the oracle).
+// reference then reads one element past the end; the index is clamped to max - 1 here (and in the CPU restatement used by the tests).
 NXD uint32_t uniform_index(uint32_t max, uint32_t& rng)
 {
     const uint32_t i = (uint32_t)floorf(rng_next(rng) * (float)max);

@@ -267,7 +267,7 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
                                uint32_t& rng, ShadowPayload& out)
 {
     // no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
-    // drawn", identically in the oracle
+    // drawn", identically in the CPU restatement used by the tests
     if (S->lightCount == 0u) return false;
     const nx_light light = S->lights[uniform_index(S->lightCount, rng)];
     if (light.type != NX_LIGHT_MESH) return false;
