@@ -6,7 +6,8 @@
 //  Cuda/Geometry/Triangle.cuh:53-118 Moeller-Trumbore): per ray the same nodes are visited in the same
 // order and the same hit record results.  How it is organised is CDNA4-first:
 //   * one ray per lane of a 64-wide wave; persistent workgroups; a wave reserves 256 rays with ONE atomic and hands them
-//     to idle lanes by ballot + popcount rank (the reference does one atomicAdd per ray);
+//     to idle lanes by ballot + popcount rank (the reference does one atomicAdd per ray); waves a small queue does not
+//     need leave at once, and a wave whose shard is dry picks the next one from a single load of all fetch heads;
 //   * the ray queue is cut into 8 contiguous shards, one fetch head per XCD group (blockIdx % 8 share an
 //     XCD and its private 4 MiB L2): waves of one XCD walk one band of the image / queue so the BVH
 //     subtrees they touch stay in that XCD's L2, and the head word is not hammered by 256 CUs; a wave
@@ -198,10 +199,19 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     // shard geometry: 8 contiguous, 64-aligned pieces of the queue
     const int chunk = ((size + kXcds * kWave - 1) / (kXcds * kWave)) * kWave;
-    int shard = blockIdx.x & (kXcds - 1);
-    int shardsTried = 0;
+    const int homeShard = blockIdx.x & (kXcds - 1);
+    const int homeBegin = homeShard * chunk;
+    const int homeRays = max(0, min(size, homeBegin + chunk) - homeBegin);
+    // this wave's rank among the waves that call this shard home
+    const int rankInShard = (int)(blockIdx.x >> 3) * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
+    // A wave whose rank is beyond the shard's ray count (one ray per lane) is not needed: it leaves without touching a
+    // fetch head.  The grid is sized for the largest queue; on a small one most waves would otherwise each walk all 8
+    // heads with returning atomics to find out that nothing is left, which made every launch cost about 0.5 ms however
+    // few rays it carried.
+    if (rankInShard * kWave >= homeRays) return;
+    int shard = homeShard;
     bool exhausted = false;
-    int rngCur = 0, rngEnd = 0;  // rays of the current shard reserved by this wave and not handed to a lane yet
+    int rngCur = 0, rngEnd = 0;  // rays reserved by this wave and not handed to a lane yet
 
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
 #ifdef NX_COOP_FETCH
@@ -242,18 +252,35 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 if (needMask == 0ull) break;
                 if (rngCur >= rngEnd) {
                     if (exhausted) break;
+                    // one returning atomic reserves kReserve rays of `shard` (the head counts rays handed out)
                     const int leader = __ffsll((long long)needMask) - 1;
+                    const int shardBegin = shard * chunk;
+                    const int shardEnd = min(size, shardBegin + chunk);
                     int base = 0;
                     if (lane == leader) base = atomicAdd(&heads[shard], kReserve);
                     base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-                    const int shardBegin = shard * chunk;
-                    const int shardEnd = min(size, shardBegin + chunk);
                     rngCur = shardBegin + base;
                     rngEnd = min(shardEnd, rngCur + kReserve);
-                    if (rngCur >= shardEnd) {  // this shard is dry: steal from the next XCD's
+                    if (rngCur >= shardEnd) {
+                        // this shard is dry: one load of all 8 heads tells which shards still hold rays (a load is served
+                        // in parallel with other waves', returning atomics on a head are serialised); go to the fullest
                         rngCur = rngEnd = 0;
-                        shard = (shard + 1) & (kXcds - 1);
-                        if (++shardsTried == kXcds) exhausted = true;
+                        int left = 0;
+                        if (lane < kXcds) {
+                            const int b2 = lane * chunk, e2 = min(size, b2 + chunk);
+                            const int taken = __hip_atomic_load(&heads[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            left = max(0, (e2 - b2) - taken);
+                        }
+                        int best = 0, bestLeft = 0;
+#pragma unroll
+                        for (int k = 0; k < kXcds; k++) {
+                            const int l = __shfl(left, k);
+                            if (l > bestLeft) { bestLeft = l; best = k; }
+                        }
+                        best = __builtin_amdgcn_readfirstlane(best);
+                        bestLeft = __builtin_amdgcn_readfirstlane(bestLeft);
+                        if (bestLeft <= 0) exhausted = true;
+                        else shard = best;
                         continue;
                     }
                 }

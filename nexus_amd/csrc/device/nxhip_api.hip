@@ -847,7 +847,7 @@ int nxhip_accumulate(nxhip_ctx* c)
 int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
 {
     NX_CHECK_CTX(c);
-    if (frames == 0 || frames > 64) return fail_invalid("nxhip_set_frames_per_pass: frames must be in [1, 64]");
+    if (frames == 0 || frames > 1024) return fail_invalid("nxhip_set_frames_per_pass: frames must be in [1, 1024]");
     if ((uint64_t)c->localCount * frames > 0x7fffffffull) return fail_invalid("nxhip_set_frames_per_pass: more than 2^31 paths");
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
