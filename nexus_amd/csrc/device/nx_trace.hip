@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             }
             NX_STAMP(5);
             activeMask = __ballot(active);
-        } while (activeMask != 0ull && (exhausted || __popcll(activeMask) >= kRefillBelow));
+        } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
     }
 
     if (STATS) {

@@ -1,6 +1,8 @@
 """Worker of tests/test_multi_rank_gloo.py: one rank of the N > 1 path on CPU (gloo).  Each rank renders its tiles with
-the CPU oracle (standing in for the HIP path, which needs a GPU), the radiance tiles are gathered to rank 0 with one
-gather, de-interleaved and accumulated — the same sequence bench.py runs over RCCL."""
+the CPU oracle (standing in for the HIP path, which needs a GPU).  Two exchange schemes, both with ONE gather per pass:
+  "tiles"    (what bench.py runs over RCCL) every rank accumulates its own tiles; the accumulated tiles are gathered and
+             scattered into the full image on rank 0;
+  "radiance" the per-frame radiance tiles are gathered and rank 0 accumulates (nxhip_accumulate_external)."""
 import os
 import sys
 
@@ -25,17 +27,24 @@ def main():
     scene = SH.cornell_scene(W, H, path_length=3)
     pm = multigpu.tile_pixel_map(W, H, rank, world, tile)
     w = O.Wavefront(scene.oracle(), len(pm), pm, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_REFERENCE)
-    acc = None
+    acc = None          # scheme "radiance": root-side accumulation of gathered radiance
+    composed = None     # scheme "tiles": gathered per-rank accumulations
     for f in range(1, FRAMES + 1):
         w.render(f)
+        w.accumulate(f)
         rad = torch.from_numpy(w.radiance().copy())
         gathered = [torch.zeros_like(rad) for _ in range(world)] if rank == 0 else None
         dist.gather(rad, gathered, dst=0)
         if rank == 0:
             full = multigpu.reassemble(W, H, world, tile, [g.numpy() for g in gathered])
             acc = multigpu.running_mean(acc, full, f)
+        mine = torch.from_numpy(w.accumulation().copy())
+        tiles = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, tiles, dst=0)
+        if rank == 0:
+            composed = multigpu.reassemble(W, H, world, tile, [t.numpy() for t in tiles])
     if rank == 0:
-        np.save(out_path, acc)
+        np.save(out_path, np.stack([acc, composed]))
     dist.barrier()
     dist.destroy_process_group()
 

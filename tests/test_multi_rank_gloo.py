@@ -38,5 +38,7 @@ def test_two_rank_gloo_gather_equals_single_rank(tmp_path):
     for f in range(1, FRAMES + 1):
         w.render(f)
         acc = multigpu.running_mean(acc, w.radiance(), f)
-    # pixel-keyed RNG: the two-rank image is the single-rank image, bit for bit
-    assert np.array_equal(got.view(np.uint32), acc.view(np.uint32))
+    # pixel-keyed RNG: the two-rank image is the single-rank image, bit for bit, under both exchange schemes
+    assert got.shape[0] == 2
+    assert np.array_equal(got[0].view(np.uint32), acc.view(np.uint32)), "radiance gather + root accumulate"
+    assert np.array_equal(got[1].view(np.uint32), acc.view(np.uint32)), "per-rank accumulation + tile gather"
