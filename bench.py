@@ -323,16 +323,16 @@ def main():
         bytes_per_launch = trace_algorithmic_bytes(closest) / max(1, launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM-side traffic per launch cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes
-        # over this same workload (profiles/r01_b_traffic.json), and is reported only when the workload matches
+        # over this same workload (profiles/r01_c_traffic.json), and is reported only when the workload matches
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             tw = tj.get("workload", {})
             if (tw.get("width"), tw.get("height"), tw.get("nu"), tw.get("nv"), tw.get("path_length"), tw.get("frames_per_pass")) == \
                     (W, H, args.nu, args.nv, args.path_length, S):
                 traffic = int(tj["kernels"]["trace_closest"]["hbm_bytes_per_launch"])
-                traffic_src = "profiles/r01_b_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of MI355X_MICROARCH.md)"
+                traffic_src = "profiles/r01_c_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of MI355X_MICROARCH.md)"
         out["roofline"] = {
             "bound": "hbm", "kernel": "trace_kernel<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,

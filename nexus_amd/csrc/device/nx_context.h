@@ -111,4 +111,5 @@ struct nxhip_ctx {
     bool graphValid = false;
 
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;
+    int shadeBlocksPerCU = 4, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
 };

@@ -322,7 +322,10 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
 }
 
 template <int TYPE, bool ORDERED>
-__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, 4) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+#ifndef NX_SHADE_WAVES
+#define NX_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const int size = C->materialSize[TYPE][bounce];

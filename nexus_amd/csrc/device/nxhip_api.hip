@@ -256,6 +256,14 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             const int n = std::atoi(e);
             if (n >= 1 && n <= 16) c->traceBlocks = c->shadowBlocks = n * c->numCUs;
         }
+        if (const char* e = std::getenv("NX_SHADE_BLOCKS_PER_CU")) {  // tuning experiments only
+            const int n = std::atoi(e);
+            if (n >= 1 && n <= 64) c->shadeBlocksPerCU = n;
+        }
+        if (const char* e = std::getenv("NX_LOGIC_BLOCKS_PER_CU")) {  // tuning experiments only
+            const int n = std::atoi(e);
+            if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
+        }
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
             const int n = std::atoi(e);
             if (n >= 1 && n <= 65536) c->traceBlocks = c->shadowBlocks = n;
@@ -683,8 +691,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
-    const int og = ordered ? 1 : 4 * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
-    const int lg = ordered ? 1 : 2 * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
+    const int og = ordered ? 1 : c->shadeBlocksPerCU * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
+    const int lg = ordered ? 1 : c->logicBlocksPerCU * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
     for (int bounce = 1; bounce <= pathLength; bounce++) {
         levels.push_back({make_launch(logic_kernel_ptr(ordered), lg, lb, NXHIP_K_LOGIC, S, bounce)});
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
