@@ -149,6 +149,17 @@ int nxhip_trace_batch(nxhip_ctx *ctx, const nx_ray *rays, uint32_t count, nx_hit
 /* TraceShadowKernel's any-hit test — BVH8Traversal.cuh:326-518.  occluded[i] = 1 if blocked within tmax[i]. */
 int nxhip_trace_shadow_batch(nxhip_ctx *ctx, const nx_ray *rays, const float *tmax, uint32_t count, uint8_t *occluded);
 
+/* Kernel-level test hooks for the shading functions (same role as nxhip_trace_batch for the traversal): run the device
+ * BSDF sample / eval (the headers of Cuda/BSDF/ as restated in nx_bsdf.h) and the software texture fetch on host arrays.
+ * sample: uses wi and rng (the xorshift state before the call); eval: uses wi and wo.  Directions are in the local
+ * shading frame (z = normal).  `material` is one nx_material; its type selects the BSDF (a CONDUCTOR runs the extended
+ * conductor BSDF whatever the context's conductor mode).  nx_bsdf_query / nx_bsdf_result: nexus_pod.h. */
+int nxhip_bsdf_sample_batch(nxhip_ctx *ctx, const nx_material *material, const nx_bsdf_query *queries, uint32_t count, nx_bsdf_result *results);
+int nxhip_bsdf_eval_batch(nxhip_ctx *ctx, const nx_material *material, const nx_bsdf_query *queries, uint32_t count, nx_bsdf_result *results);
+/* kind as in nxhip_upload_texture (0 diffuse, 1 emissive, 2 hdr; textureId ignored for hdr); uv = 2*count floats,
+ * rgba = 4*count floats (sRGB-decoded, bilinear, wrap addressing: what the shade kernels see). */
+int nxhip_tex2d_batch(nxhip_ctx *ctx, int kind, int textureId, const float *uv, uint32_t count, float *rgba);
+
 /* Visit counters of the two trace kernels (algorithmic bytes for the roofline).  When enabled
  * the trace kernels run their counting variant; off by default. */
 typedef struct nxhip_trace_stats {

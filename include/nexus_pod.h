@@ -131,6 +131,25 @@ typedef struct nx_texture_desc {
     const uint8_t *rgba8;
 } nx_texture_desc;
 
+/* query / result of the BSDF test hooks (nxhip_bsdf_sample_batch, nxhip_bsdf_eval_batch) */
+typedef struct nx_bsdf_query {
+    float wi[3];
+    uint32_t rng;
+    float wo[3];
+    uint32_t pad_;
+} nx_bsdf_query;
+typedef struct nx_bsdf_result {
+    float wo[3];
+    float pdf;
+    float throughput[3];
+    uint32_t ok;      /* the BSDF's return value (false: sample rejected / invalid pdf) */
+    uint32_t rngOut;  /* xorshift state after the call (sample only) */
+    uint32_t pad_[3];
+} nx_bsdf_result;
+NX_STATIC_ASSERT(sizeof(nx_bsdf_query) == 32, "nx_bsdf_query must be 32 bytes");
+NX_STATIC_ASSERT(sizeof(nx_bsdf_result) == 48, "nx_bsdf_result must be 48 bytes");
+
+
 /* How Logic/Shade seed their RNG.  REFERENCE_SLOT mirrors Cuda/Random.cuh:79-82 + PathTracer.cu:143,326
  * (seed by queue slot, no bounce term).  PIXEL_KEYED seeds by (global pixel, bounce, frame): the image
  * then does not depend on queue slot order, so it is reproducible under racing compaction and under a

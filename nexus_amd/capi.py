@@ -23,7 +23,7 @@ HIP_SYMBOLS = [
     "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
     "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
-    "nxhip_trace_shadow_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
+    "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
 ]
 HOST_SYMBOLS = [
@@ -117,6 +117,9 @@ def lib():
     L.nxhip_get_selected_instance.argtypes = [vp, C.POINTER(i32)]
     L.nxhip_trace_batch.argtypes = [vp, vp, u32, vp]
     L.nxhip_trace_shadow_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.nxhip_bsdf_sample_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.nxhip_bsdf_eval_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.nxhip_tex2d_batch.argtypes = [vp, C.c_int, C.c_int, vp, u32, vp]
     L.nxhip_enable_trace_stats.argtypes = [vp, C.c_int]
     L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
     L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
@@ -456,6 +459,25 @@ class Context:
         occ = np.zeros(len(rays), dtype=np.uint8)
         check(self.L.nxhip_trace_shadow_batch(self.h, _ptr(rays), _ptr(tmax), len(rays), _ptr(occ)), "nxhip_trace_shadow_batch")
         return occ
+
+    def _bsdf_batch(self, fn, name, material, queries):
+        mat = np.ascontiguousarray(material, dtype=pod.MAT_DT).reshape(1)
+        q = np.ascontiguousarray(queries, dtype=pod.BSDF_QUERY_DT)
+        out = np.zeros(len(q), dtype=pod.BSDF_RESULT_DT)
+        check(fn(self.h, _ptr(mat), _ptr(q), len(q), _ptr(out)), name)
+        return out
+
+    def bsdf_sample_batch(self, material, queries):
+        return self._bsdf_batch(self.L.nxhip_bsdf_sample_batch, "nxhip_bsdf_sample_batch", material, queries)
+
+    def bsdf_eval_batch(self, material, queries):
+        return self._bsdf_batch(self.L.nxhip_bsdf_eval_batch, "nxhip_bsdf_eval_batch", material, queries)
+
+    def tex2d_batch(self, kind, texture_id, uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        check(self.L.nxhip_tex2d_batch(self.h, {"diffuse": 0, "emissive": 1, "hdr": 2}[kind], int(texture_id), _ptr(uv), len(uv), _ptr(out)), "nxhip_tex2d_batch")
+        return out
 
     def enable_trace_stats(self, on=True):
         check(self.L.nxhip_enable_trace_stats(self.h, 1 if on else 0), "nxhip_enable_trace_stats")

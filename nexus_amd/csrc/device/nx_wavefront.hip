@@ -520,6 +520,50 @@ __global__ void __launch_bounds__(kWideBlock) compose_kernel(const float4* __res
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Test hooks: the shading functions on plain arrays (nxhip_bsdf_*_batch, nxhip_tex2d_batch)
+
+template <int TYPE>
+NXD void bsdf_hook_one(const MatParams& mp, bool sample, const nx_bsdf_query& q, nx_bsdf_result& r)
+{
+    f3 wo = ld3(q.wo), thr = mk3(0.0f);
+    float pdf = 0.0f;
+    uint32_t rng = q.rng;
+    const bool ok = sample ? Bsdf<TYPE>::sample(mp, ld3(q.wi), rng, wo, thr, pdf) : Bsdf<TYPE>::eval(mp, ld3(q.wi), wo, thr, pdf);
+    r.wo[0] = wo.x; r.wo[1] = wo.y; r.wo[2] = wo.z;
+    r.pdf = pdf;
+    r.throughput[0] = thr.x; r.throughput[1] = thr.y; r.throughput[2] = thr.z;
+    r.ok = ok ? 1u : 0u;
+    r.rngOut = rng;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0u;
+}
+
+__global__ void __launch_bounds__(kWideBlock) bsdf_hook_kernel(const nx_material* __restrict__ material, const nx_bsdf_query* __restrict__ q, const uint32_t count,
+                                                                const int sample, nx_bsdf_result* __restrict__ out)
+{
+    const nx_material m = *material;
+    const MatParams mp = load_params(m);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        nx_bsdf_result r;
+        switch (m.type) {
+        case NX_MAT_DIFFUSE: bsdf_hook_one<NX_MAT_DIFFUSE>(mp, sample != 0, q[k], r); break;
+        case NX_MAT_DIELECTRIC: bsdf_hook_one<NX_MAT_DIELECTRIC>(mp, sample != 0, q[k], r); break;
+        case NX_MAT_PLASTIC: bsdf_hook_one<NX_MAT_PLASTIC>(mp, sample != 0, q[k], r); break;
+        default: bsdf_hook_one<NX_MAT_CONDUCTOR>(mp, sample != 0, q[k], r); break;
+        }
+        out[k] = r;
+    }
+}
+
+// (the texture descriptor comes by value: selecting one of S->diffuseMaps[i] / S->emissiveMaps[i] / S->hdrMap with a
+//  uniform three-way branch here was miscompiled by hipcc 7.2 — the third arm left the descriptor pointer unset)
+__global__ void __launch_bounds__(kWideBlock) tex2d_hook_kernel(const TextureDev t, const float* __restrict__ srgbLut, const float* __restrict__ uv,
+                                                                 const uint32_t count, float4* __restrict__ out)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+        out[k] = tex2d(t, srgbLut, uv[2 * k], uv[2 * k + 1]);
+}
+
+// ------------------------------------------------------------------------------------------------------
 
 const void* logic_kernel_ptr(bool ordered) { return ordered ? (const void*)logic_kernel<true> : (const void*)logic_kernel<false>; }
 
@@ -536,5 +580,7 @@ const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
 const void* generate_kernel_ptr() { return (const void*)generate_kernel; }
 const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }
 const void* compose_kernel_ptr() { return (const void*)compose_kernel; }
+const void* bsdf_hook_kernel_ptr() { return (const void*)bsdf_hook_kernel; }
+const void* tex2d_hook_kernel_ptr() { return (const void*)tex2d_hook_kernel; }
 
 }  // namespace nxd

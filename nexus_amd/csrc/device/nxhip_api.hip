@@ -21,6 +21,8 @@ const void* begin_frame_kernel_ptr();
 const void* generate_kernel_ptr();
 const void* accumulate_kernel_ptr();
 const void* compose_kernel_ptr();
+const void* bsdf_hook_kernel_ptr();
+const void* tex2d_hook_kernel_ptr();
 
 static thread_local std::string g_lastError;
 
@@ -1151,6 +1153,65 @@ int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace
     if (closest) std::memcpy(closest, &h[0], sizeof h[0]);
     if (shadow) std::memcpy(shadow, &h[1], sizeof h[1]);
     if (reset) NX_HIP(hipMemset(c->traceStats.p, 0, sizeof h));
+    return NXHIP_OK;
+}
+
+static int bsdf_hook(nxhip_ctx* c, const nx_material* material, const nx_bsdf_query* queries, uint32_t count, nx_bsdf_result* results, int sample)
+{
+    NX_CHECK_CTX(c);
+    if (!material || (!queries && count) || (!results && count)) return fail_invalid("nxhip_bsdf_*_batch: null buffer");
+    if (material->type < NX_MAT_DIFFUSE || material->type > NX_MAT_CONDUCTOR) return fail_invalid("nxhip_bsdf_*_batch: unknown material type");
+    if (count == 0) return NXHIP_OK;
+    NX_HIP(hipSetDevice(c->device));
+    DevBuf dMat, dQ, dR;
+    NX_ALLOC(dMat, sizeof(nx_material));
+    NX_ALLOC(dQ, (size_t)count * sizeof(nx_bsdf_query));
+    NX_ALLOC(dR, (size_t)count * sizeof(nx_bsdf_result));
+    NX_HIP(hipMemcpy(dMat.p, material, sizeof(nx_material), hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(dQ.p, queries, (size_t)count * sizeof(nx_bsdf_query), hipMemcpyHostToDevice));
+    const nx_material* pm = dMat.as<nx_material>();
+    const nx_bsdf_query* pq = dQ.as<nx_bsdf_query>();
+    nx_bsdf_result* pr = dR.as<nx_bsdf_result>();
+    void* args[5] = {(void*)&pm, (void*)&pq, (void*)&count, (void*)&sample, (void*)&pr};
+    NX_HIP(hipLaunchKernel(bsdf_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_HIP(hipMemcpy(results, dR.p, (size_t)count * sizeof(nx_bsdf_result), hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+int nxhip_bsdf_sample_batch(nxhip_ctx* c, const nx_material* material, const nx_bsdf_query* queries, uint32_t count, nx_bsdf_result* results)
+{
+    return bsdf_hook(c, material, queries, count, results, 1);
+}
+
+int nxhip_bsdf_eval_batch(nxhip_ctx* c, const nx_material* material, const nx_bsdf_query* queries, uint32_t count, nx_bsdf_result* results)
+{
+    return bsdf_hook(c, material, queries, count, results, 0);
+}
+
+int nxhip_tex2d_batch(nxhip_ctx* c, int kind, int textureId, const float* uv, uint32_t count, float* rgba)
+{
+    NX_CHECK_CTX(c);
+    if ((!uv || !rgba) && count) return fail_invalid("nxhip_tex2d_batch: null buffer");
+    if (kind < 0 || kind > 2) return fail_invalid("nxhip_tex2d_batch: kind must be 0, 1 or 2");
+    if (kind == 0 && (textureId < 0 || (size_t)textureId >= c->diffuseMaps.size())) return fail_invalid("nxhip_tex2d_batch: no such diffuse map");
+    if (kind == 1 && (textureId < 0 || (size_t)textureId >= c->emissiveMaps.size())) return fail_invalid("nxhip_tex2d_batch: no such emissive map");
+    if (kind == 2 && !c->hdrMap.texels.p) return fail_invalid("nxhip_tex2d_batch: no environment map has been uploaded");
+    if (count == 0) return NXHIP_OK;
+    NX_HIP(hipSetDevice(c->device));
+    const TextureHost& th = kind == 0 ? c->diffuseMaps[textureId] : kind == 1 ? c->emissiveMaps[textureId] : c->hdrMap;
+    TextureDev t{th.texels.as<uint32_t>(), th.width, th.height};
+    DevBuf dUv, dOut;
+    NX_ALLOC(dUv, (size_t)count * 8);
+    NX_ALLOC(dOut, (size_t)count * 16);
+    NX_HIP(hipMemcpy(dUv.p, uv, (size_t)count * 8, hipMemcpyHostToDevice));
+    const float* lut = c->srgbLut.as<float>();
+    const float* pu = dUv.as<float>();
+    float4* po = dOut.as<float4>();
+    void* args[5] = {(void*)&t, (void*)&lut, (void*)&pu, (void*)&count, (void*)&po};
+    NX_HIP(hipLaunchKernel(tex2d_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_HIP(hipMemcpy(rgba, dOut.p, (size_t)count * 16, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
 
