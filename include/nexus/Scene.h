@@ -5,6 +5,7 @@
 
 #include <memory>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "Assets.h"
@@ -35,6 +36,8 @@ public:
     void Update();     // apply instance transforms / materials, rebuild + convert the TLAS
     void BuildTLAS();
     MeshInstance& CreateMeshInstance(uint32_t meshId);
+    // Scene.cpp:83-91: load a .glb / .obj (OBJLoader::LoadOBJ), one BVH per mesh, one instance per (node, primitive)
+    void CreateMeshInstanceFromFile(const std::string& path, const std::string& fileName);
     std::vector<MeshInstance>& GetMeshInstances() { return m_MeshInstances; }
     const std::vector<BVHInstance>& GetBVHInstances() const { return m_BVHInstances; }
     void AddHDRMap(const Texture& texture);

@@ -44,6 +44,25 @@ int nxh_camera_init(nx_camera *out, const float position[3], const float forward
 /* ---- flat view of nexus::Scene / nexus::AssetManager / nexus::PathTracer (include/nexus/Scene.h, PathTracer.h) ------
  * The call sequence is the reference's: load meshes -> AssetManager::CreateBVH + AddMesh, Scene::CreateMeshInstance,
  * Scene::Update (TLAS build), PathTracer::UpdateDeviceScene, PathTracer::Render (Renderer/Renderer.cpp:41-77). */
+/* ---- scene files (nexus::OBJLoader, include/nexus/OBJLoader.h): binary glTF 2.0 (.glb) and Wavefront .obj without Assimp.
+ * Replaces what Assets/OBJLoader.cpp:8-239 obtains through Assimp: one mesh per glTF primitive, one instance per
+ * (node, primitive) with the node transform decomposed to position / Euler degrees / scale, the reference's material
+ * heuristics.  Returns 0 on success; the message of a failure is in nxs_last_error(). */
+typedef struct nxh_loaded_scene nxh_loaded_scene;
+typedef struct nx_loaded_instance {
+    int32_t mesh, material;
+    float position[3], rotation[3] /* Euler XYZ, degrees */, scale[3];
+} nx_loaded_instance;
+int nxh_load_scene_file(const char *file, nxh_loaded_scene **out);
+void nxh_loaded_scene_free(nxh_loaded_scene *s);
+uint32_t nxh_loaded_mesh_count(const nxh_loaded_scene *s);
+uint32_t nxh_loaded_mesh_triangle_count(const nxh_loaded_scene *s, uint32_t mesh);
+int nxh_loaded_mesh_triangles(const nxh_loaded_scene *s, uint32_t mesh, nx_triangle *dst);
+uint32_t nxh_loaded_material_count(const nxh_loaded_scene *s);
+int nxh_loaded_materials(const nxh_loaded_scene *s, nx_material *dst);
+uint32_t nxh_loaded_instance_count(const nxh_loaded_scene *s);
+int nxh_loaded_instances(const nxh_loaded_scene *s, nx_loaded_instance *dst);
+
 typedef struct nxs_scene nxs_scene;
 typedef struct nxs_pathtracer nxs_pathtracer;
 struct nxhip_ctx;
@@ -57,6 +76,8 @@ int nxs_scene_set_hdr_map(nxs_scene *s, const uint8_t *rgba8, uint32_t w, uint32
 int nxs_scene_add_mesh(nxs_scene *s, const nx_triangle *tris, uint32_t triCount, int32_t materialId, int32_t *meshId);
 int nxs_scene_create_instance(nxs_scene *s, uint32_t meshId, int32_t materialId, const float pos[3], const float rotDeg[3],
                               const float scale[3], int32_t *instanceId);
+/* Scene::CreateMeshInstanceFromFile — Scene.cpp:83-91: adds the file's materials, meshes (one BVH8 each) and instances. */
+int nxs_scene_load_file(nxs_scene *s, const char *path, const char *fileName);
 int nxs_scene_set_camera(nxs_scene *s, const float pos[3], const float forward[3], float horizontalFovDeg, float focusDist,
                          float defocusAngleDeg);
 int nxs_scene_set_render_settings(nxs_scene *s, const nx_render_settings *settings);

@@ -30,6 +30,8 @@ HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
     "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
     "nxh_instance_init", "nxh_camera_init",
+    "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
+    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
     "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes",
@@ -144,6 +146,18 @@ def lib():
     L.nxh_mat4_invert.restype = None
     L.nxh_instance_init.argtypes = [vp, u32, i32, vp, vp]
     L.nxh_camera_init.argtypes = [vp, vp, vp, f32, u32, u32, f32, f32]
+    L.nxh_load_scene_file.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.nxh_loaded_scene_free.argtypes = [vp]
+    L.nxh_loaded_scene_free.restype = None
+    for f in ("nxh_loaded_mesh_count", "nxh_loaded_material_count", "nxh_loaded_instance_count"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = u32
+    L.nxh_loaded_mesh_triangle_count.argtypes = [vp, u32]
+    L.nxh_loaded_mesh_triangle_count.restype = u32
+    L.nxh_loaded_mesh_triangles.argtypes = [vp, u32, vp]
+    L.nxh_loaded_materials.argtypes = [vp, vp]
+    L.nxh_loaded_instances.argtypes = [vp, vp]
+    L.nxs_scene_load_file.argtypes = [vp, C.c_char_p, C.c_char_p]
     # Scene / PathTracer facade
     L.nxs_last_error.restype = C.c_char_p
     L.nxs_scene_create.argtypes = [u32, u32, C.POINTER(vp)]
@@ -273,6 +287,30 @@ def camera_init(position, forward, hfov_deg, width, height, focus_dist=5.0, defo
 
 
 # ---- device context -------------------------------------------------------------------------------
+
+def load_scene_file(path):
+    """nexus::OBJLoader::Parse through the C-ABI: (meshes [TRI_DT arrays], materials MAT_DT array, instances LOADED_INST_DT array)."""
+    L = lib()
+    h = C.c_void_p()
+    if L.nxh_load_scene_file(str(path).encode(), C.byref(h)) != 0:
+        raise NexusError("nxh_load_scene_file: " + L.nxs_last_error().decode())
+    try:
+        meshes = []
+        for m in range(L.nxh_loaded_mesh_count(h)):
+            t = np.zeros(L.nxh_loaded_mesh_triangle_count(h, m), dtype=pod.TRI_DT)
+            if L.nxh_loaded_mesh_triangles(h, m, _ptr(t)) != 0:
+                raise NexusError(L.nxs_last_error().decode())
+            meshes.append(t)
+        mats = np.zeros(L.nxh_loaded_material_count(h), dtype=pod.MAT_DT)
+        if L.nxh_loaded_materials(h, _ptr(mats)) != 0:
+            raise NexusError(L.nxs_last_error().decode())
+        insts = np.zeros(L.nxh_loaded_instance_count(h), dtype=pod.LOADED_INST_DT)
+        if L.nxh_loaded_instances(h, _ptr(insts)) != 0:
+            raise NexusError(L.nxs_last_error().decode())
+    finally:
+        L.nxh_loaded_scene_free(h)
+    return meshes, mats, insts
+
 
 class Context:
     """One ``nxhip_ctx`` (one GPU).  Thin 1:1 wrapper of the C-ABI; raises NexusError on any failure."""
@@ -552,6 +590,10 @@ class Scene:
         i = C.c_int32(-1)
         _scheck(self.L.nxs_scene_add_mesh(self.h, _ptr(t), len(t), material_id, C.byref(i)), "nxs_scene_add_mesh")
         return i.value
+
+    def load_file(self, path, file_name):
+        """Scene::CreateMeshInstanceFromFile: materials, meshes (one BVH8 each) and instances of a .glb / .obj"""
+        _scheck(self.L.nxs_scene_load_file(self.h, str(path).encode(), str(file_name).encode()), "nxs_scene_load_file")
 
     def create_instance(self, mesh_id, material_id, position=(0, 0, 0), rotation_deg=(0, 0, 0), scale=(1, 1, 1)):
         p, r, s = (np.asarray(x, np.float32) for x in (position, rotation_deg, scale))

@@ -1,8 +1,11 @@
 // nexus_scene_capi.cpp — flat C wrappers over nexus::Scene / nexus::PathTracer (see include/nexus_host.h).
 #include <cstring>
 #include <exception>
+#include <memory>
+#include <stdexcept>
 #include <string>
 
+#include "nexus/OBJLoader.h"
 #include "nexus/PathTracer.h"
 #include "nexus/Scene.h"
 #include "nexus_host.h"
@@ -12,6 +15,9 @@ using namespace nexus;
 struct nxs_scene {
     Scene scene;
     nxs_scene(uint32_t w, uint32_t h) : scene(w, h) {}
+};
+struct nxh_loaded_scene {
+    LoadedScene ls;
 };
 struct nxs_pathtracer {
     PathTracer pt;
@@ -88,6 +94,60 @@ int nxs_scene_create_instance(nxs_scene* s, uint32_t meshId, int32_t materialId,
         mi.AssignMaterial(materialId);
         mi.SetTransform(make_float3(pos), make_float3(rotDeg), make_float3(scale));
         if (instanceId) *instanceId = static_cast<int32_t>(s->scene.GetMeshInstances().size()) - 1;
+    });
+}
+
+int nxh_load_scene_file(const char* file, nxh_loaded_scene** out)
+{
+    return guarded([&] {
+        if (!file || !out) throw std::runtime_error("nxh_load_scene_file: null argument");
+        std::unique_ptr<nxh_loaded_scene> p(new nxh_loaded_scene);
+        p->ls = OBJLoader::Parse(file);
+        *out = p.release();
+    });
+}
+void nxh_loaded_scene_free(nxh_loaded_scene* s) { delete s; }
+uint32_t nxh_loaded_mesh_count(const nxh_loaded_scene* s) { return static_cast<uint32_t>(s->ls.meshes.size()); }
+uint32_t nxh_loaded_mesh_triangle_count(const nxh_loaded_scene* s, uint32_t mesh)
+{
+    return mesh < s->ls.meshes.size() ? static_cast<uint32_t>(s->ls.meshes[mesh].size()) : 0u;
+}
+int nxh_loaded_mesh_triangles(const nxh_loaded_scene* s, uint32_t mesh, nx_triangle* dst)
+{
+    return guarded([&] {
+        if (mesh >= s->ls.meshes.size() || !dst) throw std::runtime_error("nxh_loaded_mesh_triangles: bad arguments");
+        for (size_t i = 0; i < s->ls.meshes[mesh].size(); i++) dst[i] = Triangle::ToDevice(s->ls.meshes[mesh][i]);
+    });
+}
+uint32_t nxh_loaded_material_count(const nxh_loaded_scene* s) { return static_cast<uint32_t>(s->ls.materials.size()); }
+int nxh_loaded_materials(const nxh_loaded_scene* s, nx_material* dst)
+{
+    return guarded([&] {
+        if (!dst) throw std::runtime_error("nxh_loaded_materials: null destination");
+        for (size_t i = 0; i < s->ls.materials.size(); i++) dst[i] = static_cast<const nx_material&>(s->ls.materials[i]);
+    });
+}
+uint32_t nxh_loaded_instance_count(const nxh_loaded_scene* s) { return static_cast<uint32_t>(s->ls.instances.size()); }
+int nxh_loaded_instances(const nxh_loaded_scene* s, nx_loaded_instance* dst)
+{
+    return guarded([&] {
+        if (!dst) throw std::runtime_error("nxh_loaded_instances: null destination");
+        for (size_t i = 0; i < s->ls.instances.size(); i++) {
+            const LoadedInstance& in = s->ls.instances[i];
+            dst[i].mesh = in.mesh;
+            dst[i].material = in.material;
+            store(dst[i].position, in.position);
+            store(dst[i].rotation, in.rotation);
+            store(dst[i].scale, in.scale);
+        }
+    });
+}
+
+int nxs_scene_load_file(nxs_scene* s, const char* path, const char* fileName)
+{
+    return guarded([&] {
+        if (!path || !fileName) throw std::runtime_error("nxs_scene_load_file: null argument");
+        s->scene.CreateMeshInstanceFromFile(path, fileName);
     });
 }
 

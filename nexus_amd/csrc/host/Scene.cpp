@@ -3,6 +3,8 @@
 // emissive map or intensity * max(emissive) > 0; the TLAS is rebuilt whenever an instance changed.
 #include "nexus/Scene.h"
 
+#include "nexus/OBJLoader.h"
+
 namespace nexus {
 
 Scene::Scene(uint32_t width, uint32_t height)
@@ -65,6 +67,12 @@ MeshInstance& Scene::CreateMeshInstance(uint32_t meshId)
     UpdateInstanceLighting(instanceId);
     InvalidateMeshInstance(static_cast<uint32_t>(instanceId));
     return m_MeshInstances[instanceId];
+}
+
+void Scene::CreateMeshInstanceFromFile(const std::string& path, const std::string& fileName)
+{
+    OBJLoader::LoadOBJ(path, fileName, this, &m_AssetManager);
+    Invalidate();  // the TLAS is rebuilt by the next Update()
 }
 
 void Scene::AddHDRMap(const Texture& texture)

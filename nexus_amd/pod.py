@@ -88,6 +88,8 @@ SETTINGS_DT = np.dtype(
 
 RAY_DT = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3)])
 HIT_DT = np.dtype([("hitDistance", "<f4"), ("u", "<f4"), ("v", "<f4"), ("triIdx", "<u4"), ("instanceIdx", "<u4")])
+LOADED_INST_DT = np.dtype([("mesh", "<i4"), ("material", "<i4"), ("position", "<f4", 3), ("rotation", "<f4", 3), ("scale", "<f4", 3)])
+assert LOADED_INST_DT.itemsize == 44
 # BSDF test hooks (nx_bsdf_query 32 B, nx_bsdf_result 48 B)
 BSDF_QUERY_DT = np.dtype([("wi", "<f4", 3), ("rng", "<u4"), ("wo", "<f4", 3), ("pad_", "<u4")])
 BSDF_RESULT_DT = np.dtype([("wo", "<f4", 3), ("pdf", "<f4"), ("throughput", "<f4", 3), ("ok", "<u4"), ("rngOut", "<u4"), ("pad_", "<u4", 3)])

@@ -56,3 +56,42 @@ def test_facade_frame_equals_direct_capi_frame(gpu_ctx_factory):
     assert np.array_equal(got_rad.view(np.uint32), ctx.read_radiance().view(np.uint32))
     assert np.array_equal(got_px, ctx.read_rgba8())
     pt.close()
+
+
+def _cornell_from_file(width, height, path_length):
+    """The reference's own call: Scene::CreateMeshInstanceFromFile (C++ glb reader), materials as the file gives them."""
+    sc = capi.Scene(width, height)
+    sc.load_file(SH.GOLDEN + os.sep, "cornell_box.glb")
+    sc.set_camera((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, 5.0, 0.0)
+    sc.set_render_settings(O.make_settings(use_mis=True, path_length=path_length))
+    sc.update()
+    return sc
+
+
+def test_scene_from_file_bookkeeping():
+    sc = _cornell_from_file(32, 32, 4)
+    assert sc.instance_count() == 8 and sc.light_count() == 1
+    with pytest.raises(capi.NexusError):
+        capi.Scene(32, 32).load_file(SH.GOLDEN + os.sep, "no_such_file.glb")
+
+
+@pytest.mark.gpu
+def test_scene_loaded_from_file_renders_like_the_python_built_scene(gpu_ctx_factory):
+    W = H = 64
+    sc = _cornell_from_file(W, H, 4)
+    pt = capi.PathTracer(W, H)
+    pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    pt.update_device_scene(sc)
+    for _ in range(2):
+        pt.render(sc)
+    got = pt.read_radiance()
+    scene = SH.cornell_scene(W, H, path_length=4, force_diffuse=False)  # the file's materials are PLASTIC
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    ctx.reset_frame_number()
+    for _ in range(2):
+        ctx.render_frame()
+        ctx.accumulate()
+    assert np.array_equal(got.view(np.uint32), ctx.read_radiance().view(np.uint32))
+    pt.close()
