@@ -26,7 +26,7 @@ $(OBJDIR)/%.o: %.cpp $(HDRS)
 
 $(OUT): $(DEV_OBJS) $(HOST_OBJS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lpthread
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(LDEXTRA) -o $@ $^ -lpthread
 
 oracle:
 	$(MAKE) -C oracle liboracle.so
@@ -35,3 +35,13 @@ clean:
 	rm -rf build $(OUT)
 
 .PHONY: all oracle clean
+
+# Host-side AddressSanitizer + UBSan build (device code is compiled as usual; GPU ASan is not available on this pool).
+# Used by tools/run_sanitized_cpu_tests.sh; output goes to build/asan/ and never replaces the product library.
+ASAN_FLAGS := -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -g -fno-omit-frame-pointer
+asan:
+	$(MAKE) OUT=build/asan/libnexus_amd.so OBJDIR=build/asan/obj COMMON="$(COMMON) $(ASAN_FLAGS)" LDEXTRA="-fsanitize=address,undefined -shared-libsan"
+	$(MAKE) -C oracle clean
+	$(MAKE) -C oracle liboracle.so CC=/opt/rocm/lib/llvm/bin/clang SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libsan -g"
+
+.PHONY: asan
