@@ -137,6 +137,10 @@ def main():
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: libraries that print banners to stdout (RCCL does at init) are sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +149,10 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run with N ranks")
         args.gpus = world
 
-    if world > 1:
+    # NX_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, gather, compose) with whatever world size the launcher
+    # gave, even 1 — a rehearsal of the RCCL path on a single-GPU box
+    dist_mode = world > 1 or bool(os.environ.get("NX_BENCH_FORCE_DIST"))
+    if dist_mode:
         # torch ships its own libamdhip64 / libhsa-runtime64: import it BEFORE libnexus_amd.so is loaded so that the
         # library's libamdhip64.so.7 dependency binds to the copy torch already holds (two HIP runtimes in one process
         # cannot share the device, nor a stream handle).
@@ -165,7 +172,7 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    if dist_mode:
         import torch
         import torch.distributed as dist
 
@@ -189,7 +196,7 @@ def main():
         ctx = capi.Context(W, H, device=0)
     upload(ctx, sc)
 
-    if world > 1:
+    if dist_mode:
         pm = tile_pixel_map(W, H, rank, world)
         if args.pixel_order == "tiles":
             pm = multigpu.tiled_order(pm, W)
@@ -266,7 +273,7 @@ def main():
         step(n)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -296,7 +303,7 @@ def main():
     }
 
     # ---- roofline of the dominant kernel (closest-hit trace), rank 0 / single GPU only
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not dist_mode and not args.no_roofline:
         if ctx.frames_per_pass != S:
             ctx.set_frames_per_pass(S)
         passes = max(1, min(args.steps // S, 4))
@@ -353,7 +360,7 @@ def main():
             "live_rays_by_bounce": [int(x) for x in q["traceSize"][: args.path_length + 1]],
         }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not dist_mode and not args.no_cpu_baseline:
         # a 1-GPU box's CPU share is 16 hardware threads
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         cb, _ = cpu_baseline(sc, W, H, threads)
@@ -363,7 +370,7 @@ def main():
     if rank == 0 and args.png:
         from nexus_amd import imageio
 
-        if world > 1:
+        if dist_mode:
             img = full_rgba.cpu().numpy().view(np.uint32)
         elif args.pixel_order == "tiles":
             img = np.zeros(W * H, np.uint32)
@@ -373,8 +380,9 @@ def main():
         imageio.write_png(args.png, img, W, H)
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
