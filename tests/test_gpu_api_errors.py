@@ -1,0 +1,110 @@
+"""Error behaviour of the C-ABI on a GPU: misuse returns a status and a message (the reference's CheckCudaErrors prints,
+resets the device and exit(99)s, Utils/Utils.cpp:3-12), nothing is launched with bad indices, and the context stays usable."""
+import numpy as np
+import pytest
+
+from nexus_amd import capi, pod
+from nexus_amd.capi import NexusError
+from tests import oracle_lib as O
+from tests import scene_helpers as SH
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_before_a_scene_is_set(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(32, 32)
+    with pytest.raises(NexusError, match="TLAS"):
+        ctx.render_frame()
+    scene = SH.soup_scene(n=200, seed=2)
+    for nodes, tris, idx in scene.blas:
+        ctx.upload_blas(nodes, tris, idx)
+    ctx.set_tlas(scene.tlas_nodes, scene.tlas_idx, scene.instances)
+    with pytest.raises(NexusError, match="materials"):
+        ctx.render_frame()
+
+
+def test_malformed_bvh_uploads_are_rejected(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(32, 32)
+    scene = SH.soup_scene(n=300, seed=3)
+    nodes, tris, idx = scene.blas[0]
+    bad_idx = idx.copy()
+    bad_idx[5] = len(tris)
+    with pytest.raises(NexusError, match="triangle index"):
+        ctx.upload_blas(nodes, tris, bad_idx)
+    bad_nodes = nodes.copy()
+    bad_nodes["childBaseIdx"][0] = len(nodes) + 7
+    with pytest.raises(NexusError, match="child index"):
+        ctx.upload_blas(bad_nodes, tris, idx)
+    bad_nodes = nodes.copy()
+    bad_nodes["triangleBaseIdx"][:] = len(tris)
+    with pytest.raises(NexusError, match="leaf range"):
+        ctx.upload_blas(bad_nodes, tris, idx)
+    with pytest.raises(NexusError, match="empty"):
+        ctx.upload_blas(nodes[:0], tris, idx)
+    # instances that refer to a BLAS that was never uploaded
+    with pytest.raises(NexusError, match="BLAS id"):
+        ctx.set_tlas(scene.tlas_nodes, scene.tlas_idx, scene.instances)
+    ctx.upload_blas(nodes, tris, idx)
+    bad_inst_idx = scene.tlas_idx.copy()
+    bad_inst_idx[0] = 5
+    with pytest.raises(NexusError, match="instance index"):
+        ctx.set_tlas(scene.tlas_nodes, bad_inst_idx, scene.instances)
+    # and the good upload still works afterwards
+    ctx.set_tlas(scene.tlas_nodes, scene.tlas_idx, scene.instances)
+    rays = np.zeros(4, dtype=pod.RAY_DT)
+    rays["origin"] = (0, 0, -5)
+    rays["direction"] = (0, 0, 1)
+    assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
+
+
+def test_settings_modes_and_viewport_arguments(gpu_ctx_factory):
+    W, H = 32, 24
+    scene = SH.cornell_scene(W, H, path_length=2)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    for bad_len in (0, 99, 255):
+        st = O.make_settings(path_length=4)
+        st["pathLength"] = bad_len
+        with pytest.raises(NexusError, match="pathLength"):
+            ctx.set_render_settings(st)
+    with pytest.raises(NexusError, match="mode"):
+        ctx.set_modes(7, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    with pytest.raises(NexusError):
+        ctx.set_frames_per_pass(0)
+    with pytest.raises(NexusError):
+        ctx.set_frames_per_pass(100000)
+    with pytest.raises(NexusError, match="zero-sized"):
+        ctx.resize(0, 16)
+    with pytest.raises(NexusError, match="out of range"):
+        ctx.set_pixel_map(np.array([0, 1, W * H], dtype=np.uint32))
+    with pytest.raises(NexusError, match="outside"):
+        ctx.set_pixel_query(W, 0)
+    cam = capi.camera_init((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, W * 2, H, 5.0, 0.0)
+    with pytest.raises(NexusError, match="resolution"):
+        ctx.set_camera(cam)
+    with pytest.raises(NexusError):
+        ctx.bind_radiance(ctx.accumulation_device_ptr(), 3)  # smaller than the path count
+    with pytest.raises(NexusError):
+        ctx.tex2d_batch("diffuse", 0, np.zeros((1, 2), np.float32))  # no such texture
+    # none of the failed calls disturbed the context: it still renders the oracle's frame
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    ctx.accumulate()
+    w = O.Wavefront(scene.oracle(), W * H, None, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_REFERENCE)
+    w.render(1, threads=4)
+    assert SH.image_agreement(ctx.read_radiance(), w.radiance(), 1e-3) >= 0.995
+
+
+def test_contexts_are_independent_and_closing_is_idempotent(gpu_ctx_factory):
+    a = gpu_ctx_factory(16, 16)
+    b = gpu_ctx_factory(16, 16)
+    scene = SH.soup_scene(n=100, seed=4)
+    scene.upload(a)
+    with pytest.raises(NexusError):
+        b.render_frame()  # b has no scene although a does
+    a.render_frame()
+    a.close()
+    a.close()
+    with pytest.raises(NexusError):
+        b.render_frame()
