@@ -23,8 +23,14 @@
 namespace nxd {
 
 constexpr int kWideBlock = 256;     // generate / accumulate
-constexpr int kLogicBlock = 1024;   // one slot atomic per 1024 items
-constexpr int kShadeBlock = 512;
+#ifndef NX_SHADE_BLOCK
+#define NX_SHADE_BLOCK 512
+#endif
+#ifndef NX_LOGIC_BLOCK
+#define NX_LOGIC_BLOCK 1024
+#endif
+constexpr int kLogicBlock = NX_LOGIC_BLOCK;   // one slot atomic per block-sized tile of items
+constexpr int kShadeBlock = NX_SHADE_BLOCK;
 constexpr int kOrderedBlock = 1024;  // single-workgroup ordered mode
 
 // ------------------------------------------------------------------------------------------------------

@@ -50,8 +50,14 @@ bool DevBuf::alloc(size_t n)
 
 constexpr int kTraceBlockThreads = 256;
 constexpr int kWideBlockThreads = 256;
-constexpr int kLogicBlockThreads = 1024;
-constexpr int kShadeBlockThreads = 512;
+#ifndef NX_SHADE_BLOCK
+#define NX_SHADE_BLOCK 512
+#endif
+#ifndef NX_LOGIC_BLOCK
+#define NX_LOGIC_BLOCK 1024
+#endif
+constexpr int kLogicBlockThreads = NX_LOGIC_BLOCK;
+constexpr int kShadeBlockThreads = NX_SHADE_BLOCK;
 constexpr int kOrderedBlockThreads = 1024;
 constexpr int kHookBounceSlot = NX_PATH_MAX_LENGTH - 1;  // queue-size slot used by the batch test hooks
 
