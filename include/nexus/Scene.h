@@ -35,6 +35,9 @@ public:
 
     void Update();     // apply instance transforms / materials, rebuild + convert the TLAS
     void BuildTLAS();
+    // Extension: when only transforms / materials of existing instances change, refit the TLAS (O(n)) instead of
+    // rebuilding it (the reference always rebuilds, Scene.cpp:29-55).  Off by default.
+    void SetTlasRefit(bool enable) { m_TlasRefit = enable; }
     MeshInstance& CreateMeshInstance(uint32_t meshId);
     // Scene.cpp:83-91: load a .glb / .obj (OBJLoader::LoadOBJ), one BVH per mesh, one instance per (node, primitive)
     void CreateMeshInstanceFromFile(const std::string& path, const std::string& fileName);
@@ -63,6 +66,8 @@ private:
     AssetManager m_AssetManager;
     RenderSettings m_RenderSettings;
     bool m_Invalid = true;
+    bool m_TlasRefit = false;
+    size_t m_TlasBuiltFor = 0;  // instance count of the last full TLAS build
 };
 
 }  // namespace nexus

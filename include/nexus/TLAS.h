@@ -28,6 +28,9 @@ struct TLAS {
     // Same clustering from device-layout instances (only their world bounds are used).
     void BuildFromBounds(const nx_bvh_instance* instances, uint32_t count);
     void Convert();
+    // Same topology, bounds from the instances' current boxes (after SetBVHInstances): O(n) instead of the O(n^2) Build().
+    // Returns false (nothing done) if the instance count differs from the one the tree was built for.
+    bool Refit();
     void SetBVHInstances(const std::vector<BVHInstance>& instances) { bvhInstances = instances; }
     std::vector<BVHInstance>& GetInstances() { return bvhInstances; }
     int FindBestMatch(int N, int A) const;

@@ -27,11 +27,11 @@ HIP_SYMBOLS = [
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
 ]
 HOST_SYMBOLS = [
-    "nxh_bvh8_build", "nxh_tlas_build", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
+    "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
     "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
     "nxh_instance_init", "nxh_camera_init",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
-    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file",
+    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
     "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes",
@@ -129,6 +129,7 @@ def lib():
     # host builders
     L.nxh_bvh8_build.argtypes = [vp, u32, u32, C.POINTER(vp)]
     L.nxh_tlas_build.argtypes = [vp, u32, C.POINTER(vp)]
+    L.nxh_tlas_refit.argtypes = [vp, u32, vp, vp, u32]
     L.nxh_bvh8_node_count.argtypes = [vp]
     L.nxh_bvh8_node_count.restype = u32
     L.nxh_bvh8_prim_count.argtypes = [vp]
@@ -158,6 +159,8 @@ def lib():
     L.nxh_loaded_materials.argtypes = [vp, vp]
     L.nxh_loaded_instances.argtypes = [vp, vp]
     L.nxs_scene_load_file.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.nxs_scene_set_instance_transform.argtypes = [vp, u32, vp, vp, vp]
+    L.nxs_scene_set_tlas_refit.argtypes = [vp, C.c_int]
     # Scene / PathTracer facade
     L.nxs_last_error.restype = C.c_char_p
     L.nxs_scene_create.argtypes = [u32, u32, C.POINTER(vp)]
@@ -287,6 +290,16 @@ def camera_init(position, forward, hfov_deg, width, height, focus_dist=5.0, defo
 
 
 # ---- device context -------------------------------------------------------------------------------
+
+def tlas_refit(nodes, inst_idx, instances):
+    """In-place-style refit of a TLAS (returns the new node array): same topology, bounds from the instances' current boxes."""
+    nodes = np.ascontiguousarray(nodes, dtype=pod.NODE_DT).copy()
+    inst_idx = np.ascontiguousarray(inst_idx, dtype=np.uint32)
+    instances = np.ascontiguousarray(instances, dtype=pod.INST_DT)
+    if lib().nxh_tlas_refit(_ptr(nodes), len(nodes), _ptr(inst_idx), _ptr(instances), len(instances)) != 0:
+        raise NexusError("nxh_tlas_refit: malformed TLAS")
+    return nodes
+
 
 def load_scene_file(path):
     """nexus::OBJLoader::Parse through the C-ABI: (meshes [TRI_DT arrays], materials MAT_DT array, instances LOADED_INST_DT array)."""
@@ -590,6 +603,13 @@ class Scene:
         i = C.c_int32(-1)
         _scheck(self.L.nxs_scene_add_mesh(self.h, _ptr(t), len(t), material_id, C.byref(i)), "nxs_scene_add_mesh")
         return i.value
+
+    def set_instance_transform(self, instance_id, position, rotation_deg, scale):
+        p, r, sc = (np.asarray(x, np.float32) for x in (position, rotation_deg, scale))
+        _scheck(self.L.nxs_scene_set_instance_transform(self.h, instance_id, _ptr(p), _ptr(r), _ptr(sc)), "nxs_scene_set_instance_transform")
+
+    def set_tlas_refit(self, enable=True):
+        _scheck(self.L.nxs_scene_set_tlas_refit(self.h, 1 if enable else 0), "nxs_scene_set_tlas_refit")
 
     def load_file(self, path, file_name):
         """Scene::CreateMeshInstanceFromFile: materials, meshes (one BVH8 each) and instances of a .glb / .obj"""

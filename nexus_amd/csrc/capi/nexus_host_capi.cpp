@@ -1,6 +1,8 @@
 // nexus_host_capi.cpp — flat C wrappers over the C++ host classes (see include/nexus_host.h).
 #include "nexus_host.h"
 
+#include "Collapse.h"
+
 #include <cstring>
 #include <new>
 #include <vector>
@@ -62,6 +64,35 @@ int nxh_tlas_build(const nx_bvh_instance* instances, uint32_t instanceCount, nxh
         nxh_bvh8* h = new nxh_bvh8();
         h->bvh = std::move(tlas.bvh8);
         *out = h;
+        return 0;
+    } catch (const std::bad_alloc&) {
+        return 2;
+    }
+}
+
+int nxh_tlas_refit(nx_bvh8_node* nodes, uint32_t nodeCount, const uint32_t* instanceIdx, const nx_bvh_instance* instances, uint32_t instanceCount)
+{
+    if (!nodes || nodeCount == 0 || !instanceIdx || !instances || instanceCount == 0) return 1;
+    try {
+        // the same structural checks as nxhip_set_tlas: a refit must not read outside the arrays it was given
+        for (uint32_t i = 0; i < instanceCount; i++)
+            if (instanceIdx[i] >= instanceCount) return 1;
+        for (uint32_t i = 0; i < nodeCount; i++) {
+            const nx_bvh8_node& n = nodes[i];
+            int inner = 0, prims = 0;
+            for (int s = 0; s < 8; s++) {
+                if (n.imask & (1u << s)) inner++;
+                else if (n.meta[s]) prims = std::max(prims, (n.meta[s] & 0x1f) + __builtin_popcount(n.meta[s] >> 5));
+            }
+            if (inner && (n.childBaseIdx <= i || static_cast<uint64_t>(n.childBaseIdx) + inner > nodeCount)) return 1;
+            if (prims && static_cast<uint64_t>(n.triangleBaseIdx) + prims > instanceCount) return 1;
+        }
+        std::vector<AABB> bounds;
+        bounds.reserve(instanceCount);
+        for (uint32_t i = 0; i < instanceCount; i++) bounds.emplace_back(make_float3(instances[i].boundsMin), make_float3(instances[i].boundsMax));
+        std::vector<BVH8Node> v(nodes, nodes + nodeCount);
+        collapse::Refit(v, instanceIdx, bounds.data());
+        std::memcpy(nodes, v.data(), sizeof(nx_bvh8_node) * nodeCount);
         return 0;
     } catch (const std::bad_alloc&) {
         return 2;

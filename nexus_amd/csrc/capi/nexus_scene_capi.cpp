@@ -143,6 +143,20 @@ int nxh_loaded_instances(const nxh_loaded_scene* s, nx_loaded_instance* dst)
     });
 }
 
+int nxs_scene_set_instance_transform(nxs_scene* s, uint32_t instanceId, const float pos[3], const float rotDeg[3], const float scale[3])
+{
+    return guarded([&] {
+        if (instanceId >= s->scene.GetMeshInstances().size()) throw std::runtime_error("nxs_scene_set_instance_transform: no such instance");
+        s->scene.GetMeshInstances()[instanceId].SetTransform(make_float3(pos), make_float3(rotDeg), make_float3(scale));
+        s->scene.InvalidateMeshInstance(instanceId);  // what the viewer's transform panel does (SceneHierarchyPanel.cpp)
+    });
+}
+
+int nxs_scene_set_tlas_refit(nxs_scene* s, int enable)
+{
+    return guarded([&] { s->scene.SetTlasRefit(enable != 0); });
+}
+
 int nxs_scene_load_file(nxs_scene* s, const char* path, const char* fileName)
 {
     return guarded([&] {

@@ -221,6 +221,59 @@ struct Collapser {
 
 }  // namespace
 
+AABB Refit(std::vector<BVH8Node>& nodes, const uint32_t* primIdx, const AABB* primBounds)
+{
+    const size_t n = nodes.size();
+    std::vector<AABB> nodeBox(n);
+    // children are emitted after their parent (childBaseIdx > own index), so a descending sweep sees children first
+    for (size_t k = n; k-- > 0;) {
+        BVH8Node& node = nodes[k];
+        AABB childBox[8];
+        bool used[8] = {false, false, false, false, false, false, false, false};
+        AABB nb;
+        for (int s = 0; s < 8; s++) {
+            AABB cb;
+            if (node.imask & (1u << s)) {
+                const uint32_t rel = static_cast<uint32_t>(__builtin_popcount(node.imask & ((1u << s) - 1u)));
+                cb = nodeBox[node.childBaseIdx + rel];
+            } else if (node.meta[s]) {
+                const uint32_t first = node.triangleBaseIdx + (node.meta[s] & 0x1fu);
+                const int count = __builtin_popcount(node.meta[s] >> 5);
+                for (int j = 0; j < count; j++) cb.Grow(primBounds[primIdx[first + static_cast<uint32_t>(j)]]);
+            } else {
+                continue;
+            }
+            used[s] = true;
+            childBox[s] = cb;
+            nb.Grow(cb);
+        }
+        nodeBox[k] = nb;
+        const float denom = 1.0f / static_cast<float>((1 << N_Q) - 1);
+        const float ex = std::ceil(std::log2((nb.bMax.x - nb.bMin.x) * denom));
+        const float ey = std::ceil(std::log2((nb.bMax.y - nb.bMin.y) * denom));
+        const float ez = std::ceil(std::log2((nb.bMax.z - nb.bMin.z) * denom));
+        const float pw[3] = {std::exp2(ex), std::exp2(ey), std::exp2(ez)};
+        for (int a = 0; a < 3; a++) {
+            uint32_t bits;
+            std::memcpy(&bits, &pw[a], 4);
+            node.e[a] = static_cast<uint8_t>(bits >> 23);
+        }
+        store(node.p, nb.bMin);
+        const float3 invScale = make_float3(1.0f / std::pow(2.0f, ex), 1.0f / std::pow(2.0f, ey), 1.0f / std::pow(2.0f, ez));
+        for (int s = 0; s < 8; s++) {
+            if (!used[s]) continue;
+            const AABB& cb = childBox[s];
+            node.qlox[s] = Quantize(std::floor((cb.bMin.x - node.p[0]) * invScale.x));
+            node.qloy[s] = Quantize(std::floor((cb.bMin.y - node.p[1]) * invScale.y));
+            node.qloz[s] = Quantize(std::floor((cb.bMin.z - node.p[2]) * invScale.z));
+            node.qhix[s] = Quantize(std::ceil((cb.bMax.x - node.p[0]) * invScale.x));
+            node.qhiy[s] = Quantize(std::ceil((cb.bMax.y - node.p[1]) * invScale.y));
+            node.qhiz[s] = Quantize(std::ceil((cb.bMax.z - node.p[2]) * invScale.z));
+        }
+    }
+    return n ? nodeBox[0] : AABB();
+}
+
 void Collapse(const Tree& t, const std::vector<Eval>& evals, BVH8& out)
 {
     out.nodes.clear();

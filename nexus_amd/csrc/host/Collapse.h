@@ -38,5 +38,10 @@ void ComputeCosts(const Tree& t, std::vector<Eval>& evals);
 // out.triangleIdx must already be sized to the primitive count.
 void Collapse(const Tree& t, const std::vector<Eval>& evals, BVH8& out);
 
+// Refit: same topology, new leaf bounds.  primBounds[id] is the (world) box of primitive id (ids as stored in primIdx).
+// Every node's frame (p, e) and the quantised boxes of its children are recomputed bottom-up with the formulas of
+// Collapse(); imask, meta, child and primitive indices are untouched.  Returns the new root box.
+AABB Refit(std::vector<BVH8Node>& nodes, const uint32_t* primIdx, const AABB* primBounds);
+
 }  // namespace collapse
 }  // namespace nexus

@@ -21,6 +21,7 @@ void Scene::Reset()
     m_Lights.clear();
     m_AssetManager.Reset();
     m_Camera->Invalidate();
+    m_TlasBuiltFor = 0;
     tlasDirty = lightsDirty = true;
 }
 
@@ -41,8 +42,11 @@ void Scene::Update()
         }
         if (!m_Tlas) m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
         m_Tlas->SetBVHInstances(m_BVHInstances);
-        m_Tlas->Build();
-        m_Tlas->Convert();
+        if (!(m_TlasRefit && m_TlasBuiltFor == m_BVHInstances.size() && m_Tlas->Refit())) {
+            m_Tlas->Build();
+            m_Tlas->Convert();
+            m_TlasBuiltFor = m_BVHInstances.size();
+        }
         tlasDirty = true;
         m_InvalidMeshInstances.clear();
     }
@@ -54,6 +58,7 @@ void Scene::BuildTLAS()
     m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
     m_Tlas->Build();
     m_Tlas->Convert();
+    m_TlasBuiltFor = m_BVHInstances.size();
     tlasDirty = true;
 }
 

@@ -81,6 +81,16 @@ int TLAS::FindBestMatch(int N, int A) const
     return bestB;
 }
 
+bool TLAS::Refit()
+{
+    if (bvh8.nodes.empty() || bvh8.triangleIdx.size() != bvhInstances.size()) return false;
+    std::vector<AABB> bounds;
+    bounds.reserve(bvhInstances.size());
+    for (const BVHInstance& inst : bvhInstances) bounds.push_back(inst.GetBounds());
+    collapse::Refit(bvh8.nodes, bvh8.triangleIdx.data(), bounds.data());
+    return true;
+}
+
 void TLAS::Convert()
 {
     TLASBuilder builder(*this);
