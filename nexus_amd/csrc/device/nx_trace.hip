@@ -34,8 +34,11 @@
 namespace nxd {
 
 constexpr int kTraceBlock = 256;  // 4 waves
-constexpr int kLdsDepth = 8;      // stack entries per lane held in LDS (16 KiB per workgroup)
-constexpr int kSpillDepth = 24;   // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
+#ifndef NX_LDS_DEPTH
+#define NX_LDS_DEPTH 8
+#endif
+constexpr int kLdsDepth = NX_LDS_DEPTH;        // stack entries per lane held in LDS (2 KiB each per workgroup)
+constexpr int kSpillDepth = 32 - kLdsDepth;  // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
 #ifdef NX_COOP_FETCH
 constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
 #endif
