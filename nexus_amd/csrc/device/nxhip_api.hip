@@ -148,6 +148,7 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
 {
     const size_t n = (size_t)std::max<uint32_t>(localCount, 1u) * c->framesPerPass;
     const size_t full = std::max<size_t>((size_t)c->width * c->height, localCount);
+    if (n > 0x7fffffffull) return fail_invalid("more than 2^31 paths (pixels x frames per pass): lower nxhip_set_frames_per_pass first");
     const int rc = alloc_queues(c, n);
     if (rc != NXHIP_OK) return rc;
     NX_ALLOC(c->accumulation, full * 16);
@@ -200,6 +201,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
     if (!out) return fail_invalid("nxhip_create: out is null");
     *out = nullptr;
     if (width == 0 || height == 0) return fail_invalid("nxhip_create: zero-sized viewport");
+    if ((uint64_t)width * height > 0x7fffffffull) return fail_invalid("nxhip_create: more than 2^31 pixels");
     if (nxhip_device_count() <= device || device < 0) {
         set_error("nxhip_create: no such HIP device");
         return NXHIP_ERR_NO_DEVICE;
@@ -311,6 +313,8 @@ int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
 {
     NX_CHECK_CTX(c);
     if (width == 0 || height == 0) return fail_invalid("nxhip_resize: zero-sized viewport");
+    if ((uint64_t)width * height * c->framesPerPass > 0x7fffffffull)
+        return fail_invalid("nxhip_resize: more than 2^31 paths (pixels x frames per pass): lower nxhip_set_frames_per_pass first");
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
     c->width = width;
@@ -383,7 +387,7 @@ static int refresh_inst_trav(nxhip_ctx* c)
 
 int nxhip_upload_blas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, const nx_triangle* tris, uint32_t triCount,
                       const uint32_t* triIdx, int32_t* blasId)
-{
+try {
     NX_CHECK_CTX(c);
     if (!nodes || !tris || !triIdx || nodeCount == 0 || triCount == 0) return fail_invalid("nxhip_upload_blas: empty input");
     NX_HIP(hipSetDevice(c->device));
@@ -430,10 +434,13 @@ int nxhip_upload_blas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCoun
     c->blas.push_back(std::move(b));
     if (blasId) *blasId = (int32_t)c->blas.size() - 1;
     return refresh_blas_table(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_upload_blas: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_clear_blas(nxhip_ctx* c)
-{
+try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
@@ -443,11 +450,14 @@ int nxhip_clear_blas(nxhip_ctx* c)
     c->h.tlasNodes = nullptr;
     c->h.instanceCount = 0;
     return refresh_blas_table(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_clear_blas: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, const uint32_t* instanceIdx, const nx_bvh_instance* instances,
                    uint32_t instanceCount)
-{
+try {
     NX_CHECK_CTX(c);
     if (!nodes || !instanceIdx || !instances || nodeCount == 0 || instanceCount == 0) return fail_invalid("nxhip_set_tlas: empty input");
     NX_HIP(hipSetDevice(c->device));
@@ -481,10 +491,13 @@ int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, 
     c->h.instanceCount = instanceCount;
     c->stateDirty = true;
     return refresh_inst_trav(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_set_tlas: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_set_materials(nxhip_ctx* c, const nx_material* materials, uint32_t count)
-{
+try {
     NX_CHECK_CTX(c);
     if (!materials || count == 0) return fail_invalid("nxhip_set_materials: empty input");
     NX_HIP(hipSetDevice(c->device));
@@ -495,10 +508,13 @@ int nxhip_set_materials(nxhip_ctx* c, const nx_material* materials, uint32_t cou
     c->h.materials = c->materials.as<nx_material>();
     c->stateDirty = true;
     return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_set_materials: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_set_lights(nxhip_ctx* c, const nx_light* lights, uint32_t count)
-{
+try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
@@ -509,6 +525,9 @@ int nxhip_set_lights(nxhip_ctx* c, const nx_light* lights, uint32_t count)
     c->h.lightCount = count;
     c->stateDirty = true;
     return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_set_lights: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 static int refresh_texture_tables(nxhip_ctx* c)
@@ -533,7 +552,7 @@ static int refresh_texture_tables(nxhip_ctx* c)
 }
 
 int nxhip_upload_texture(nxhip_ctx* c, int kind, const uint8_t* rgba8, uint32_t width, uint32_t height, int32_t* texId)
-{
+try {
     NX_CHECK_CTX(c);
     if (!rgba8 || width == 0 || height == 0 || kind < 0 || kind > 2) return fail_invalid("nxhip_upload_texture: bad arguments");
     NX_HIP(hipSetDevice(c->device));
@@ -548,10 +567,13 @@ int nxhip_upload_texture(nxhip_ctx* c, int kind, const uint8_t* rgba8, uint32_t 
     else { NX_HIP(hipStreamSynchronize(c->stream)); c->hdrMap = std::move(t); }
     if (texId) *texId = id;
     return refresh_texture_tables(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_upload_texture: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_clear_textures(nxhip_ctx* c)
-{
+try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
@@ -559,6 +581,9 @@ int nxhip_clear_textures(nxhip_ctx* c)
     c->emissiveMaps.clear();
     c->hdrMap = TextureHost();
     return refresh_texture_tables(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_clear_textures: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_set_camera(nxhip_ctx* c, const nx_camera* camera)
@@ -796,7 +821,7 @@ static int build_graph(nxhip_ctx* c)
 extern "C" {
 
 int nxhip_render_frame(nxhip_ctx* c)
-{
+try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
     int rc = check_scene_ready(c);
@@ -832,6 +857,9 @@ int nxhip_render_frame(nxhip_ctx* c)
     }
     c->frameNumber += c->framesPerPass;
     return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_render_frame: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t slices, uint32_t sliceStride, uint32_t firstFrame,
@@ -969,7 +997,7 @@ int nxhip_render(nxhip_ctx* c, uint32_t frames)
 }
 
 static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, float* dst)
-{
+try {
     if (!dst) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
@@ -981,6 +1009,9 @@ static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, 
         dst[3 * (size_t)i + 2] = tmp[i].z;
     }
     return NXHIP_OK;
+} catch (const std::exception& e) {
+    set_error(std::string("read-back: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_read_radiance(nxhip_ctx* c, float* dst)
@@ -1066,7 +1097,7 @@ static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
 }
 
 int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* hits)
-{
+try {
     NX_CHECK_CTX(c);
     if (count == 0) return NXHIP_OK;
     if (!rays || !hits) return fail_invalid("nxhip_trace_batch: null buffer");
@@ -1103,10 +1134,13 @@ int nxhip_trace_batch(nxhip_ctx* c, const nx_ray* rays, uint32_t count, nx_hit* 
         }
     }
     return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_trace_batch: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_trace_shadow_batch(nxhip_ctx* c, const nx_ray* rays, const float* tmax, uint32_t count, uint8_t* occluded)
-{
+try {
     NX_CHECK_CTX(c);
     if (count == 0) return NXHIP_OK;
     if (!rays || !tmax || !occluded) return fail_invalid("nxhip_trace_shadow_batch: null buffer");
@@ -1138,6 +1172,9 @@ int nxhip_trace_shadow_batch(nxhip_ctx* c, const nx_ray* rays, const float* tmax
         for (uint32_t i = 0; i < n; i++) occluded[first + i] = res[i].x == 1.0f ? 0 : 1;
     }
     return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_trace_shadow_batch: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_enable_trace_stats(nxhip_ctx* c, int enable)

@@ -75,6 +75,9 @@ def test_settings_modes_and_viewport_arguments(gpu_ctx_factory):
         ctx.set_frames_per_pass(100000)
     with pytest.raises(NexusError, match="zero-sized"):
         ctx.resize(0, 16)
+    with pytest.raises(NexusError, match="2\\^31"):
+        ctx.resize(65536, 65536)
+    assert (ctx.width, ctx.height) == (W, H)
     with pytest.raises(NexusError, match="out of range"):
         ctx.set_pixel_map(np.array([0, 1, W * H], dtype=np.uint32))
     with pytest.raises(NexusError, match="outside"):
