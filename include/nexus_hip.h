@@ -102,6 +102,10 @@ int nxhip_render(nxhip_ctx *ctx, uint32_t frames);
 int nxhip_read_radiance(nxhip_ctx *ctx, float *dst);
 int nxhip_read_accumulation(nxhip_ctx *ctx, float *dst);
 int nxhip_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);
+/* Resume: load a previously read accumulation (localCount x 3 floats) and continue as if `frameNumber` frames had been
+ * rendered; the next frame is frameNumber + 1 and the running mean continues bit for bit.  (The reference keeps the
+ * accumulation on the device only and restarts on every change, PathTracer.cpp:243-246.) */
+int nxhip_write_accumulation(nxhip_ctx *ctx, const float *src, uint32_t frameNumber);
 /* Device pointers for zero-copy consumers on the same GPU (e.g. an RCCL gather of radiance tiles):
  * float4 per local pixel (xyz = radiance, w unused).  Valid until the next resize / set_pixel_map. */
 void *nxhip_radiance_device_ptr(nxhip_ctx *ctx);

@@ -21,7 +21,7 @@ HIP_SYMBOLS = [
     "nxhip_upload_texture", "nxhip_clear_textures", "nxhip_set_camera", "nxhip_set_render_settings", "nxhip_set_modes",
     "nxhip_set_pixel_map", "nxhip_set_frames_per_pass", "nxhip_reset_frame_number", "nxhip_set_frame_number", "nxhip_frame_number",
     "nxhip_render_frame", "nxhip_accumulate", "nxhip_render", "nxhip_read_radiance", "nxhip_read_accumulation",
-    "nxhip_read_rgba8", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
+    "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
@@ -104,6 +104,7 @@ def lib():
     L.nxhip_read_radiance.argtypes = [vp, vp]
     L.nxhip_read_accumulation.argtypes = [vp, vp]
     L.nxhip_read_rgba8.argtypes = [vp, vp]
+    L.nxhip_write_accumulation.argtypes = [vp, vp, u32]
     L.nxhip_radiance_device_ptr.argtypes = [vp]
     L.nxhip_radiance_device_ptr.restype = vp
     L.nxhip_accumulation_device_ptr.argtypes = [vp]
@@ -443,6 +444,11 @@ class Context:
     def set_frames_per_pass(self, frames):
         check(self.L.nxhip_set_frames_per_pass(self.h, frames), "nxhip_set_frames_per_pass")
         self.frames_per_pass = int(frames)
+
+    def write_accumulation(self, accumulation, frame_number):
+        a = np.ascontiguousarray(accumulation, dtype=np.float32).reshape(-1, 3)
+        assert len(a) == self.local_count
+        check(self.L.nxhip_write_accumulation(self.h, _ptr(a), int(frame_number)), "nxhip_write_accumulation")
 
     def bind_radiance(self, dev_ptr, capacity):
         check(self.L.nxhip_bind_radiance(self.h, C.c_void_p(dev_ptr) if dev_ptr else None, capacity), "nxhip_bind_radiance")

@@ -1026,6 +1026,21 @@ int nxhip_read_accumulation(nxhip_ctx* c, float* dst)
     return read_float4_as_float3(c, c->accumulation.p, c->localCount, dst);
 }
 
+int nxhip_write_accumulation(nxhip_ctx* c, const float* src, uint32_t frameNumber)
+try {
+    NX_CHECK_CTX(c);
+    if (!src) return fail_invalid("nxhip_write_accumulation: null source");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float4> tmp(c->localCount);
+    for (uint32_t i = 0; i < c->localCount; i++) tmp[i] = make_float4(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], 0.0f);
+    NX_HIP(hipMemcpy(c->accumulation.p, tmp.data(), (size_t)c->localCount * 16, hipMemcpyHostToDevice));
+    return set_frame_number_device(c, frameNumber);
+} catch (const std::exception& e) {
+    set_error(std::string("nxhip_write_accumulation: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
 int nxhip_read_rgba8(nxhip_ctx* c, uint32_t* dst)
 {
     NX_CHECK_CTX(c);

@@ -323,3 +323,41 @@ def test_cross_table_indices_are_validated_before_launch(gpu_ctx_factory):
     _, want = _render_oracle(scene, W * H, 1, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
     assert np.isfinite(got).all() and SH.image_agreement(got, want[-1], PIXEL_TOL) >= 0.99
     assert ctx.read_queue_sizes()["traceShadowSize"][1] == 0
+
+
+def test_accumulation_checkpoint_resumes_bit_for_bit(gpu_ctx_factory, tmp_path):
+    from nexus_amd import imageio
+
+    W, H = 48, 32
+    scene = SH.material_zoo_scene(W, H, path_length=3)
+    a = gpu_ctx_factory(W, H)
+    scene.upload(a)
+    a.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    for _ in range(6):
+        a.render_frame()
+        a.accumulate()
+    want_acc, want_px = a.read_accumulation(), a.read_rgba8()
+
+    b = gpu_ctx_factory(W, H)
+    scene.upload(b)
+    b.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    for _ in range(4):
+        b.render_frame()
+        b.accumulate()
+    ckpt = tmp_path / "acc.pfm"
+    imageio.write_pfm(str(ckpt), b.read_accumulation(), W, H)
+    frame = b.frame_number()
+    b.close()
+
+    c = gpu_ctx_factory(W, H)
+    scene.upload(c)
+    c.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    acc, w, h = imageio.read_pfm(str(ckpt))
+    assert (w, h) == (W, H)
+    c.write_accumulation(acc, frame)
+    assert c.frame_number() == 4
+    for _ in range(2):
+        c.render_frame()
+        c.accumulate()
+    assert np.array_equal(c.read_accumulation().view(np.uint32), want_acc.view(np.uint32))
+    assert np.array_equal(c.read_rgba8(), want_px)
