@@ -45,3 +45,10 @@ asan:
 	$(MAKE) -C oracle liboracle.so CC=/opt/rocm/lib/llvm/bin/clang SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libsan -g"
 
 .PHONY: asan
+
+# The reference's render loop through the kept C++ API, headless (examples/nexus_render.cpp)
+example: $(OUT)
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Iinclude examples/nexus_render.cpp -o build/nexus_render -Lnexus_amd/lib -lnexus_amd -Wl,-rpath,'$$ORIGIN/../nexus_amd/lib'
+
+.PHONY: example

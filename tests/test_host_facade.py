@@ -121,3 +121,40 @@ def test_moving_instances_with_tlas_refit_renders_like_a_rebuild():
         pt.close()
     assert np.isfinite(imgs[0]).all() and imgs[0].max() > 0
     assert SH.image_agreement(imgs[1], imgs[0], 1e-6) >= 0.999
+
+
+@pytest.mark.gpu
+def test_cpp_example_program_renders_the_same_image(tmp_path):
+    """examples/nexus_render.cpp (the reference's render loop through the kept C++ API, no Python in the process) against
+    the same scene driven through the ctypes facade."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "nexus_render")
+    cmd = ["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "nexus_render.cpp"), "-o", exe,
+           "-L" + os.path.join(root, "nexus_amd", "lib"), "-lnexus_amd", "-Wl,-rpath," + os.path.join(root, "nexus_amd", "lib")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    W = H = 64
+    out = str(tmp_path / "cornell.ppm")
+    r = subprocess.run([exe, SH.GOLDEN + os.sep, "cornell_box.glb", out, str(W), str(H), "3", "4"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, NEXUS_DETERMINISTIC="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "8 instances, 1 lights" in r.stdout
+    data = open(out, "rb").read()
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    assert data.startswith(header) and len(data) == len(header) + W * H * 3
+    got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)[::-1]  # back to bottom row first
+
+    sc = _cornell_from_file(W, H, 4)
+    pt = capi.PathTracer(W, H)
+    pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    pt.update_device_scene(sc)
+    for _ in range(3):
+        pt.render(sc)
+    want = pt.read_pixels().reshape(H, W).view(np.uint8).reshape(H, W, 4)[..., :3]
+    pt.close()
+    assert np.array_equal(got, want)
+    # bad input: a message and a non-zero status, no crash
+    r = subprocess.run([exe, SH.GOLDEN + os.sep, "missing.glb", out], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open" in r.stderr
