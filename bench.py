@@ -280,7 +280,7 @@ def main():
 
     value = W * H * args.steps / elapsed / 1e6
     out = {
-        "metric": "Msamples/sec (rays traced/sec) at 1080p, 8-bounce, 1M-tri BVH8",
+        "metric": "Msamples/sec (rays traced/sec) at 1080p, 8-bounce, 1M-tri BVH8; 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
         "value": round(value, 3),
         "unit": "Msamples/s",
         "n_gpus": world,
@@ -343,6 +343,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "trace_kernel<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            # the rocprof-measured memory-side rate of the same kernel against the chip's peak (north_star's second figure)
+            "traffic_GBs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+            "traffic_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
             "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
