@@ -113,9 +113,14 @@ def cpu_baseline(sc, width, height, threads):
         w.render(f, threads=threads)
         w.accumulate(f)
     dt = time.time() - t0
+    # one more frame on a single thread: the 1-core figure SURVEY.md section 8d asks for beside the all-cores one
+    t0 = time.time()
+    w.render(frames + 1, threads=1)
+    dt1 = time.time() - t0
     return dict(value=width * height * frames / dt / 1e6, unit="Msamples/s", cores=threads, kind="port",
                 sample="%d full frames (%dx%d, same scene/camera/settings, frames 1..%d); both trace passes on %d pthreads, logic/shade serial; %.1f s"
-                       % (frames, width, height, frames, threads, dt)), w
+                       % (frames, width, height, frames, threads, dt),
+                single_core_value=round(width * height / dt1 / 1e6, 4), single_core_sample="1 full frame on 1 thread; %.1f s" % dt1), w
 
 
 def main():
