@@ -5,7 +5,8 @@ ARCH      ?= gfx950
 OUT       := nexus_amd/lib/libnexus_amd.so
 OBJDIR    := build/obj
 COMMON    := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Inexus_amd/csrc/device -Inexus_amd/csrc/host -Wall -Wno-unused-function
-DEVFLAGS  := $(COMMON) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
+DEVEXTRA  ?=
+DEVFLAGS  := $(COMMON) $(DEVEXTRA) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
 HOSTFLAGS := $(COMMON)
 
 DEV_SRCS  := $(wildcard nexus_amd/csrc/device/*.hip)
