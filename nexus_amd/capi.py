@@ -544,10 +544,12 @@ class Context:
         check(self.L.nxhip_read_trace_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0), "nxhip_read_trace_stats")
         return a.as_dict(), b.as_dict()
 
-    def enable_kernel_timing(self, on=True, in_graph=False):
+    def enable_kernel_timing(self, on=True, in_graph=False, last_replay_only=False):
         """on: hipEvent pair per kernel launch; in_graph: keep the hipGraph (and its trace || shadow overlap) and time with
-        event-record nodes inside it, otherwise launch kernel by kernel"""
-        check(self.L.nxhip_enable_kernel_timing(self.h, (2 if in_graph else 1) if on else 0), "nxhip_enable_kernel_timing")
+        event-record nodes inside it, otherwise launch kernel by kernel; last_replay_only (with in_graph): no sync between
+        replays, read_kernel_times returns the last replay of the series"""
+        mode = 0 if not on else (3 if (in_graph and last_replay_only) else 2 if in_graph else 1)
+        check(self.L.nxhip_enable_kernel_timing(self.h, mode), "nxhip_enable_kernel_timing")
 
     def read_kernel_times(self, reset=False):
         t = KernelTimes()

@@ -98,9 +98,10 @@ struct nxhip_ctx {
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
     bool statsEnabled = false;
     bool timingEnabled = false;
-    int timingMode = 0;  // 0 off, 1 eager launches with an event pair each, 2 event-record nodes inside the frame graph
+    int timingMode = 0;  // 0 off, 1 eager launches with an event pair each, 2 / 3 event-record nodes inside the frame graph
     std::vector<nxd::KernelTimer> graphTimers;
     std::vector<int> graphTimerClass;
+    bool graphTimersPending = false;  // mode 3: the graph's events hold an unread replay
     nxhip_kernel_times times{};
     std::vector<nxd::KernelTimer> timerPool;
     std::vector<int> timerClass;  // kernel class of timerPool[i]

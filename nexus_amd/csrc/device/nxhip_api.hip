@@ -778,7 +778,7 @@ static int build_graph(nxhip_ctx* c)
 {
     invalidate_graph(c);
     NX_HIP(hipGraphCreate(&c->graph, 0));
-    const bool timed = c->timingMode == 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
+    const bool timed = c->timingMode >= 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
     auto levels = frame_levels(c);
     std::vector<hipGraphNode_t> prev;
     for (auto& level : levels) {
@@ -844,6 +844,7 @@ try {
             if (rc != NXHIP_OK) return rc;
         }
         NX_HIP(hipGraphLaunch(c->graphExec, c->stream));
+        if (c->timingMode == 3) c->graphTimersPending = true;  // read at nxhip_read_kernel_times: the last replay only
         if (c->timingMode == 2) {
             // the graph's events are re-recorded by the next replay: read them now (timing mode is not the fast path)
             NX_HIP(hipStreamSynchronize(c->stream));
@@ -1276,9 +1277,10 @@ int nxhip_tex2d_batch(nxhip_ctx* c, int kind, int textureId, const float* uv, ui
 int nxhip_enable_kernel_timing(nxhip_ctx* c, int enable)
 {
     NX_CHECK_CTX(c);
-    if (enable < 0 || enable > 2) return fail_invalid("nxhip_enable_kernel_timing: mode must be 0, 1 or 2");
+    if (enable < 0 || enable > 3) return fail_invalid("nxhip_enable_kernel_timing: mode must be 0, 1, 2 or 3");
     if (enable != c->timingMode) invalidate_graph(c);
     c->timingMode = enable;
+    c->graphTimersPending = false;
     c->timingEnabled = enable != 0;
     return NXHIP_OK;
 }
@@ -1298,6 +1300,15 @@ int nxhip_read_kernel_times(nxhip_ctx* c, nxhip_kernel_times* out, int reset)
     }
     c->timerPool.clear();
     c->timerClass.clear();
+    if (c->graphTimersPending) {  // mode 3: the events hold the last replay of a back-to-back series
+        for (size_t i = 0; i < c->graphTimers.size(); i++) {
+            float ms = 0.0f;
+            NX_HIP(hipEventElapsedTime(&ms, c->graphTimers[i].start, c->graphTimers[i].stop));
+            c->times.ms[c->graphTimerClass[i]] += ms;
+            c->times.launches[c->graphTimerClass[i]]++;
+        }
+        c->graphTimersPending = false;
+    }
     *out = c->times;
     if (reset) std::memset(&c->times, 0, sizeof c->times);
     return NXHIP_OK;
