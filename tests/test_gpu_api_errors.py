@@ -111,3 +111,39 @@ def test_contexts_are_independent_and_closing_is_idempotent(gpu_ctx_factory):
     a.close()
     with pytest.raises(NexusError):
         b.render_frame()
+
+
+def test_contexts_release_their_device_memory():
+    """create -> upload -> render -> destroy, many times: free device memory returns to where it was (queues, BVH copies,
+    textures, graph, events and streams are all owned by the context)."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so.7")  # the runtime libnexus_amd.so is bound to
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    scene = SH.material_zoo_scene(256, 192, path_length=3)
+
+    def cycle():
+        ctx = capi.Context(256, 192, device=0)
+        scene.upload(ctx)
+        ctx.set_frames_per_pass(4)
+        ctx.render_frame()
+        ctx.accumulate()
+        ctx.enable_kernel_timing(True, in_graph=True)
+        ctx.render_frame()
+        ctx.read_kernel_times(reset=True)
+        ctx.resize(128, 96)
+        ctx.close()
+
+    for _ in range(6):  # the runtime's own pools (code objects, scratch, graph memory) settle during the first cycles
+        cycle()
+    before = free_bytes()
+    for _ in range(24):
+        cycle()
+    after = free_bytes()
+    assert before - after < 16 << 20, (before, after)  # one context of this size holds about 60 MB
