@@ -109,3 +109,53 @@ def test_config5_ten_million_triangles_4k_path16(gpu_ctx_factory):
     for k in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize"):
         assert q[k][1] > 0, k
     assert q["traceShadowSize"][1] > 0
+
+
+def test_config1_gpu_bvh8_against_the_cpu_bvh2_path(gpu_ctx_factory):
+    """BASELINE.json configs[0] names a "CPU BVH2 intersect reference path": the Cornell box flattened to 32 world-space
+    triangles, a binary BVH2 over them and the two-child ordered descent (the oracle's restatement of the algorithm in
+    the reference's un-included Cuda/BVH/BVH2Traversal.cuh:7-52), against the GPU's TLAS + BVH8 traversal of the instanced
+    scene, for every primary ray of the 512 x 512 view.  Different arithmetic (world-space triangles vs instance-space
+    rays), so distances agree to 1e-5 relative, hit / miss exactly away from silhouettes."""
+    import ctypes as C
+
+    W = H = 512
+    scene = SH.cornell_scene(W, H, path_length=4)
+    # world-space copy of every instance's triangles
+    world = []
+    for inst in scene.instances:
+        tris = scene.blas[int(inst["bvhIdx"])][1].copy()
+        M = inst["transform"].reshape(4, 4).astype(np.float64)
+        for k in ("pos0", "pos1", "pos2"):
+            p = tris[k].astype(np.float64)
+            tris[k] = (p @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+        world.append(tris)
+    world = np.concatenate(world)
+    assert len(world) == 32
+    # the camera's pixel-centre rays (no lens, no jitter)
+    cam = scene.camera
+    jj, ii = np.mgrid[0:H, 0:W]
+    x = ((ii + 0.5) / W).reshape(-1, 1)
+    y = ((jj + 0.5) / H).reshape(-1, 1)
+    target = cam["lowerLeftCorner"].astype(np.float64) + cam["viewportX"].astype(np.float64) * x + cam["viewportY"].astype(np.float64) * y
+    d = target - cam["position"].astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(W * H, dtype=pod.RAY_DT)
+    rays["origin"] = cam["position"]
+    rays["direction"] = d.astype(np.float32)
+
+    b = O._Bvh2()
+    assert O.lib().orc_bvh2_build(O._ptr(world), len(world), C.byref(b)) == 0
+    want = np.zeros(len(rays), dtype=pod.HIT_DT)
+    O.lib().orc_bvh2_trace_closest(C.byref(b), O._ptr(world), O._ptr(rays), len(rays), O._ptr(want))
+    O.lib().orc_bvh2_free(C.byref(b))
+
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    got = ctx.trace_batch(rays)
+    hit_g, hit_w = got["hitDistance"] < 1e29, want["hitDistance"] < 1e29
+    assert hit_w.mean() > 0.85
+    assert (hit_g == hit_w).mean() > 0.9995  # silhouette pixels may fall either side
+    both = hit_g & hit_w
+    rel = np.abs(got["hitDistance"][both] - want["hitDistance"][both]) / want["hitDistance"][both]
+    assert np.quantile(rel, 0.999) < 1e-5 and (rel < 1e-3).mean() > 0.9995
