@@ -126,3 +126,37 @@ def test_axis_aligned_rays_with_signed_zero_components(gpu_ctx_factory, make_sce
     # nearly-aligned half is expected to hit anything
     assert (want["hitDistance"][n:] < 1e29).mean() > 0.02
     assert SH.hit_records_equal(got, want)
+
+
+def test_degenerate_geometry_planar_meshes_and_zero_area_triangles(gpu_ctx_factory):
+    """Nodes with zero extent on an axis (every triangle in one plane: the frame exponent comes from log2(0)), zero-area
+    triangles (1/det = inf, NaN barycentrics) and sliver triangles: same hits as the oracle, bit for bit, and the planar
+    meshes are still hit."""
+    rng = np.random.RandomState(71)
+    # an axis-aligned planar grid (z = 0.25 exactly) and a tilted one
+    g = np.linspace(-1, 1, 17, dtype=np.float32)
+    quads = []
+    for i in range(16):
+        for j in range(16):
+            p = lambda a, b: (g[a], g[b], np.float32(0.25))
+            quads.append([p(i, j), p(i + 1, j), p(i + 1, j + 1)])
+            quads.append([p(i, j), p(i + 1, j + 1), p(i, j + 1)])
+    planar = pod.make_triangles(np.array(quads, dtype=np.float32))
+    soup = scenegen.random_soup(400, seed=9, extent=0.8, size=0.1)
+    bad = soup[:60].copy()
+    bad["pos1"][:20] = bad["pos0"][:20]                                     # two equal vertices
+    bad["pos2"][20:40] = bad["pos0"][20:40] * 0.5 + bad["pos1"][20:40] * 0.5  # three collinear vertices
+    bad["pos2"][40:60] = bad["pos1"][40:60] + np.float32(1e-7)               # slivers
+    mixed = np.concatenate([soup, bad])
+    scene = SH.BuiltScene([planar, mixed], [(0, 0, SH.IDENTITY), (1, 0, SH.IDENTITY),
+                                            (0, 0, __import__("nexus_amd").capi.mat4_from_trs((0.2, -0.3, 0.1), (35, 20, 10), (1.3, 0.7, 1.0)))])
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    rays = _rays_for(scene, 40000, seed=81)
+    got = ctx.trace_batch(rays)
+    want = scene.oracle().trace_closest(rays)
+    assert SH.hit_records_equal(got, want)
+    planar_hits = (want["hitDistance"] < 1e29) & ((want["instanceIdx"] == 0) | (want["instanceIdx"] == 2))
+    assert planar_hits.mean() > 0.05
+    tmax = np.where(want["hitDistance"] < 1e29, want["hitDistance"] * 1.001, 10.0).astype(np.float32)
+    assert np.array_equal(ctx.trace_shadow_batch(rays, tmax), scene.oracle().trace_any(rays, tmax))
