@@ -361,3 +361,36 @@ def test_accumulation_checkpoint_resumes_bit_for_bit(gpu_ctx_factory, tmp_path):
         c.accumulate()
     assert np.array_equal(c.read_accumulation().view(np.uint32), want_acc.view(np.uint32))
     assert np.array_equal(c.read_rgba8(), want_px)
+
+
+@pytest.mark.parametrize("W,H,path_length", [(1, 1, 3), (33, 17, 1), (7, 64, 40), (130, 3, 6)])
+def test_ragged_viewports_and_extreme_path_lengths(gpu_ctx_factory, W, H, path_length):
+    """Viewports that are not multiples of the wave / workgroup / tile sizes, a single pixel, pathLength 1 and a long one."""
+    scene = SH.material_zoo_scene(W, H, path_length=path_length)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    frames = 3
+    got = _render_gpu(ctx, frames)
+    w, want = _render_oracle(scene, W * H, frames, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
+    for f in range(frames):
+        assert got[f].shape == (W * H, 3) and np.isfinite(got[f]).all()
+        # few pixels: allow one pixel whose path branched differently
+        bad = (~np.all(np.abs(got[f] - want[f]) <= PIXEL_TOL * np.maximum(1.0, np.abs(want[f])), axis=1)).sum()
+        assert bad <= max(1, int(0.01 * W * H)), (f, bad)
+    q, qo = ctx.read_queue_sizes(), w.queue_sizes()
+    assert q["traceSize"][0] == W * H
+    assert all(int(q["traceSize"][b]) == 0 for b in range(path_length + 1, path_length + 3))
+    # the same frames with several frames per pass and with an 8x8-tiled pixel order
+    from nexus_amd import multigpu
+
+    pm = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)
+    ctx.set_pixel_map(pm)
+    ctx.set_frames_per_pass(frames)
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    rad = ctx.read_radiance().reshape(frames, W * H, 3)
+    for f in range(frames):
+        full = np.zeros_like(rad[f])
+        full[pm] = rad[f]
+        assert np.array_equal(full.view(np.uint32), got[f].view(np.uint32)), f
