@@ -1,5 +1,7 @@
-// nexus/BVHInstance.h — an instance of a BLAS: transform, inverse, world bounds, material.
-// Mirrors /root/reference/Nexus/src/Geometry/BVH/BVHInstance.h:11-38, BVHInstance.cpp:4-45.
+// nexus/BVHInstance.h — one placement of a BLAS in the scene.
+// Public methods of /root/reference/Nexus/src/Geometry/BVH/BVHInstance.h:11-38 (SetTransform x2, GetBounds, AssignMaterial,
+// ToDevice).  The object keeps the 160-byte device record itself up to date, so ToDevice() is a copy and a scene upload is
+// a gather of records.
 #pragma once
 
 #include "BVH8.h"
@@ -9,32 +11,30 @@ namespace nexus {
 
 class BVHInstance {
 public:
-    BVHInstance() = default;
-    BVHInstance(unsigned int blasIdx, const BVH8* bvh) : m_BvhIdx(blasIdx), m_Bvh(bvh)
-    {
-        Mat4 m;
-        SetTransform(m);
-    }
+    BVHInstance();
+    // identity placement of BLAS number `blasIdx`; `blas` supplies the root quantisation frame the world bounds derive from
+    BVHInstance(unsigned int blasIdx, const BVH8* blas);
 
-    void SetTransform(const Mat4& t);
+    // Place the instance.  Euler angles in degrees, composed as Translate * Rz * Ry * Rx * Scale (BVHInstance.cpp:23-28).
     void SetTransform(float3 pos, float3 rotationDegrees, float3 scale);
-    const AABB& GetBounds() const { return m_Bounds; }
-    void AssignMaterial(int mIdx) { m_MaterialId = mIdx; }
-    void SetBvh(const BVH8* bvh) { m_Bvh = bvh; }  // the owning vector may have been re-allocated
-    int GetMaterialId() const { return m_MaterialId; }
-    unsigned int GetBvhIdx() const { return m_BvhIdx; }
-    const Mat4& GetTransform() const { return m_Transform; }
-    const Mat4& GetInvTransform() const { return m_InvTransform; }
+    void SetTransform(const Mat4& objectToWorld);
 
-    static nx_bvh_instance ToDevice(const BVHInstance& inst);
+    void AssignMaterial(int materialIdx) { m_Record.materialId = materialIdx; }
+    int GetMaterialId() const { return m_Record.materialId; }
+    unsigned int GetBvhIdx() const { return m_Record.bvhIdx; }
+    // The BLAS lives in a std::vector owned by the AssetManager: re-point after that vector may have re-allocated.
+    void SetBvh(const BVH8* blas) { m_Blas = blas; }
+
+    const AABB& GetBounds() const { return m_WorldBounds; }
+    Mat4 GetTransform() const;
+    Mat4 GetInvTransform() const;
+
+    static nx_bvh_instance ToDevice(const BVHInstance& inst) { return inst.m_Record; }
 
 private:
-    unsigned int m_BvhIdx = 0;
-    const BVH8* m_Bvh = nullptr;
-    Mat4 m_InvTransform;
-    Mat4 m_Transform;
-    AABB m_Bounds;
-    int m_MaterialId = 0;
+    nx_bvh_instance m_Record;  // bvhIdx, inverse and forward transform, world bounds, material: what the kernels read
+    AABB m_WorldBounds;        // same box as m_Record.boundsMin/Max, in the host's AABB type for the TLAS builder
+    const BVH8* m_Blas = nullptr;
 };
 
 }  // namespace nexus

@@ -1,7 +1,8 @@
 // nexus/Camera.h — thin-lens camera of the kept API surface.
-// Mirrors /root/reference/Nexus/src/Scene/Camera.h:9-50 and Camera.cpp:14-35,102-168 minus the GLFW/glm input
-// handling (viewer side, out of scope): position / forward / right, horizontal FOV, focus distance, defocus angle,
-// ToDevice() computing the viewport basis the generate kernel reads.
+// Same public methods as /root/reference/Nexus/src/Scene/Camera.h:9-50 (so viewer code compiles against it) minus the
+// GLFW / glm input handling (OnUpdate, RayThroughPixel, mouse state: viewer side, out of scope).  State is grouped the
+// way the device consumes it: a pose, a lens, a viewport.  ToDevice() derives the viewport basis the generate kernel
+// reads (Camera.cpp:142-168).
 #pragma once
 
 #include "Math.h"
@@ -10,37 +11,52 @@ namespace nexus {
 
 class Camera {
 public:
+    struct Pose {
+        float3 position, forward, right;
+    };
+    struct Lens {
+        float horizontalFovDeg;  // full horizontal angle
+        float defocusAngleDeg;   // aperture cone angle; 0 = pinhole
+        float focusDist;
+    };
+
+    // Reference defaults: at (0,0,2) looking down -z, defocus 10 degrees, focus distance 5.
     Camera(float horizontalFOV, uint32_t width, uint32_t height);
     Camera(float3 position, float3 forward, float horizontalFOV, uint32_t width, uint32_t height, float focusDistance, float defocusAngle);
 
-    void OnResize(uint32_t width, uint32_t height);
-    void SetHorizontalFOV(float horizontalFOV) { m_HorizontalFOV = horizontalFOV; m_Invalid = true; }
-    float& GetHorizontalFOV() { return m_HorizontalFOV; }
-    float& GetDefocusAngle() { return m_DefocusAngle; }
-    float& GetFocusDist() { return m_FocusDist; }
-    uint32_t GetViewportWidth() const { return m_ViewportWidth; }
-    uint32_t GetViewportHeight() const { return m_ViewportHeight; }
-    float3& GetPosition() { return m_Position; }
-    float3& GetForwardDirection() { return m_ForwardDirection; }
-    float3& GetRightDirection() { return m_RightDirection; }
-    void LookAt(float3 position, float3 forward);
+    // ---- pose
+    void LookAt(float3 position, float3 forward);  // right := forward x +Y
+    float3& GetPosition() { return m_Pose.position; }
+    float3& GetForwardDirection() { return m_Pose.forward; }
+    float3& GetRightDirection() { return m_Pose.right; }
 
-    bool IsInvalid() const { return m_Invalid; }
-    void SetInvalid(bool invalid) { m_Invalid = invalid; }
-    void Invalidate() { m_Invalid = true; }
+    // ---- lens (the reference hands out references for its ImGui sliders; callers then Invalidate())
+    void SetHorizontalFOV(float horizontalFOV)
+    {
+        m_Lens.horizontalFovDeg = horizontalFOV;
+        m_Dirty = true;
+    }
+    float& GetHorizontalFOV() { return m_Lens.horizontalFovDeg; }
+    float& GetDefocusAngle() { return m_Lens.defocusAngleDeg; }
+    float& GetFocusDist() { return m_Lens.focusDist; }
+
+    // ---- viewport
+    void OnResize(uint32_t width, uint32_t height);
+    uint32_t GetViewportWidth() const { return m_Viewport[0]; }
+    uint32_t GetViewportHeight() const { return m_Viewport[1]; }
+
+    // ---- dirty tracking consumed by Scene::IsInvalid / PathTracer::UpdateDeviceScene
+    void Invalidate() { m_Dirty = true; }
+    void SetInvalid(bool invalid) { m_Dirty = invalid; }
+    bool IsInvalid() const { return m_Dirty; }
 
     static nx_camera ToDevice(const Camera& camera);
 
 private:
-    float m_HorizontalFOV;
-    float m_DefocusAngle;
-    float m_FocusDist;
-    uint32_t m_ViewportWidth;
-    uint32_t m_ViewportHeight;
-    float3 m_Position;
-    float3 m_ForwardDirection;
-    float3 m_RightDirection;
-    bool m_Invalid = true;
+    Pose m_Pose;
+    Lens m_Lens;
+    uint32_t m_Viewport[2];
+    bool m_Dirty = true;
 };
 
 }  // namespace nexus

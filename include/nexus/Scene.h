@@ -1,6 +1,7 @@
-// nexus/Scene.h — mirrors /root/reference/Nexus/src/Scene/Scene.h:17-76, Scene.cpp:10-176: mesh instances, lights
-// (an instance is a light iff its material is emissive), dirty tracking, TLAS rebuild on change.
-// The device copies are pushed by PathTracer::UpdateDeviceScene through the C-ABI instead of by DeviceVector members.
+// nexus/Scene.h — the scene graph of the kept API surface: assets, placed mesh instances, derived lights, TLAS.
+// Public methods of /root/reference/Nexus/src/Scene/Scene.h:17-76 (Scene.cpp:10-176).  Differences in kind, not in API:
+// there are no device members here — PathTracer::UpdateDeviceScene pushes what changed through the C-ABI and uses the
+// `*Dirty` flags below to know what that is — and the HDR map is handed over as pixels, not as a file to decode.
 #pragma once
 
 #include <memory>
@@ -20,51 +21,61 @@ public:
     Scene(uint32_t width, uint32_t height);
     void Reset();
 
-    std::shared_ptr<Camera> GetCamera() const { return m_Camera; }
-    void AddMaterial(Material& material) { m_AssetManager.AddMaterial(material); }
-    std::vector<Material>& GetMaterials() { return m_AssetManager.GetMaterials(); }
-    AssetManager& GetAssetManager() { return m_AssetManager; }
-    const AssetManager& GetAssetManager() const { return m_AssetManager; }
-    std::shared_ptr<TLAS> GetTLAS() const { return m_Tlas; }
-    const RenderSettings& GetRenderSettings() const { return m_RenderSettings; }
-    RenderSettings& GetRenderSettings() { return m_RenderSettings; }
-
-    bool IsEmpty() const { return m_MeshInstances.empty(); }
-    void Invalidate() { m_Invalid = true; }
-    bool IsInvalid() const { return m_Invalid || !m_InvalidMeshInstances.empty() || m_Camera->IsInvalid() || m_AssetManager.IsInvalid(); }
-
-    void Update();     // apply instance transforms / materials, rebuild + convert the TLAS
-    void BuildTLAS();
-    // Extension: when only transforms / materials of existing instances change, refit the TLAS (O(n)) instead of
-    // rebuilding it (the reference always rebuilds, Scene.cpp:29-55).  Off by default.
-    void SetTlasRefit(bool enable) { m_TlasRefit = enable; }
-    MeshInstance& CreateMeshInstance(uint32_t meshId);
-    // Scene.cpp:83-91: load a .glb / .obj (OBJLoader::LoadOBJ), one BVH per mesh, one instance per (node, primitive)
+    // ---- building the scene ------------------------------------------------------------------------------------
+    // Load a .glb / .obj through OBJLoader::LoadOBJ: one BVH8 per mesh, one instance per (node, primitive) — Scene.cpp:83-91
     void CreateMeshInstanceFromFile(const std::string& path, const std::string& fileName);
-    std::vector<MeshInstance>& GetMeshInstances() { return m_MeshInstances; }
-    const std::vector<BVHInstance>& GetBVHInstances() const { return m_BVHInstances; }
+    // Place mesh `meshId` (AssetManager::AddMesh) with the mesh's own transform and material; a light is derived if its
+    // material emits.  The returned reference is valid until the next instance is created.
+    MeshInstance& CreateMeshInstance(uint32_t meshId);
+    void AddMaterial(Material& material) { m_AssetManager.AddMaterial(material); }
     void AddHDRMap(const Texture& texture);
-    const Texture& GetHDRMap() const { return m_HdrMap; }
-    void InvalidateMeshInstance(uint32_t instanceId) { m_InvalidMeshInstances.insert(instanceId); }
-    const std::vector<Light>& GetLights() const { return m_Lights; }
     size_t AddLight(const Light& light);
     void RemoveLight(size_t index);
 
-    // consumed by PathTracer::UpdateDeviceScene
+    // ---- editing: change a MeshInstance, then tell the scene which one --------------------------------------------
+    std::vector<MeshInstance>& GetMeshInstances() { return m_MeshInstances; }
+    void InvalidateMeshInstance(uint32_t instanceId) { m_InvalidMeshInstances.insert(instanceId); }
+    void Invalidate() { m_Invalid = true; }
+    // Extension, off by default: when only existing instances changed, refit the TLAS (O(n)) in Update() instead of the
+    // reference's full agglomerative rebuild (Scene.cpp:29-55).
+    void SetTlasRefit(bool enable) { m_TlasRefit = enable; }
+
+    // ---- per frame -----------------------------------------------------------------------------------------------
+    bool IsInvalid() const { return m_Invalid || !m_InvalidMeshInstances.empty() || m_Camera->IsInvalid() || m_AssetManager.IsInvalid(); }
+    void Update();     // apply pending instance edits, refresh lights, bring the TLAS up to date
+    void BuildTLAS();  // unconditional rebuild + BVH8 conversion
+
+    // ---- read access ---------------------------------------------------------------------------------------------
+    bool IsEmpty() const { return m_MeshInstances.empty(); }
+    std::shared_ptr<Camera> GetCamera() const { return m_Camera; }
+    std::shared_ptr<TLAS> GetTLAS() const { return m_Tlas; }
+    AssetManager& GetAssetManager() { return m_AssetManager; }
+    const AssetManager& GetAssetManager() const { return m_AssetManager; }
+    std::vector<Material>& GetMaterials() { return m_AssetManager.GetMaterials(); }
+    RenderSettings& GetRenderSettings() { return m_RenderSettings; }
+    const RenderSettings& GetRenderSettings() const { return m_RenderSettings; }
+    const std::vector<BVHInstance>& GetBVHInstances() const { return m_BVHInstances; }
+    const std::vector<Light>& GetLights() const { return m_Lights; }
+    const Texture& GetHDRMap() const { return m_HdrMap; }
+
+    // what the device has not seen yet (set here, cleared by PathTracer::UpdateDeviceScene)
     mutable bool tlasDirty = true, lightsDirty = true, hdrDirty = false;
 
 private:
+    // derive / drop the MESH_LIGHT of instance `index` from its material (Scene.cpp:142-176)
     void UpdateInstanceLighting(size_t index);
 
-    std::shared_ptr<Camera> m_Camera;
-    std::vector<BVHInstance> m_BVHInstances;
-    std::vector<MeshInstance> m_MeshInstances;
-    std::vector<Light> m_Lights;
-    std::set<uint32_t> m_InvalidMeshInstances;
-    std::shared_ptr<TLAS> m_Tlas;
-    Texture m_HdrMap;
     AssetManager m_AssetManager;
     RenderSettings m_RenderSettings;
+    std::shared_ptr<Camera> m_Camera;
+    Texture m_HdrMap;
+
+    std::vector<MeshInstance> m_MeshInstances;  // what the user edits
+    std::vector<BVHInstance> m_BVHInstances;    // what the TLAS and the device see, one per mesh instance
+    std::vector<Light> m_Lights;
+    std::shared_ptr<TLAS> m_Tlas;
+
+    std::set<uint32_t> m_InvalidMeshInstances;
     bool m_Invalid = true;
     bool m_TlasRefit = false;
     size_t m_TlasBuiltFor = 0;  // instance count of the last full TLAS build

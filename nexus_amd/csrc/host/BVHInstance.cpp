@@ -1,42 +1,76 @@
-// BVHInstance.cpp — instance transform and world bounds.
-// Semantics of /root/reference/Nexus/src/Geometry/BVH/BVHInstance.cpp:4-45: the world AABB is the
-// transform of the BLAS *root node's quantisation frame* (p, p + 2^(e-127) * 255), i.e. looser than the
-// exact bounds; rotation order Translate * Rz * Ry * Rx * Scale with angles in degrees.
+// BVHInstance.cpp — see include/nexus/BVHInstance.h.
+// World bounds follow /root/reference/Nexus/src/Geometry/BVH/BVHInstance.cpp:4-21 exactly, because the TLAS (and with it
+// every traversal order) is built from them: they are the transformed corners of the BLAS root node's *quantisation frame*
+// [p, p + 2^(e-127) * 255], which is looser than the mesh's exact box.
 #include "nexus/BVHInstance.h"
 
 namespace nexus {
 
-void BVHInstance::SetTransform(const Mat4& t)
+namespace {
+
+// the root node's decode frame of a BLAS: lower corner and per-axis extent 2^(e-127) * (2^8 - 1)
+void root_frame(const BVH8& blas, float3& lo, float3& hi)
 {
-    m_Transform = t;
-    m_InvTransform = t.Inverted();
-    const BVH8Node& root = m_Bvh->nodes[0];
-    const float3 bMin = make_float3(root.p);
-    const float3 bMax = bMin + make_float3(std::exp2(static_cast<float>(root.e[0] - 127)), std::exp2(static_cast<float>(root.e[1] - 127)),
-                                           std::exp2(static_cast<float>(root.e[2] - 127))) * (std::exp2(8.0f) - 1.0f);
-    m_Bounds = AABB();
-    for (int i = 0; i < 8; i++)
-        m_Bounds.Grow(TransformPosition(make_float3(i & 1 ? bMax.x : bMin.x, i & 2 ? bMax.y : bMin.y, i & 4 ? bMax.z : bMin.z), t));
+    const BVH8Node& root = blas.nodes[0];
+    const float steps = std::exp2(8.0f) - 1.0f;
+    lo = make_float3(root.p);
+    hi = lo + make_float3(std::exp2(static_cast<float>(root.e[0] - 127)), std::exp2(static_cast<float>(root.e[1] - 127)),
+                          std::exp2(static_cast<float>(root.e[2] - 127))) * steps;
 }
 
-void BVHInstance::SetTransform(float3 pos, float3 r, float3 s)
+Mat4 to_mat4(const nx_mat4& m)
 {
-    const Mat4 t = Mat4::Translate(pos) * Mat4::RotateZ(Utils::ToRadians(r.z)) * Mat4::RotateY(Utils::ToRadians(r.y)) *
-                   Mat4::RotateX(Utils::ToRadians(r.x)) * Mat4::Scale(s);
-    SetTransform(t);
+    Mat4 r;
+    std::memcpy(r.cell, m.cell, sizeof r.cell);
+    return r;
 }
 
-nx_bvh_instance BVHInstance::ToDevice(const BVHInstance& inst)
+}  // namespace
+
+BVHInstance::BVHInstance()
 {
-    nx_bvh_instance d;
-    std::memset(&d, 0, sizeof d);
-    d.bvhIdx = inst.m_BvhIdx;
-    std::memcpy(d.invTransform.cell, inst.m_InvTransform.cell, 64);
-    std::memcpy(d.transform.cell, inst.m_Transform.cell, 64);
-    store(d.boundsMin, inst.m_Bounds.bMin);
-    store(d.boundsMax, inst.m_Bounds.bMax);
-    d.materialId = inst.m_MaterialId;
-    return d;
+    std::memset(&m_Record, 0, sizeof m_Record);
+    const Mat4 identity;
+    std::memcpy(m_Record.transform.cell, identity.cell, sizeof identity.cell);
+    std::memcpy(m_Record.invTransform.cell, identity.cell, sizeof identity.cell);
+}
+
+BVHInstance::BVHInstance(unsigned int blasIdx, const BVH8* blas) : BVHInstance()
+{
+    m_Record.bvhIdx = blasIdx;
+    m_Blas = blas;
+    SetTransform(Mat4::Identity());
+}
+
+Mat4 BVHInstance::GetTransform() const { return to_mat4(m_Record.transform); }
+Mat4 BVHInstance::GetInvTransform() const { return to_mat4(m_Record.invTransform); }
+
+void BVHInstance::SetTransform(float3 pos, float3 rotationDegrees, float3 scale)
+{
+    using Utils::ToRadians;
+    // evaluated left to right, as the reference's expression is: ((((T * Rz) * Ry) * Rx) * S)
+    Mat4 m = Mat4::Translate(pos);
+    m = m * Mat4::RotateZ(ToRadians(rotationDegrees.z));
+    m = m * Mat4::RotateY(ToRadians(rotationDegrees.y));
+    m = m * Mat4::RotateX(ToRadians(rotationDegrees.x));
+    SetTransform(m * Mat4::Scale(scale));
+}
+
+void BVHInstance::SetTransform(const Mat4& objectToWorld)
+{
+    const Mat4 worldToObject = objectToWorld.Inverted();
+    std::memcpy(m_Record.transform.cell, objectToWorld.cell, sizeof objectToWorld.cell);
+    std::memcpy(m_Record.invTransform.cell, worldToObject.cell, sizeof worldToObject.cell);
+
+    float3 lo, hi;
+    root_frame(*m_Blas, lo, hi);
+    m_WorldBounds = AABB();
+    for (int corner = 0; corner < 8; corner++) {  // corner bit 0 / 1 / 2 selects hi on x / y / z
+        const float3 c = make_float3((corner & 1) ? hi.x : lo.x, (corner & 2) ? hi.y : lo.y, (corner & 4) ? hi.z : lo.z);
+        m_WorldBounds.Grow(TransformPosition(c, objectToWorld));
+    }
+    store(m_Record.boundsMin, m_WorldBounds.bMin);
+    store(m_Record.boundsMax, m_WorldBounds.bMax);
 }
 
 }  // namespace nexus

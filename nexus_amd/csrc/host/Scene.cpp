@@ -25,31 +25,40 @@ void Scene::Reset()
     tlasDirty = lightsDirty = true;
 }
 
+// Scene::Update — Scene.cpp:29-55: push pending instance edits into the BVH instances, refresh lights, then bring the TLAS
+// up to date (a full agglomerative rebuild as in the reference, or the O(n) refit extension when only existing instances
+// changed and it is enabled).
 void Scene::Update()
 {
     m_Camera->SetInvalid(false);
     m_AssetManager.SendDataToDevice();
-    if (!m_InvalidMeshInstances.empty()) {
-        for (uint32_t i : m_InvalidMeshInstances) {
-            MeshInstance& meshInstance = m_MeshInstances[i];
-            BVHInstance& inst = m_BVHInstances[meshInstance.bvhInstanceIdx];
-            inst.SetBvh(&m_AssetManager.GetBVHs()[m_AssetManager.GetMeshes()[inst.GetBvhIdx()].bvhId]);
-            inst.SetTransform(meshInstance.position, meshInstance.rotation, meshInstance.scale);
-            if (meshInstance.materialId != -1) {
-                inst.AssignMaterial(meshInstance.materialId);
-                UpdateInstanceLighting(i);
-            }
-        }
-        if (!m_Tlas) m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
-        m_Tlas->SetBVHInstances(m_BVHInstances);
-        if (!(m_TlasRefit && m_TlasBuiltFor == m_BVHInstances.size() && m_Tlas->Refit())) {
-            m_Tlas->Build();
-            m_Tlas->Convert();
-            m_TlasBuiltFor = m_BVHInstances.size();
-        }
-        tlasDirty = true;
-        m_InvalidMeshInstances.clear();
+    if (m_InvalidMeshInstances.empty()) {
+        m_Invalid = false;
+        return;
     }
+
+    const std::vector<Mesh>& meshes = m_AssetManager.GetMeshes();
+    std::vector<BVH8>& blases = m_AssetManager.GetBVHs();
+    for (const uint32_t id : m_InvalidMeshInstances) {
+        const MeshInstance& edited = m_MeshInstances[id];
+        BVHInstance& placed = m_BVHInstances[static_cast<size_t>(edited.bvhInstanceIdx)];
+        placed.SetBvh(&blases[static_cast<size_t>(meshes[placed.GetBvhIdx()].bvhId)]);  // the vector may have grown since
+        placed.SetTransform(edited.position, edited.rotation, edited.scale);
+        if (edited.materialId == -1) continue;
+        placed.AssignMaterial(edited.materialId);
+        UpdateInstanceLighting(id);
+    }
+    m_InvalidMeshInstances.clear();
+
+    if (!m_Tlas) m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
+    m_Tlas->SetBVHInstances(m_BVHInstances);
+    const bool sameInstances = m_TlasBuiltFor == m_BVHInstances.size();
+    if (!(m_TlasRefit && sameInstances && m_Tlas->Refit())) {
+        m_Tlas->Build();
+        m_Tlas->Convert();
+        m_TlasBuiltFor = m_BVHInstances.size();
+    }
+    tlasDirty = true;
     m_Invalid = false;
 }
 
@@ -99,20 +108,29 @@ void Scene::RemoveLight(size_t index)
     lightsDirty = true;
 }
 
+namespace {
+
+// Scene.cpp:142-176 in two predicates.  An instance *becomes* a light when its material has an emissive map or
+// intensity * max(emissive) > 0; an existing light is *dropped* only when max(emissive * intensity) is exactly 0 (so a
+// textured emitter with a black emissive factor keeps its light — the reference's asymmetry, kept).
+bool starts_emitting(const Material& m) { return m.emissiveMapId != -1 || m.intensity * fmaxf(make_float3(m.emissive)) > 0.0f; }
+bool stops_emitting(const Material& m) { return fmaxf(make_float3(m.emissive) * m.intensity) == 0.0f; }
+
+}  // namespace
+
 void Scene::UpdateInstanceLighting(size_t index)
 {
-    const MeshInstance& meshInstance = m_MeshInstances[index];
-    if (meshInstance.materialId == -1) return;
-    const Material& material = m_AssetManager.GetMaterials()[meshInstance.materialId];
-    const float3 emissive = make_float3(material.emissive);
-    for (size_t i = 0; i < m_Lights.size(); i++) {
-        const Light& light = m_Lights[i];
-        if (light.type == NX_LIGHT_MESH && light.mesh.meshId == index) {
-            if (fmaxf(emissive * material.intensity) == 0.0f) RemoveLight(i);
-            return;
-        }
-    }
-    if (material.emissiveMapId != -1 || material.intensity * fmaxf(emissive) > 0.0f) {
+    const int materialId = m_MeshInstances[index].materialId;
+    if (materialId == -1) return;
+    const Material& material = m_AssetManager.GetMaterials()[static_cast<size_t>(materialId)];
+
+    size_t existing = m_Lights.size();
+    for (size_t i = 0; i < m_Lights.size() && existing == m_Lights.size(); i++)
+        if (m_Lights[i].type == NX_LIGHT_MESH && m_Lights[i].mesh.meshId == index) existing = i;
+
+    if (existing != m_Lights.size()) {
+        if (stops_emitting(material)) RemoveLight(existing);
+    } else if (starts_emitting(material)) {
         Light meshLight;
         meshLight.type = NX_LIGHT_MESH;
         meshLight.mesh.meshId = static_cast<uint32_t>(index);
