@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         const f3 origin = camPos + offset;
         const f3 direction = normalize3((((llc + vpX * x) + vpY * y) - camPos) - offset);
         S->rayOrigin[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-        S->throughputPdf[index] = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);
+        // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
+        // reading them back, and the logic kernel stores them for every path that survives its first hit
         S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
         S->trace.rayD[index] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
     }
@@ -211,8 +212,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
             dirPix = S->trace.rayD[index];
             pixelIdx = __float_as_uint(dirPix.w);
             const f3 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
-            const float4 tp = S->throughputPdf[pixelIdx];
-            const f3 throughput = bounce == 1 ? mk3(1.0f) : mk3(tp.x, tp.y, tp.z);
+            const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
+            const f3 throughput = mk3(tp.x, tp.y, tp.z);
             if (hit.x == 1e30f) {
                 const f3 bg = throughput * sample_background(S, dir);
                 float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
@@ -357,8 +358,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             const uint32_t instanceIdx = __float_as_uint(dirInst.w), triIdx = __float_as_uint(hit.w);
             const float hu = hit.y, hv = hit.z;
 
-            const float4 tpdf = S->throughputPdf[pixelIdx];
-            f3 throughput = bounce == 1 ? mk3(1.0f) : mk3(tpdf.x, tpdf.y, tpdf.z);
+            const float4 tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
+            f3 throughput = mk3(tpdf.x, tpdf.y, tpdf.z);
             uint32_t rng = seed_for(S, (uint32_t)requestIdx, pixelIdx, (uint32_t)bounce, 1u, frame);
 
             const nx_bvh_instance* inst = &S->instances[instanceIdx];
