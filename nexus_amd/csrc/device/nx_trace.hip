@@ -181,10 +181,10 @@ NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t inv
 }
 
 template <bool ANY_HIT, bool STATS>
-// 5 waves per SIMD for both variants: the any-hit kernel would otherwise take 108 VGPRs (4 waves); measured +7 % on the bench
-// (4: +1 %, 6: -1 %, spills)
+// 6 waves per SIMD for both variants (80 VGPRs; the any-hit variant spills 64 B): measured best with the SLP vectorizer off
+// (5: -3 %, 7: -0.3 %, 8: -1.5 %)
 #ifndef NX_WAVES_PER_EU
-#define NX_WAVES_PER_EU 5
+#define NX_WAVES_PER_EU 6
 #endif
 __attribute__((amdgpu_waves_per_eu(NX_WAVES_PER_EU, NX_WAVES_PER_EU)))
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
