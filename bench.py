@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
     ap.add_argument("--nv", type=int, default=512)
     ap.add_argument("--frames-per-pass", type=int, default=64,
-                    help="frames batched into one wavefront pass on 1 GPU (N ranks: N times as many, at most 256, so that a rank's pass keeps "
+                    help="frames batched into one wavefront pass on 1 GPU (N ranks: N times as many, at most 512, so that a rank's pass keeps "
                          "its size); a step budget that is not a multiple ends with one shorter pass")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,7 +168,7 @@ def main():
     W, H = args.width, args.height
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
-    S = max(1, min(args.frames_per_pass * world, 256, args.steps))
+    S = max(1, min(args.frames_per_pass * world, 512, args.steps))
 
     def schedule(frames):
         """pass sizes that render exactly `frames` frames"""
