@@ -82,32 +82,32 @@ struct Builder {
             }
         }
 
+        // Cost of cutting after bin k = (triangles at or below k) x (area of their box) + the same for the bins above k.
+        // The seven "at or below" states are one running sweep upwards, the seven "above" states one sweep downwards;
+        // both are kept so that the cost loop below reads them side by side.
+        struct Side {
+            AABB box;
+            int tris = 0;
+            void Take(const Bin& b) { box.Grow(b.bounds); tris += b.triCount; }
+            float Weighted() const { return static_cast<float>(tris) * box.Area(); }
+        };
         float bestCost = 1e30f;
         int axis = -1;
         for (int a = 0; a < 3; a++) {
             if (!live[a]) continue;
-            float leftArea[BINS - 1], rightArea[BINS - 1];
-            int leftCount[BINS - 1], rightCount[BINS - 1];
-            AABB leftBox, rightBox;
-            int leftSum = 0, rightSum = 0;
-            for (int i = 0; i < BINS - 1; i++) {
-                leftSum += bins[a][i].triCount;
-                leftCount[i] = leftSum;
-                leftBox.Grow(bins[a][i].bounds);
-                leftArea[i] = leftBox.Area();
-                rightSum += bins[a][BINS - 1 - i].triCount;
-                rightCount[BINS - 2 - i] = rightSum;
-                rightBox.Grow(bins[a][BINS - 1 - i].bounds);
-                rightArea[BINS - 2 - i] = rightBox.Area();
-            }
-            const float boundsMin = comp(cmin, a), boundsMax = comp(cmax, a);
-            const double width = static_cast<double>((boundsMax - boundsMin) / static_cast<float>(BINS));
-            for (int i = 0; i < BINS - 1; i++) {
-                const float planeCost = static_cast<float>(leftCount[i]) * leftArea[i] + static_cast<float>(rightCount[i]) * rightArea[i];
-                if (planeCost < bestCost) {
+            Side below[BINS - 1], above[BINS - 1];
+            Side run;
+            for (int k = 0; k < BINS - 1; k++) { run.Take(bins[a][k]); below[k] = run; }
+            run = Side();
+            for (int k = BINS - 1; k >= 1; k--) { run.Take(bins[a][k]); above[k - 1] = run; }
+            const float lo = comp(cmin, a);
+            const double step = static_cast<double>((comp(cmax, a) - lo) / static_cast<float>(BINS));
+            for (int k = 0; k < BINS - 1; k++) {
+                const float cost = below[k].Weighted() + above[k].Weighted();
+                if (cost < bestCost) {
+                    bestCost = cost;
                     axis = a;
-                    splitPos = boundsMin + width * (i + 1);
-                    bestCost = planeCost;
+                    splitPos = lo + step * (k + 1);
                 }
             }
         }

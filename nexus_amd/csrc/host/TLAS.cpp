@@ -4,6 +4,8 @@
 // TLASBuilder.cpp:5-26 (same SAH-DP collapse as the BLAS, leaf payload = instance id).
 #include "nexus/TLAS.h"
 
+#include <algorithm>
+
 #include "Collapse.h"
 
 namespace nexus {
@@ -24,61 +26,114 @@ void TLAS::BuildFromBounds(const nx_bvh_instance* instances, uint32_t count)
     Cluster(bounds);
 }
 
+namespace {
+
+// The clusters still waiting for a partner, as a structure of arrays: slot k holds the box of BVH2 node `node[k]`.
+// Keeping the six box planes in six contiguous float arrays lets the partner search below run as straight-line
+// vector code over all live slots (the reference walks an index array and dereferences one 40-byte node per candidate).
+// Slot order is part of the result: ties in the search go to the lowest slot, a merged cluster takes the slot of the
+// cluster that started the chain link and the last live slot moves into the hole — the same bookkeeping as the
+// reference's instance-index array (Geometry/BVH/TLAS.cpp:13-91), so the emitted BVH2 is node for node the same.
+struct LiveClusters {
+    std::vector<float> lox, loy, loz, hix, hiy, hiz;
+    std::vector<uint32_t> node;
+    mutable std::vector<float> cost;  // scratch of the partner search
+    int live = 0;
+
+    void Append(const AABB& b, uint32_t nodeIdx)
+    {
+        lox.push_back(b.bMin.x); loy.push_back(b.bMin.y); loz.push_back(b.bMin.z);
+        hix.push_back(b.bMax.x); hiy.push_back(b.bMax.y); hiz.push_back(b.bMax.z);
+        node.push_back(nodeIdx);
+        cost.push_back(0.0f);
+        live++;
+    }
+    void Put(int slot, float3 mn, float3 mx, uint32_t nodeIdx)
+    {
+        lox[slot] = mn.x; loy[slot] = mn.y; loz[slot] = mn.z;
+        hix[slot] = mx.x; hiy[slot] = mx.y; hiz[slot] = mx.z;
+        node[slot] = nodeIdx;
+    }
+    void MoveLastInto(int slot)
+    {
+        const int last = --live;
+        lox[slot] = lox[last]; loy[slot] = loy[last]; loz[slot] = loz[last];
+        hix[slot] = hix[last]; hiy[slot] = hiy[last]; hiz[slot] = hiz[last];
+        node[slot] = node[last];
+    }
+    // Slot whose union with `self` has the smallest half-area; the lowest such slot on ties; -1 if every union
+    // reaches 1e30 (the reference's sentinel) or nothing else is live.
+    int Partner(int self) const
+    {
+        const float ax = lox[self], ay = loy[self], az = loz[self], bx = hix[self], by = hiy[self], bz = hiz[self];
+        float* c = cost.data();
+        for (int k = 0; k < live; k++) {
+            const float ex = std::max(bx, hix[k]) - std::min(ax, lox[k]);
+            const float ey = std::max(by, hiy[k]) - std::min(ay, loy[k]);
+            const float ez = std::max(bz, hiz[k]) - std::min(az, loz[k]);
+            c[k] = ex * ey + ey * ez + ex * ez;
+        }
+        c[self] = 1e30f;
+        int best = -1;
+        float least = 1e30f;
+        for (int k = 0; k < live; k++)
+            if (c[k] < least) { least = c[k]; best = k; }
+        return best;
+    }
+};
+
+}  // namespace
+
 void TLAS::Cluster(const std::vector<AABB>& bounds)
 {
-    nodes.clear();
+    const uint32_t count = static_cast<uint32_t>(bounds.size());
+    nodes.assign(1, TLASNode());  // node 0 is reserved for the root
     instancesIdx.clear();
-    nodes.emplace_back();
-    for (uint32_t i = 0; i < bounds.size(); i++) {
-        instancesIdx.push_back(i + 1);
-        TLASNode node;
-        node.aabbMin = bounds[i].bMin;
-        node.aabbMax = bounds[i].bMax;
-        node.blasIdx = i;
-        node.blasCount = 1;
-        nodes.push_back(node);
+    if (count == 0) return;
+    nodes.reserve(2 * static_cast<size_t>(count));
+    LiveClusters set;
+    for (uint32_t i = 0; i < count; i++) {
+        TLASNode leaf;
+        leaf.aabbMin = bounds[i].bMin;
+        leaf.aabbMax = bounds[i].bMax;
+        leaf.blasIdx = i;
+        leaf.blasCount = 1;
+        set.Append(bounds[i], static_cast<uint32_t>(nodes.size()));
+        nodes.push_back(leaf);
     }
-    int nodeIndices = static_cast<int>(bounds.size());
-    if (nodeIndices == 0) return;
-    int A = 0, B = FindBestMatch(nodeIndices, A);
-    while (nodeIndices > 1) {
-        const int C = FindBestMatch(nodeIndices, B);
-        if (A == C) {
-            const uint32_t nodeIdxA = instancesIdx[A], nodeIdxB = instancesIdx[B];
-            TLASNode newNode;
-            newNode.left = nodeIdxB;
-            newNode.right = nodeIdxA;
-            newNode.blasCount = nodes[nodeIdxA].blasCount + nodes[nodeIdxB].blasCount;
-            newNode.aabbMin = fminf(nodes[nodeIdxA].aabbMin, nodes[nodeIdxB].aabbMin);
-            newNode.aabbMax = fmaxf(nodes[nodeIdxA].aabbMax, nodes[nodeIdxB].aabbMax);
-            instancesIdx[A] = static_cast<uint32_t>(nodes.size());
-            instancesIdx[B] = instancesIdx[nodeIndices - 1];
-            nodes.push_back(newNode);
-            B = FindBestMatch(--nodeIndices, A);
-        } else {
-            A = B;
-            B = C;
+    // Nearest-neighbour chain of length two: `tail` wants `head`; when `head` wants `tail` back the two are joined.
+    int tail = 0, head = set.Partner(tail);
+    while (set.live > 1) {
+        const int wanted = set.Partner(head);
+        if (wanted != tail) {  // not mutual: follow the chain
+            tail = head;
+            head = wanted;
+            continue;
         }
+        const TLASNode& first = nodes[set.node[head]];
+        const TLASNode& second = nodes[set.node[tail]];
+        TLASNode joined;
+        joined.left = set.node[head];
+        joined.right = set.node[tail];
+        joined.blasCount = first.blasCount + second.blasCount;
+        joined.aabbMin = fminf(second.aabbMin, first.aabbMin);
+        joined.aabbMax = fmaxf(second.aabbMax, first.aabbMax);
+        set.Put(tail, joined.aabbMin, joined.aabbMax, static_cast<uint32_t>(nodes.size()));
+        set.MoveLastInto(head);
+        nodes.push_back(joined);
+        head = set.Partner(tail);
     }
-    nodes[0] = nodes[instancesIdx[A]];
+    nodes[0] = nodes[set.node[tail]];
+    // the live-slot table in its final state is what the reference leaves in TLAS::instancesIdx
+    instancesIdx.assign(set.node.begin(), set.node.end());
 }
 
 int TLAS::FindBestMatch(int N, int A) const
 {
-    float smallest = 1e30f;
-    int bestB = -1;
-    for (int B = 0; B < N; B++) {
-        if (B == A) continue;
-        const float3 bMax = fmaxf(nodes[instancesIdx[A]].aabbMax, nodes[instancesIdx[B]].aabbMax);
-        const float3 bMin = fminf(nodes[instancesIdx[A]].aabbMin, nodes[instancesIdx[B]].aabbMin);
-        const float3 e = bMax - bMin;
-        const float surfaceArea = e.x * e.y + e.y * e.z + e.x * e.z;
-        if (surfaceArea < smallest) {
-            smallest = surfaceArea;
-            bestB = B;
-        }
-    }
-    return bestB;
+    // kept for API compatibility (Geometry/BVH/TLAS.h:35): partner search over the current instancesIdx table
+    LiveClusters set;
+    for (int k = 0; k < N; k++) set.Append(AABB(nodes[instancesIdx[k]].aabbMin, nodes[instancesIdx[k]].aabbMax), instancesIdx[k]);
+    return set.Partner(A);
 }
 
 bool TLAS::Refit()
