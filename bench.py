@@ -4,31 +4,43 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config 5        # configs[4]: the 9.9 M-triangle interior whose traversal streams from HBM (1 GPU)
 
 A "step" is one frame = one primary sample per pixel through the whole hot path (generate, trace, then pathLength x
 (logic, shade x4 + NEE, trace || shadow trace), accumulate).  Frames are rendered in passes of up to --frames-per-pass
 frames (one hipGraph replay per pass; each frame keeps its own frame number and RNG streams and the result is
-bit-identical to rendering them one by one); exactly K frames are timed, the last pass being shorter if need be.  Msamples/s is the
-reference viewer's "Megarays/sec": width * height * frames / seconds / 1e6
-(/root/reference/Nexus/src/Renderer/Panels/MetricsPanel.cpp:28,35,56).  Scene and BVH live in HBM before the timed
-region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every rank renders AND accumulates its tiles with
-the scene replicated, and the accumulated tiles (16 B per pixel) are gathered to rank 0 with ONE RCCL gather per pass,
-where they are scattered into the full image and tonemapped; the image is bit-identical to the 1-GPU one.  Total work
-per step is fixed (one 1080p frame): strong scaling.
+bit-identical to rendering them one by one); exactly K frames are timed, the last pass being shorter if need be.  The
+K-frame region is timed --reps times, each bracketed by a barrier + device synchronisation, and the MEDIAN is reported
+(`steps` stays K, `ms_per_step` = median / K; every repetition is listed in `config.rep_ms`): at the driver's K = 20 a
+region is one 30 ms graph replay, and single replays vary by several per cent.  Msamples/s is the reference viewer's
+"Megarays/sec": width * height * frames / seconds / 1e6 (/root/reference/Nexus/src/Renderer/Panels/MetricsPanel.cpp:28,35,56).
+Scene and BVH live in HBM before the timed region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every
+rank renders AND accumulates its tiles with the scene replicated, and the accumulated tiles (16 B per pixel) are gathered
+to rank 0 with ONE RCCL gather per pass, where they are scattered into the full image and tonemapped; the image is
+bit-identical to the 1-GPU one.  Total work per step is fixed (one frame): strong scaling.
 
 Rank 0 prints ONE JSON line.  It also carries
-  roofline     : the trace kernel (closest hit) — algorithmic bytes per launch (SURVEY.md section 8d:
-                 44 B/ray + 80 B/node visit + 40 B/triangle test + 104 B/instance entry, visits counted by the
-                 kernel's own counting variant on the same frames) / average launch duration from hipEvents recorded
-                 by event nodes placed around every kernel node of the production hipGraph (the last replay of a
-                 back-to-back series on the context's stream, i.e. the conditions of the timed region), against
-                 8 TB/s HBM peak.
-  cpu_baseline : the CPU oracle (port of the reference algorithm) on one full frame of the same scene, timed on the
+  roofline     : the closest-hit trace kernel against the two ceilings that could bind it, both from live launch durations
+                 (hipEvents recorded by event nodes around every kernel node of the production hipGraph, last replay of a
+                 back-to-back series on the context's stream):
+                   hbm        : memory-side bytes per launch (`traffic`) = this run's rays per launch x the bytes per ray
+                                that `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` measured for this workload (committed under
+                                profiles/, reads doubled per the gfx950 note of MI355X_MICROARCH.md) / duration / 8 TB/s.
+                                The ALGORITHMIC bytes (44 B/ray + 80 B/node visit + 40 B/triangle
+                                test + 104 B/instance entry, visits counted by the kernel's counting variant on the same
+                                frames) are reported beside it: where the scene fits the caches they are served on-die
+                                and exceed the memory-side figure several times.
+                   valu-issue : VALU wave-instructions per launch (rays x the profiled instructions per ray) x 2 cycles
+                                (a wave64 VALU instruction on a SIMD-32 with several waves resident, MI355X_MICROARCH.md)
+                                / (1024 SIMDs x the clock the profile measured) / duration.
+                 `bound` names the ceiling with the larger fraction; `frac`, `achieved`, `peak`, `unit` belong to it.
+  cpu_baseline : the CPU oracle (port of the reference algorithm) on full frames of the same scene, timed on the
                  host cores of this box.  A reported baseline, not a target.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,58 +50,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from nexus_amd import capi, multigpu, pod, scenegen  # noqa: E402
+from nexus_amd import capi, multigpu, pod, workloads  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-TILE_ROWS = 5          # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
+SIMDS = 256 * 4         # 256 CUs x 4 SIMD-32
+VALU_ISSUE_CYCLES = 2   # wave64 VALU instruction, several waves resident (MI355X_MICROARCH.md, execution model)
+TILE_ROWS = 5           # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "trace_counters.json")
 
 
-def build_config2(width, height, nu, nv, path_length):
-    """configs[1]: seeded displaced torus (2*nu*nv triangles) resting on a 2-triangle floor under a 2-triangle emissive
-    quad; mesh = CONDUCTOR (ior (0.2,0.9,1.1), k (3.9,2.4,2.2), roughness 0.3), floor = DIFFUSE 0.7, light intensity 20."""
+def build_workload(args):
     t0 = time.time()
-    torus = scenegen.displaced_torus(nu, nv, seed=1, major=1.0, minor=0.45, amp=0.06, center=(0.0, 0.56, 0.0))
-    floor = scenegen.quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
-    light = scenegen.quad((-1.2, 4.0, -1.2), (1.2, 4.0, -1.2), (1.2, 4.0, 1.2), (-1.2, 4.0, 1.2))
-    t_gen = time.time() - t0
-    mats = np.array([
-        pod.make_material(pod.MAT_CONDUCTOR, roughness=0.3, conductor_ior=(0.2, 0.9, 1.1), conductor_k=(3.9, 2.4, 2.2)),
-        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.7, 0.7, 0.7)),
-        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 1.0, 1.0), intensity=20.0),
-    ], dtype=pod.MAT_DT)
-    t0 = time.time()
-    blas = []
-    for mesh in (torus, floor, light):
-        nodes, idx = capi.bvh8_build(mesh, threads=0)
-        blas.append((nodes, mesh, idx))
-    t_build = time.time() - t0
-    ident = np.eye(4, dtype=np.float32).reshape(16)
-    insts = np.array([capi.instance_init(i, i, ident, blas[i][0][0]) for i in range(3)], dtype=pod.INST_DT)
-    tlas_nodes, tlas_idx = capi.tlas_build(insts)
-    light_rec = np.zeros(1, dtype=pod.LIGHT_DT)
-    light_rec["meshId"] = 2
-    light_rec["type"] = pod.LIGHT_MESH
-    eye = np.array([0.0, 3.3, 4.9])
-    fwd = np.array([0.0, 0.35, 0.0]) - eye
-    fwd /= np.linalg.norm(fwd)
-    cam = capi.camera_init(eye, fwd, 52.0, width, height, 5.0, 0.0)
-    settings = np.zeros((), dtype=pod.SETTINGS_DT)
-    settings["useMIS"] = 1
-    settings["pathLength"] = path_length
-    settings["backgroundColor"] = (1, 1, 1)
-    settings["backgroundIntensity"] = 0.0
-    return dict(blas=blas, instances=insts, tlas_nodes=tlas_nodes, tlas_idx=tlas_idx, materials=mats, lights=light_rec, camera=cam,
-                settings=settings, triangles=int(len(torus) + 4), bvh8_nodes=int(len(blas[0][0])), t_gen=t_gen, t_build=t_build)
+    if args.config == 2:
+        sc = workloads.config2(args.width, args.height, args.nu, args.nv, args.path_length)
+        name = ("configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
+                % (sc.triangles, sc.bvh8_nodes, args.width, args.height, args.path_length))
+    elif args.config == 5:
+        sc = workloads.config5(args.width, args.height, args.path_length)
+        name = ("configs[4] on 1 GPU: displaced room shell + instanced props, %d triangles in the TLAS (%d unique, BVH8 %d nodes, %.0f MB of nodes + "
+                "intersection records: beyond the 256 MiB Infinity Cache), all four material types, textured emissive panels, %dx%d, pathLength %d"
+                % (sc.triangles, sc.unique_triangles, sc.bvh8_nodes, sc.scene_bytes() / 1e6, args.width, args.height, args.path_length))
+    else:
+        raise SystemExit("--config must be 2 or 5")
+    return sc, name, time.time() - t0
 
 
 def upload(ctx, sc):
-    for nodes, tris, idx in sc["blas"]:
-        ctx.upload_blas(nodes, tris, idx)
-    ctx.set_tlas(sc["tlas_nodes"], sc["tlas_idx"], sc["instances"])
-    ctx.set_materials(sc["materials"])
-    ctx.set_lights(sc["lights"])
-    ctx.set_camera(sc["camera"])
-    ctx.set_render_settings(sc["settings"])
+    sc.upload(ctx)
     ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
 
 
@@ -103,45 +91,56 @@ def trace_algorithmic_bytes(st):
     return 44 * st["rays"] + 80 * st["nodes"] + 40 * st["tris"] + 104 * st["instances"]
 
 
-def cpu_baseline(sc, width, height, threads):
+def cpu_baseline(sc, width, height, threads, frames, single_core=True):
     from tests import oracle_lib as O  # test infrastructure, used here only as the reported CPU baseline
 
-    scene = O.OracleScene(sc["blas"], sc["instances"], sc["tlas_nodes"], sc["tlas_idx"], sc["materials"], sc["lights"], sc["camera"], sc["settings"])
+    scene = O.OracleScene(sc.blas, sc.instances, sc.tlas_nodes, sc.tlas_idx, sc.materials, sc.lights, sc.camera, sc.settings,
+                          sc.diffuse_maps, sc.emissive_maps, sc.hdr_map)
     w = O.Wavefront(scene, width * height, None, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
-    frames = 4
     t0 = time.time()
     for f in range(1, frames + 1):
         w.render(f, threads=threads)
         w.accumulate(f)
     dt = time.time() - t0
-    # one more frame on a single thread: the 1-core figure SURVEY.md section 8d asks for beside the all-cores one
-    t0 = time.time()
-    w.render(frames + 1, threads=1)
-    dt1 = time.time() - t0
-    return dict(value=width * height * frames / dt / 1e6, unit="Msamples/s", cores=threads, kind="port",
-                sample="%d full frames (%dx%d, same scene/camera/settings, frames 1..%d); both trace passes on %d pthreads, logic/shade serial; %.1f s"
-                       % (frames, width, height, frames, threads, dt),
-                single_core_value=round(width * height / dt1 / 1e6, 4), single_core_sample="1 full frame on 1 thread; %.1f s" % dt1), w
+    out = dict(value=width * height * frames / dt / 1e6, unit="Msamples/s", cores=threads, kind="port",
+               sample="%d full frame%s (%dx%d, same scene/camera/settings, frames 1..%d); both trace passes on %d pthreads, logic/shade serial; %.1f s"
+                      % (frames, "s" if frames > 1 else "", width, height, frames, threads, dt))
+    if single_core:
+        # one more frame on a single thread: the 1-core figure SURVEY.md section 8d asks for beside the all-cores one
+        t0 = time.time()
+        w.render(frames + 1, threads=1)
+        dt1 = time.time() - t0
+        out.update(single_core_value=round(width * height / dt1 / 1e6, 4), single_core_sample="1 full frame on 1 thread; %.1f s" % dt1)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--path-length", type=int, default=8)
-    ap.add_argument("--nu", type=int, default=1024, help="torus grid: 2*nu*nv triangles")
+    ap.add_argument("--steps", type=int, default=None, help="frames timed per repetition (default 512; --config 5: 64)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default 64; --config 5: 16)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-frame timed region; the median is reported")
+    ap.add_argument("--config", type=int, default=2, help="2 = BASELINE.json configs[1] (the metric's workload); 5 = configs[4] on one GPU (HBM-resident scene)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--path-length", type=int, default=None)
+    ap.add_argument("--nu", type=int, default=1024, help="config 2 torus grid: 2*nu*nv triangles")
     ap.add_argument("--nv", type=int, default=512)
-    ap.add_argument("--frames-per-pass", type=int, default=64,
-                    help="frames batched into one wavefront pass on 1 GPU (N ranks: N times as many, at most 512, so that a rank's pass keeps "
-                         "its size); a step budget that is not a multiple ends with one shorter pass")
+    ap.add_argument("--frames-per-pass", type=int, default=None,
+                    help="frames batched into one wavefront pass on 1 GPU (default 64; --config 5: 16; N ranks: N times as many, at most 512, so that a "
+                         "rank's pass keeps its size); a step budget that is not a multiple ends with one shorter pass")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
     args = ap.parse_args()
+    big = args.config == 5
+    args.width = args.width or (3840 if big else 1920)
+    args.height = args.height or (2160 if big else 1080)
+    args.path_length = args.path_length or (16 if big else 8)
+    args.steps = args.steps if args.steps is not None else (64 if big else 512)
+    args.warmup = args.warmup if args.warmup is not None else (16 if big else 64)
+    args.frames_per_pass = args.frames_per_pass or (16 if big else 64)
 
     # stdout carries exactly one line, the JSON: libraries that print banners to stdout (RCCL does at init) are sent to stderr
     json_fd = os.dup(1)
@@ -166,15 +165,15 @@ def main():
         import torch.distributed  # noqa: F401
 
     W, H = args.width, args.height
-    if args.steps < 1 or args.warmup < 0:
-        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    if args.steps < 1 or args.warmup < 0 or args.reps < 1:
+        raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
     S = max(1, min(args.frames_per_pass * world, 512, args.steps))
 
     def schedule(frames):
         """pass sizes that render exactly `frames` frames"""
         return [S] * (frames // S) + ([frames % S] if frames % S else [])
 
-    sc = build_config2(W, H, args.nu, args.nv, args.path_length)
+    sc, workload_name, t_build = build_workload(args)
 
     dist = None
     torch = None
@@ -234,7 +233,7 @@ def main():
         def step(n):
             # every rank path-traces and accumulates its own tiles (the exact per-frame running mean of the 1-GPU path) ...
             if ctx.frames_per_pass != n:
-                ctx.set_frames_per_pass(n)
+                ctx.set_frames_per_pass(n)  # within the allocated capacity: no synchronisation, the size travels as a kernel argument
             ctx.render_frame()
             ctx.accumulate()
             # ... and the one collective of the path moves the accumulated tiles (16 B per pixel, once per pass) to rank 0
@@ -263,7 +262,7 @@ def main():
 
         def step(n):
             if ctx.frames_per_pass != n:
-                ctx.set_frames_per_pass(n)
+                ctx.set_frames_per_pass(n)  # within the allocated capacity: no synchronisation, the size travels as a kernel argument
             ctx.render_frame()
             ctx.accumulate()
 
@@ -274,15 +273,20 @@ def main():
     for n in schedule(args.warmup):
         step(n)
     sync()
-    t0 = time.perf_counter()
-    for n in schedule(args.steps):
-        step(n)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist_mode:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rep_s = []
+    for _ in range(args.reps):
+        sync()
+        t0 = time.perf_counter()
+        for n in schedule(args.steps):
+            step(n)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist_mode:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rep_s.append(elapsed)
+    elapsed = statistics.median(rep_s)
 
     value = W * H * args.steps / elapsed / 1e6
     out = {
@@ -299,12 +303,13 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
-                        % (sc["triangles"], sc["bvh8_nodes"], W, H, args.path_length),
+            "workload": workload_name,
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, per-rank accumulation, one RCCL gather of accumulated tiles per pass" % (world, TILE_ROWS),
             "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of up to %d frames" % S,
             "frames_per_pass": S, "pixel_order": args.pixel_order,
-            "host_bvh_build_s": round(sc["t_build"], 2),
+            "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
+            "rep_ms": [round(x * 1e3, 3) for x in rep_s],
+            "host_scene_build_s": round(t_build, 2),
         },
     }
 
@@ -325,38 +330,54 @@ def main():
         # (b) durations: hipEvent pair around every kernel of the production graph (event-record nodes inside the hipGraph, so
         # the closest-hit and shadow traces of a bounce overlap exactly as in the timed region).  The replays run back to back
         # like the timed region and the events of the LAST replay are read.  NB the closest-hit launch of a bounce shares the GPU
-        # with the shadow launch of the same bounce: its duration includes that time-sharing and is bimodal for bounce 1 (20 ms
-        # when its workgroups win the CUs first, 27 ms when the two kernels interleave evenly; the level takes 27 ms either way).
+        # with the shadow launch of the same bounce: its duration includes that time-sharing.
         ctx.enable_kernel_timing(True, in_graph=True, last_replay_only=True)
         ctx.read_kernel_times(reset=True)
-        for _ in range(passes):
+        for _ in range(max(passes, 3)):
             ctx.render_frame()
             ctx.accumulate()
         kt = ctx.read_kernel_times(reset=True)
         ctx.enable_kernel_timing(False)
-        launches = kt["trace"]["launches"]               # closest-hit launches of one replay (pathLength + 1)
-        avg_ms = kt["trace"]["ms"] / max(1, launches)
-        bytes_per_launch = trace_algorithmic_bytes(closest) / max(1, launches * passes)   # the counting run covered `passes` replays
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        frames_timed = {k: (S * passes if k == "accumulate" else S) for k in kt}           # accumulate is launched outside the graph
-        # HBM-side traffic per launch cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes
-        # over this same workload (profiles/r01_c_traffic.json), and is reported only when the workload matches
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            tw = tj.get("workload", {})
-            if (tw.get("width"), tw.get("height"), tw.get("nu"), tw.get("nv"), tw.get("path_length"), tw.get("frames_per_pass")) == \
-                    (W, H, args.nu, args.nv, args.path_length, S):
-                traffic = int(tj["kernels"]["trace_closest"]["hbm_bytes_per_launch"])
-                traffic_src = "profiles/r01_c_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of MI355X_MICROARCH.md)"
+        launches = max(1, kt["trace"]["launches"])        # closest-hit launches of one replay (pathLength + 1)
+        avg_ms = kt["trace"]["ms"] / launches
+        dur_s = max(avg_ms * 1e-3, 1e-12)
+        rays_per_launch = closest["rays"] / (launches * passes)                        # the counting run covered `passes` replays
+        alg_bytes_per_launch = trace_algorithmic_bytes(closest) / (launches * passes)
+        alg_gbs = alg_bytes_per_launch / dur_s / 1e9
+        frames_timed = {k: (S * max(passes, 3) if k == "accumulate" else S) for k in kt}  # accumulate is launched outside the graph
+        # Counter-side constants of this workload, per ray, from the committed rocprofv3 --pmc passes (profiles/README.md):
+        # HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE), VALU wave-instructions and the clock under the profiler.  Per ray they
+        # do not depend on the pass size (measured equal within 4 % at 1 and 20 frames per pass), so the driver's pass size
+        # gets the same figures as the profiled one.
+        ck = None
+        if os.path.exists(COUNTERS_JSON):
+            ck = json.load(open(COUNTERS_JSON)).get("config%d" % args.config, {}).get("trace_closest")
+        ceilings = {}
+        traffic = None
+        if ck:
+            traffic = int(rays_per_launch * (ck["hbm_read_bytes_per_ray"] + ck["hbm_write_bytes_per_ray"]))
+            hbm_gbs = traffic / dur_s / 1e9
+            ceilings["hbm"] = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                               "bytes_per_ray": round(ck["hbm_read_bytes_per_ray"] + ck["hbm_write_bytes_per_ray"], 1)}
+            clock = ck["clock_GHz"]
+            ginst = rays_per_launch * ck["valu_insts_per_ray"] / dur_s / 1e9
+            peak_ginst = SIMDS * clock / VALU_ISSUE_CYCLES
+            ceilings["valu-issue"] = {"achieved": round(ginst, 1), "peak": round(peak_ginst, 1), "unit": "G wave-instructions/s", "frac": round(ginst / peak_ginst, 4),
+                                      "valu_insts_per_ray": round(ck["valu_insts_per_ray"], 1), "cycles_per_instruction": VALU_ISSUE_CYCLES, "clock_GHz": clock}
+        bound = max(ceilings, key=lambda k: ceilings[k]["frac"]) if ceilings else "hbm"
+        top = ceilings.get(bound, {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
         out["roofline"] = {
-            "bound": "hbm", "kernel": "trace_kernel<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            # the rocprof-measured memory-side rate of the same kernel against the chip's peak (north_star's second figure)
-            "traffic_GBs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
-            "traffic_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
-            "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+            "bound": bound, "kernel": "trace_kernel<closest>", "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "traffic": traffic,
+            "traffic_source": ("rays per launch of this run x bytes per ray from %s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of "
+                               "MI355X_MICROARCH.md)" % os.path.relpath(COUNTERS_JSON, ROOT)) if ck else None,
+            "ceilings": ceilings,
+            # the algorithmic bytes of SURVEY.md section 8d: mostly served by L1 / L2 / Infinity Cache when the scene fits them
+            "algorithmic": {"bytes_per_launch": int(alg_bytes_per_launch), "GBs": round(alg_gbs, 1), "bytes_per_ray": round(alg_bytes_per_launch / max(1.0, rays_per_launch), 1),
+                            "vs_counter_bytes": round(alg_bytes_per_launch / traffic, 2) if traffic else None,
+                            "frac_of_l2_peak": round(alg_gbs / L2_PEAK_GBS, 4), "l2_peak_GBs": L2_PEAK_GBS,
+                            "caches": {k: ck[k] for k in ("l1_hit_rate", "l2_hit_rate") if k in ck} if ck else None},
+            "avg_launch_ms": round(avg_ms, 5), "launches": launches, "rays_per_launch": int(rays_per_launch),
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
             "simd": {"iters_per_ray_lane": round(64.0 * closest["waveIters"] / max(1, closest["rays"]), 2),
@@ -368,7 +389,7 @@ def main():
                      "cycles_per_wave_iter": round(sum(closest["cycles"]) / max(1, closest["waveIters"]), 1)},
             "mrays_per_s": round(closest["rays"] / passes / (kt["trace"]["ms"] * 1e-3) / 1e6, 1) if kt["trace"]["ms"] > 0 else None,
             "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
-                       "achieved_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"] * passes)) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
+                       "algorithmic_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"] * passes)) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
             "kernel_ms_per_frame": {k: round(v["ms"] / frames_timed[k], 4) for k, v in kt.items()},
             "live_rays_by_bounce": [int(x) for x in q["traceSize"][: args.path_length + 1]],
         }
@@ -376,7 +397,7 @@ def main():
     if rank == 0 and not dist_mode and not args.no_cpu_baseline:
         # a 1-GPU box's CPU share is 16 hardware threads
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-        cb, _ = cpu_baseline(sc, W, H, threads)
+        cb = cpu_baseline(sc, W, H, threads, 1 if big else 4, single_core=not big)
         cb["value"] = round(cb["value"], 4)
         out["cpu_baseline"] = cb
 

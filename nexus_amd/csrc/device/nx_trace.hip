@@ -218,6 +218,11 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // heads with returning atomics to find out that nothing is left, which made every launch cost about 0.5 ms however
     // few rays it carried.
     if (rankInShard * kWave >= homeRays) return;
+#ifdef NX_STAGGER
+    // experiment: desynchronise the waves of a launch (they all start in the same microsecond and would otherwise hit
+    // the memory pipeline and the issue slots in lockstep)
+    for (int k = rankInShard % NX_STAGGER; k > 0; k--) __builtin_amdgcn_s_sleep(32);
+#endif
     // Reservation size: kReserve rays, but no more than half a wave's even share of the queue, so that on a small queue
     // every wave draws a few times and the launch does not end with a handful of waves still holding full blocks
     // (one frame per pass: +14 %; 64 frames per pass: within noise).

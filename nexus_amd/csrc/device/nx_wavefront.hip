@@ -126,18 +126,22 @@ NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pathIdx, uin
 }
 
 // ------------------------------------------------------------------------------------------------------
-// begin frame: frameNumber++, zero every counter, traceSize[0] = localCount (GenerateKernel's thread 0 in
-// the reference, PathTracer.cu:112-113; the memset of PathTracer.cpp:263)
+// begin pass: the pass size (frames batched into this pass) arrives as a kernel argument and is published to the other
+// kernels through the device state, so a pass of a different size needs no host-side state upload or synchronisation;
+// frameNumber += frames, zero every counter, traceSize[0] = localCount * frames (GenerateKernel's thread 0 in the
+// reference, PathTracer.cu:112-113; the memset of PathTracer.cpp:263)
 
-__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(const DeviceState* __restrict__ S)
+__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __restrict__ S, const uint32_t frames)
 {
     int* c = reinterpret_cast<int*>(S->counters);
     constexpr int n = (int)(sizeof(Counters) / sizeof(int));
     for (int i = threadIdx.x; i < n; i += blockDim.x) c[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        S->counters->traceSize[0] = (int)S->pathCount;
-        S->frame->frameNumber += S->framesPerPass;
+        S->framesPerPass = frames;
+        S->pathCount = S->localCount * frames;
+        S->counters->traceSize[0] = (int)(S->localCount * frames);
+        S->frame->frameNumber += frames;
     }
 }
 
@@ -197,6 +201,9 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
 {
     Counters* C = S->counters;
     const int size = C->traceSize[bounce - 1];
+    // the grid is sized for the largest queue: a workgroup with no tile to process leaves before the allocator's
+    // barriers (late bounces carry a few thousand items; an all-empty launch used to cost 30 us)
+    if ((int)(blockIdx.x * blockDim.x) >= size) return;
     const uint32_t frame = S->frame->frameNumber;
     SlotAllocator<ORDERED, 4> slots;
     int* const ctr[4] = {&C->materialSize[0][bounce], &C->materialSize[1][bounce], &C->materialSize[2][bounce], &C->materialSize[3][bounce]};
@@ -336,6 +343,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
 {
     Counters* C = S->counters;
     const int size = C->materialSize[TYPE][bounce];
+    if ((int)(blockIdx.x * blockDim.x) >= size) return;  // no tile for this workgroup (see logic_kernel)
     const uint32_t frame = S->frame->frameNumber;
     const MaterialQueue mq = S->material[TYPE];
     SlotAllocator<ORDERED, 2> slots;  // 0: shadow requests, 1: continuation rays

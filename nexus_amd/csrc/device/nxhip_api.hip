@@ -710,6 +710,17 @@ Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceS
     return l;
 }
 
+// Every pass starts with begin_frame_kernel, launched outside the graph because its argument (the pass size) may change from
+// pass to pass.
+int launch_begin_frame(nxhip_ctx* c)
+{
+    DeviceState* S = c->dState.as<DeviceState>();
+    uint32_t frames = c->framesPerPass;
+    void* args[2] = {(void*)&S, (void*)&frames};
+    NX_HIP(hipLaunchKernel(begin_frame_kernel_ptr(), dim3(1), dim3(kWideBlockThreads), args, 0, c->stream));
+    return NXHIP_OK;
+}
+
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
 std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
@@ -720,7 +731,6 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
     const int wide = c->wideBlocks;
     const int wideThreads = kWideBlockThreads;
     std::vector<std::vector<Launch>> levels;
-    levels.push_back({make_launch(begin_frame_kernel_ptr(), 1, kWideBlockThreads, NXHIP_K_GENERATE, S)});
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
@@ -828,6 +838,8 @@ try {
     if (rc != NXHIP_OK) return rc;
     rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
+    rc = launch_begin_frame(c);
+    if (rc != NXHIP_OK) return rc;
     if (c->timingEnabled && c->timingMode == 1) {
         // eager path: one event pair per launch, launches strictly in level order on one stream
         auto levels = frame_levels(c);
@@ -894,14 +906,14 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
     NX_CHECK_CTX(c);
     if (frames == 0 || frames > 1024) return fail_invalid("nxhip_set_frames_per_pass: frames must be in [1, 1024]");
     if ((uint64_t)c->localCount * frames > 0x7fffffffull) return fail_invalid("nxhip_set_frames_per_pass: more than 2^31 paths");
-    NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
     const size_t n = (size_t)std::max<uint32_t>(c->localCount, 1u) * frames;
     if (c->radianceBoundCapacity != 0 && n > c->radianceBoundCapacity)
         return fail_invalid("nxhip_set_frames_per_pass: the bound radiance buffer is too small for this many frames; rebind first");
     if (n > c->pathCapacity) {
         // grow only: a later, smaller pass (e.g. the remainder of a frame budget) reuses the buffers.  The frame counter
         // and the accumulation are left alone: a pass size is a scheduling choice, not a new image.
+        NX_HIP(hipSetDevice(c->device));
+        NX_HIP(hipStreamSynchronize(c->stream));
         float4* const boundPtr = c->h.radiance;
         const size_t boundCap = c->radianceBoundCapacity;
         const int rc = alloc_queues(c, n);
@@ -911,11 +923,12 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
             c->radianceBoundCapacity = boundCap;
         }
     }
+    // Within the capacity nothing is uploaded and nothing waits: the next pass's begin_frame_kernel carries the size as a
+    // kernel argument and publishes it on the device, in stream order.
     c->framesPerPass = frames;
     c->pathCount = c->localCount * frames;
     c->h.framesPerPass = frames;
     c->h.pathCount = c->pathCount;
-    c->stateDirty = true;
     return NXHIP_OK;
 }
 

@@ -1,0 +1,197 @@
+"""Scene assembly and the BASELINE.json configurations as seeded procedural workloads.
+
+`Workload` builds BLAS / TLAS with the product's host builders (nexus_amd.capi) and uploads them to a device context;
+bench.py renders them, and the tests hand the very same bytes to their CPU checker (tests.scene_helpers.BuiltScene adds
+that side; nothing here depends on it)."""
+import numpy as np
+
+from . import capi, pod, scenegen
+
+IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
+
+
+def make_settings(use_mis=True, path_length=4, background=(1, 1, 1), background_intensity=0.0):
+    """RenderSettings defaults of the reference: Renderer/RenderSettings.h:4-10"""
+    s = np.zeros((), dtype=pod.SETTINGS_DT)
+    s["useMIS"] = 1 if use_mis else 0
+    s["pathLength"] = path_length
+    s["backgroundColor"] = background
+    s["backgroundIntensity"] = background_intensity
+    return s
+
+
+def mesh_lights(instances, materials):
+    """Scene::UpdateInstanceLighting (/root/reference/Nexus/src/Scene/Scene.cpp:142-176): an instance is a light iff its
+    material has an emissive map or intensity * max(emissive) > 0; meshId = index of the instance."""
+    out = []
+    for i, inst in enumerate(instances):
+        m = materials[inst["materialId"]]
+        if m["emissiveMapId"] != -1 or float(m["intensity"]) * float(np.max(m["emissive"])) > 0.0:
+            l = np.zeros((), dtype=pod.LIGHT_DT)
+            l["meshId"] = i
+            l["type"] = pod.LIGHT_MESH
+            out.append(l)
+    return np.array(out, dtype=pod.LIGHT_DT) if out else np.zeros(0, pod.LIGHT_DT)
+
+
+def checker_texture(w=64, h=32, seed=0, alpha=False):
+    rng = np.random.RandomState(seed)
+    img = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    chk = ((xx // 8 + yy // 8) % 2).astype(bool)
+    img[chk, :3] = img[chk, :3] // 3
+    img[..., 3] = rng.randint(128, 256, size=(h, w)) if alpha else 255
+    return img
+
+
+class Workload:
+    def __init__(self, meshes, placements, materials=None, lights=None, camera=None, settings=None, diffuse_maps=(), emissive_maps=(),
+                 hdr_map=None, build_threads=4):
+        """meshes: list of TRI_DT arrays; placements: list of (meshIdx, materialId, transform16); build_threads 0 = all cores."""
+        self.meshes = [np.ascontiguousarray(m, dtype=pod.TRI_DT) for m in meshes]
+        self.blas = []
+        for m in self.meshes:
+            nodes, idx = capi.bvh8_build(m, threads=build_threads)
+            self.blas.append((nodes, m, idx))
+        insts = []
+        for mesh_idx, mat_id, xf in placements:
+            insts.append(capi.instance_init(mesh_idx, mat_id, xf, self.blas[mesh_idx][0][0]))
+        self.instances = np.array(insts, dtype=pod.INST_DT)
+        self.tlas_nodes, self.tlas_idx = capi.tlas_build(self.instances)
+        self.materials = np.ascontiguousarray(materials if materials is not None else np.array([pod.make_material()], dtype=pod.MAT_DT), dtype=pod.MAT_DT)
+        self.lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, pod.LIGHT_DT), dtype=pod.LIGHT_DT)
+        self.camera = camera
+        self.settings = settings if settings is not None else make_settings()
+        self.diffuse_maps, self.emissive_maps, self.hdr_map = list(diffuse_maps), list(emissive_maps), hdr_map
+
+    @property
+    def triangles(self):
+        """triangles reachable through the TLAS (instanced meshes count once per instance)"""
+        return int(sum(len(self.meshes[int(i["bvhIdx"])]) for i in self.instances))
+
+    @property
+    def unique_triangles(self):
+        return int(sum(len(m) for m in self.meshes))
+
+    @property
+    def bvh8_nodes(self):
+        return int(sum(len(b[0]) for b in self.blas))
+
+    def scene_bytes(self):
+        """device bytes the trace kernels read from: 80-byte nodes + 48-byte intersection records + instance records"""
+        return int(sum(80 * len(b[0]) + 48 * len(b[1]) for b in self.blas) + 80 * len(self.tlas_nodes) + 80 * len(self.instances))
+
+    def upload(self, ctx):
+        ctx.clear_blas()
+        ctx.clear_textures()
+        for nodes, tris, idx in self.blas:
+            ctx.upload_blas(nodes, tris, idx)
+        ctx.set_tlas(self.tlas_nodes, self.tlas_idx, self.instances)
+        ctx.set_materials(self.materials)
+        ctx.set_lights(self.lights)
+        for img in self.diffuse_maps:
+            ctx.upload_texture("diffuse", img)
+        for img in self.emissive_maps:
+            ctx.upload_texture("emissive", img)
+        if self.hdr_map is not None:
+            ctx.upload_texture("hdr", self.hdr_map)
+        if self.camera is not None:
+            ctx.set_camera(self.camera)
+        ctx.set_render_settings(self.settings)
+
+
+def _look(eye, target, hfov, width, height):
+    eye = np.asarray(eye, dtype=np.float64)
+    fwd = np.asarray(target, dtype=np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    return capi.camera_init(eye, fwd, hfov, width, height, 5.0, 0.0)
+
+
+def config2(width=1920, height=1080, nu=1024, nv=512, path_length=8, cls=Workload):
+    """configs[1]: seeded displaced torus (2*nu*nv triangles) resting on a 2-triangle floor under a 2-triangle emissive
+    quad; mesh = CONDUCTOR (ior (0.2,0.9,1.1), k (3.9,2.4,2.2), roughness 0.3), floor = DIFFUSE 0.7, light intensity 20."""
+    torus = scenegen.displaced_torus(nu, nv, seed=1, major=1.0, minor=0.45, amp=0.06, center=(0.0, 0.56, 0.0))
+    floor = scenegen.quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+    light = scenegen.quad((-1.2, 4.0, -1.2), (1.2, 4.0, -1.2), (1.2, 4.0, 1.2), (-1.2, 4.0, 1.2))
+    mats = np.array([
+        pod.make_material(pod.MAT_CONDUCTOR, roughness=0.3, conductor_ior=(0.2, 0.9, 1.1), conductor_k=(3.9, 2.4, 2.2)),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.7, 0.7, 0.7)),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 1.0, 1.0), intensity=20.0),
+    ], dtype=pod.MAT_DT)
+    sc = cls([torus, floor, light], [(i, i, IDENTITY) for i in range(3)], materials=mats,
+             camera=_look((0.0, 3.3, 4.9), (0.0, 0.35, 0.0), 52.0, width, height),
+             settings=make_settings(use_mis=True, path_length=path_length, background=(1, 1, 1), background_intensity=0.0), build_threads=0)
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc
+
+
+def procedural_sky(width=2048, height=1024):
+    """Equirectangular RGBA8 sky: vertical gradient, a bright sun disc and seeded bands (config 4's environment)."""
+    v = np.linspace(0.0, 1.0, height, dtype=np.float32)[:, None]
+    u = np.linspace(0.0, 1.0, width, dtype=np.float32)[None, :]
+    top = np.array([0.25, 0.45, 0.9], np.float32)
+    hor = np.array([0.9, 0.85, 0.8], np.float32)
+    gnd = np.array([0.25, 0.22, 0.2], np.float32)
+    t = np.clip(v * 2.0, 0.0, 1.0)[..., None]
+    b = np.clip(v * 2.0 - 1.0, 0.0, 1.0)[..., None]
+    img = (top * (1 - t) + hor * t) * (1 - b) + gnd * b
+    img = np.broadcast_to(img, (height, width, 3)).copy()
+    sun = np.exp(-(((u - 0.3) * 2.0) ** 2 + ((v - 0.25) * 1.0) ** 2) * 400.0)[..., None]
+    img = np.clip(img + sun * np.array([1.0, 0.95, 0.8], np.float32), 0.0, 1.0)
+    img *= (0.9 + 0.1 * np.sin(u * 40.0))[..., None]
+    out = np.zeros((height, width, 4), np.uint8)
+    out[..., :3] = (img * 255.0 + 0.5).astype(np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+def config4(width=1920, height=1080, path_length=8, n_side=10, nu=250, nv=200, cls=Workload):
+    """configs[3]: one 2*nu*nv-triangle BLAS (seed 2) instanced n_side^3 times on a jittered lattice with random rotations
+    and scales (seed 3), DIELECTRIC roughness 0.2 ior 1.45, procedural 2048x1024 equirectangular environment.  The
+    reference adds the environment on a miss only (PathTracer.cu:152-164); no environment NEE."""
+    mesh = scenegen.displaced_torus(nu, nv, seed=2, major=0.5, minor=0.2, amp=0.03)
+    rng = np.random.RandomState(3)
+    placements = []
+    for ix in range(n_side):
+        for iy in range(n_side):
+            for iz in range(n_side):
+                pos = (np.array([ix, iy, iz], np.float64) - (n_side - 1) / 2.0) * 1.6 + rng.uniform(-0.3, 0.3, 3)
+                placements.append((0, 0, capi.mat4_from_trs(pos, rng.uniform(0, 360, 3), rng.uniform(0.6, 1.3, 3))))
+    mats = np.array([pod.make_material(pod.MAT_DIELECTRIC, albedo=(0.95, 0.97, 1.0), roughness=0.2, ior=1.45)], dtype=pod.MAT_DT)
+    ext = n_side * 1.6
+    return cls([mesh], placements, materials=mats, camera=_look((ext * 0.9, ext * 0.55, ext * 1.25), (0, 0, 0), 45.0, width, height),
+               settings=make_settings(use_mis=True, path_length=path_length, background=(1, 1, 1), background_intensity=1.0),
+               hdr_map=procedural_sky(), build_threads=0)
+
+
+def config5(width=3840, height=2160, path_length=16, field=2200, prop_nu=512, prop_nv=256, n_props=16, cls=Workload):
+    """configs[4]: ~10 M triangles — a 2*field^2-triangle displaced room shell (floor / back wall / ceiling from one
+    height-field BLAS, rotated) plus instanced props, all four material types, emissive-textured light panels,
+    3840x2160, pathLength 16.  About 0.6 GB of nodes + intersection records: larger than the 256 MiB Infinity Cache, so
+    this is the configuration whose traversal streams from HBM."""
+    shell = scenegen.height_field(field, seed=5, amp=0.08)
+    prop = scenegen.displaced_torus(prop_nu, prop_nv, seed=6, major=0.5, minor=0.2, amp=0.04)
+    panel = scenegen.quad((-0.8, 0, -0.8), (0.8, 0, -0.8), (0.8, 0, 0.8), (-0.8, 0, 0.8))
+    mats = np.array([
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.75, 0.72, 0.7), diffuse_map=0),
+        pod.make_material(pod.MAT_PLASTIC, albedo=(0.8, 0.3, 0.2), roughness=0.35, ior=1.5),
+        pod.make_material(pod.MAT_DIELECTRIC, albedo=(0.95, 0.97, 1.0), roughness=0.15, ior=1.45),
+        pod.make_material(pod.MAT_CONDUCTOR, roughness=0.25),
+        pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 0.92, 0.85), intensity=18.0, emissive_map=0),
+    ], dtype=pod.MAT_DT)
+    placements = [
+        (0, 0, capi.mat4_from_trs((0, 0, 0), (0, 0, 0), (6, 1, 6))),            # floor
+        (0, 0, capi.mat4_from_trs((0, 3, -6), (90, 0, 0), (6, 1, 3))),          # back wall
+        (0, 0, capi.mat4_from_trs((0, 6, 0), (180, 0, 0), (6, 1, 6))),          # ceiling
+    ]
+    rng = np.random.RandomState(7)
+    for k in range(n_props):
+        pos = (rng.uniform(-4.5, 4.5), rng.uniform(0.5, 2.5), rng.uniform(-4.5, 3.0))
+        placements.append((1, 1 + k % 3, capi.mat4_from_trs(pos, rng.uniform(0, 360, 3), rng.uniform(0.7, 1.4, 3))))
+    for x in (-3.0, 0.0, 3.0):
+        placements.append((2, 4, capi.mat4_from_trs((x, 5.6, -1.0), (180, 0, 0))))
+    sc = cls([shell, prop, panel], placements, materials=mats, camera=_look((0.0, 2.6, 9.5), (0.0, 1.8, 0.0), 55.0, width, height),
+             settings=make_settings(use_mis=True, path_length=path_length, background=(0.5, 0.6, 0.8), background_intensity=0.3),
+             diffuse_maps=[checker_texture(256, 256, 11)], emissive_maps=[checker_texture(64, 64, 12)], build_threads=0)
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc

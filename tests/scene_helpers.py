@@ -2,68 +2,21 @@
 the same bytes to both the oracle (tests.oracle_lib.OracleScene) and a device context."""
 import numpy as np
 
-from nexus_amd import capi, pod, scenegen
+from nexus_amd import capi, pod, scenegen, workloads
 from tests import oracle_lib as O
 
 
-class BuiltScene:
-    def __init__(self, meshes, placements, materials=None, lights=None, camera=None, settings=None, diffuse_maps=(), emissive_maps=(),
-                 hdr_map=None, build_threads=4):
-        """meshes: list of TRI_DT arrays; placements: list of (meshIdx, materialId, transform16); build_threads 0 = all cores."""
-        self.meshes = [np.ascontiguousarray(m, dtype=pod.TRI_DT) for m in meshes]
-        self.blas = []
-        for m in self.meshes:
-            nodes, idx = capi.bvh8_build(m, threads=build_threads)
-            self.blas.append((nodes, m, idx))
-        insts = []
-        for mesh_idx, mat_id, xf in placements:
-            insts.append(capi.instance_init(mesh_idx, mat_id, xf, self.blas[mesh_idx][0][0]))
-        self.instances = np.array(insts, dtype=pod.INST_DT)
-        self.tlas_nodes, self.tlas_idx = capi.tlas_build(self.instances)
-        self.materials = np.ascontiguousarray(materials if materials is not None else np.array([pod.make_material()], dtype=pod.MAT_DT), dtype=pod.MAT_DT)
-        self.lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, pod.LIGHT_DT), dtype=pod.LIGHT_DT)
-        self.camera = camera
-        self.settings = settings if settings is not None else O.make_settings()
-        self.diffuse_maps, self.emissive_maps, self.hdr_map = list(diffuse_maps), list(emissive_maps), hdr_map
+class BuiltScene(workloads.Workload):
+    """A product workload plus the oracle's view of the very same bytes."""
 
     def oracle(self):
         return O.OracleScene(self.blas, self.instances, self.tlas_nodes, self.tlas_idx, self.materials, self.lights, self.camera, self.settings,
                              self.diffuse_maps, self.emissive_maps, self.hdr_map)
 
-    def upload(self, ctx):
-        ctx.clear_blas()
-        ctx.clear_textures()
-        for nodes, tris, idx in self.blas:
-            ctx.upload_blas(nodes, tris, idx)
-        ctx.set_tlas(self.tlas_nodes, self.tlas_idx, self.instances)
-        ctx.set_materials(self.materials)
-        ctx.set_lights(self.lights)
-        for img in self.diffuse_maps:
-            ctx.upload_texture("diffuse", img)
-        for img in self.emissive_maps:
-            ctx.upload_texture("emissive", img)
-        if self.hdr_map is not None:
-            ctx.upload_texture("hdr", self.hdr_map)
-        if self.camera is not None:
-            ctx.set_camera(self.camera)
-        ctx.set_render_settings(self.settings)
 
-
-def mesh_lights(instances, materials):
-    """Scene::UpdateInstanceLighting (/root/reference/Nexus/src/Scene/Scene.cpp:142-176): an instance is a light iff its
-    material has an emissive map or intensity * max(emissive) > 0; meshId = index of the instance."""
-    out = []
-    for i, inst in enumerate(instances):
-        m = materials[inst["materialId"]]
-        if m["emissiveMapId"] != -1 or float(m["intensity"]) * float(np.max(m["emissive"])) > 0.0:
-            l = np.zeros((), dtype=pod.LIGHT_DT)
-            l["meshId"] = i
-            l["type"] = pod.LIGHT_MESH
-            out.append(l)
-    return np.array(out, dtype=pod.LIGHT_DT) if out else np.zeros(0, pod.LIGHT_DT)
-
-
-IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
+mesh_lights = workloads.mesh_lights
+checker_texture = workloads.checker_texture
+IDENTITY = workloads.IDENTITY
 
 
 def soup_scene(n=3000, seed=1):
@@ -111,16 +64,6 @@ def cornell_scene(width=512, height=512, path_length=4, force_diffuse=True, use_
     sc = BuiltScene(ls.meshes, placements, materials=mats, camera=cam, settings=settings)
     sc.lights = mesh_lights(sc.instances, sc.materials)
     return sc
-
-
-def checker_texture(w=64, h=32, seed=0, alpha=False):
-    rng = np.random.RandomState(seed)
-    img = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
-    yy, xx = np.mgrid[0:h, 0:w]
-    chk = ((xx // 8 + yy // 8) % 2).astype(bool)
-    img[chk, :3] = img[chk, :3] // 3
-    img[..., 3] = rng.randint(128, 256, size=(h, w)) if alpha else 255
-    return img
 
 
 def material_zoo_scene(width=96, height=64, path_length=5, hdr=True, textures=True):

@@ -7,7 +7,7 @@ import bench
 from nexus_amd import capi, scenegen
 
 W, H = 1920, 1080
-sc = bench.build_config2(W, H, 1024, 512, 8)
+sc = bench.workloads.config2(W, H, 1024, 512, 8)
 ctx = capi.Context(W, H, device=0)
 bench.upload(ctx, sc)
 rays_all = scenegen.interior_rays(1 << 21, seed=5, extent=1.6)

@@ -1,4 +1,5 @@
-"""Experiment: do two independent passes in flight (two contexts, two streams) overlap usefully on one GPU?"""
+"""Experiment: aggregate Msamples/s of K independent contexts (own queues, own stream each) that render small passes
+concurrently on one GPU: does the drain phase of one pass overlap with the bulk of another?"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,18 +33,14 @@ def run(ctxs, passes, S):
         c.sync()
     dt = time.perf_counter() - t0
     frames = passes * len(ctxs) * S
-    return W * H * frames / dt / 1e6, dt / frames * 1e3
+    return round(W * H * frames / dt / 1e6, 1), round(dt / frames * 1e3, 3)
 
 
-for S in (32, 16):
-    for blocks in ("", "4", "3"):
-        if blocks:
-            os.environ["NX_TRACE_BLOCKS_PER_CU"] = blocks
-        else:
-            os.environ.pop("NX_TRACE_BLOCKS_PER_CU", None)
-        one = [make(S)]
-        print("S", S, "blocks", blocks or "auto", "one ctx  ", run(one, 4, S), flush=True)
-        two = one + [make(S)]
-        print("S", S, "blocks", blocks or "auto", "two ctxs ", run(two, 2, S), flush=True)
-        for c in two:
-            c.close()
+for S, passes in ((1, 16), (5, 8)):
+    ctxs = []
+    for K in (4, 6, 8):
+        while len(ctxs) < K:
+            ctxs.append(make(S))
+        print("S", S, "contexts", K, run(ctxs, passes, S), flush=True)
+    for c in ctxs:
+        c.close()

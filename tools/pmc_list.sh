@@ -2,7 +2,7 @@
 # rocprofv3 --pmc passes from a list file (one pass per line); usage: tools/pmc_list.sh <outdir> <listfile> [bench args]
 out=$1; list=$2; shift; shift
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp && export TMPDIR=/tmp && cd "$root"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
