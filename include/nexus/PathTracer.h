@@ -30,6 +30,14 @@ public:
     const std::vector<uint32_t>& GetPixelBuffer();
     // Extensions (see nexus_pod.h)
     void SetModes(int rngMode, int compactMode, int conductorMode);
+    // Multi-GPU extension (no counterpart in the reference): one PathTracer per GPU, each renders and
+    // accumulates the interleaved row tiles of its rank; Render() then ends with ONE RCCL gather of the accumulated tiles to
+    // rank 0, whose GetPixelBuffer() returns the full frame.  `id128`: the 128 bytes rank 0 obtained from
+    // CreateTileSplitId() and handed to every rank.  Call after construction / OnResize, before the first Render.
+    static void CreateTileSplitId(void* id128);
+    void EnableTileSplit(int worldSize, int rank, const void* id128, uint32_t tileRows = 5);
+    void DisableTileSplit();
+    bool IsTileSplitRoot() const { return m_TileSplit && m_Rank == 0; }
     nxhip_ctx* GetDeviceContext() const { return m_Ctx; }
     uint32_t GetWidth() const { return m_ViewportWidth; }
     uint32_t GetHeight() const { return m_ViewportHeight; }
@@ -40,6 +48,8 @@ private:
     uint32_t m_ViewportWidth = 0, m_ViewportHeight = 0;
     std::vector<uint32_t> m_Pixels;
     bool m_PixelQueryPending = false;
+    bool m_TileSplit = false;
+    int m_Rank = 0;
 };
 
 }  // namespace nexus

@@ -131,6 +131,30 @@ int nxhip_compose_tiles(nxhip_ctx *ctx, const void *srcAccumulationDevice, uint3
 int nxhip_read_full_accumulation(nxhip_ctx *ctx, float *dst);
 int nxhip_read_full_rgba8(nxhip_ctx *ctx, uint32_t *dst);
 
+/* ---- multi-GPU: interleaved row tiles + one RCCL gather per pass ---------------------------------------
+ * No counterpart in the reference (single GPU; SURVEY.md section 8e defines the layer).  One context per GPU — one process
+ * or one host thread each.  RCCL (librccl.so.1, or $NX_RCCL_LIB) is loaded on first use.  Call sequence per rank:
+ *   rank 0: nxhip_mgpu_unique_id(id) -> hand the 128 bytes to every rank (MPI, a file, a socket: the caller's choice)
+ *   all   : nxhip_mgpu_init(ctx, world, rank, id, tileRows)   [ncclCommInitRank; installs the rank's pixel map]
+ *   loop  : nxhip_render_frame, nxhip_accumulate, nxhip_mgpu_gather   [asynchronous, one stream]
+ *   rank 0: nxhip_mgpu_read_rgba8 / nxhip_mgpu_read_accumulation      [full width x height image]
+ * With the pixel-keyed RNG (nxhip_set_modes) the assembled image equals the single-GPU image bit for bit. */
+/* Row r belongs to rank (r / tileRows) % worldSize; height must be a multiple of tileRows * worldSize.  Writes the global
+ * pixel index of every local pixel in the context's path order (tiledOrder != 0: 8x8 pixel tiles; 0: rows);
+ * out == NULL: only *localCount. */
+int nxhip_tile_pixel_map(uint32_t width, uint32_t height, int worldSize, int rank, uint32_t tileRows, int tiledOrder, uint32_t *out,
+                         uint32_t *localCount);
+int nxhip_mgpu_unique_id(void *id128);
+int nxhip_mgpu_init(nxhip_ctx *ctx, int worldSize, int rank, const void *id128, uint32_t tileRows);
+/* The same with a communicator the caller already owns (an ncclComm_t passed as void*; it is not destroyed). */
+int nxhip_mgpu_attach(nxhip_ctx *ctx, void *ncclComm, int worldSize, int rank, uint32_t tileRows);
+/* ncclGather of every rank's accumulated tile (16 B per local pixel) to rank 0 on the context's stream; rank 0 then
+ * scatters the tiles into the full image and tonemaps (a copy: no arithmetic on the accumulated values). */
+int nxhip_mgpu_gather(nxhip_ctx *ctx);
+int nxhip_mgpu_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);        /* rank 0: width*height uint32 */
+int nxhip_mgpu_read_accumulation(nxhip_ctx *ctx, float *dst);    /* rank 0: width*height x 3 floats */
+int nxhip_mgpu_shutdown(nxhip_ctx *ctx);
+
 /* D_QueueSize after the last rendered frame — Cuda/PathTracer/PathTracer.cuh:61-73.  Each array NX_PATH_MAX_LENGTH ints. */
 typedef struct nxhip_queue_sizes {
     int32_t traceSize[NX_PATH_MAX_LENGTH];

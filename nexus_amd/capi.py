@@ -25,6 +25,8 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
+    "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
+    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
 ]
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
@@ -127,6 +129,14 @@ def lib():
     L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
     L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.nxhip_read_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.c_int]
+    L.nxhip_tile_pixel_map.argtypes = [u32, u32, C.c_int, C.c_int, u32, C.c_int, vp, C.POINTER(u32)]
+    L.nxhip_mgpu_unique_id.argtypes = [vp]
+    L.nxhip_mgpu_init.argtypes = [vp, C.c_int, C.c_int, vp, u32]
+    L.nxhip_mgpu_attach.argtypes = [vp, vp, C.c_int, C.c_int, u32]
+    L.nxhip_mgpu_gather.argtypes = [vp]
+    L.nxhip_mgpu_read_rgba8.argtypes = [vp, vp]
+    L.nxhip_mgpu_read_accumulation.argtypes = [vp, vp]
+    L.nxhip_mgpu_shutdown.argtypes = [vp]
     # host builders
     L.nxh_bvh8_build.argtypes = [vp, u32, u32, C.POINTER(vp)]
     L.nxh_tlas_build.argtypes = [vp, u32, C.POINTER(vp)]
@@ -412,6 +422,31 @@ class Context:
             check(self.L.nxhip_set_pixel_map(self.h, _ptr(pm), len(pm)), "nxhip_set_pixel_map")
             self.local_count = len(pm)
 
+    # ---- native multi-GPU tile split (RCCL inside the library; bench.py's N > 1 path uses torch.distributed instead)
+    def mgpu_init(self, world, rank, unique_id, tile_rows):
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        assert len(uid) == 128
+        check(self.L.nxhip_mgpu_init(self.h, world, rank, _ptr(uid), tile_rows), "nxhip_mgpu_init")
+        n = C.c_uint32(0)
+        check(self.L.nxhip_tile_pixel_map(self.width, self.height, world, rank, tile_rows, 1, None, C.byref(n)), "nxhip_tile_pixel_map")
+        self.local_count = int(n.value)
+
+    def mgpu_gather(self):
+        check(self.L.nxhip_mgpu_gather(self.h), "nxhip_mgpu_gather")
+
+    def mgpu_read_rgba8(self):
+        out = np.zeros(self.width * self.height, dtype=np.uint32)
+        check(self.L.nxhip_mgpu_read_rgba8(self.h, _ptr(out)), "nxhip_mgpu_read_rgba8")
+        return out
+
+    def mgpu_read_accumulation(self):
+        out = np.zeros((self.width * self.height, 3), dtype=np.float32)
+        check(self.L.nxhip_mgpu_read_accumulation(self.h, _ptr(out)), "nxhip_mgpu_read_accumulation")
+        return out
+
+    def mgpu_shutdown(self):
+        check(self.L.nxhip_mgpu_shutdown(self.h), "nxhip_mgpu_shutdown")
+
     def resize(self, width, height):
         check(self.L.nxhip_resize(self.h, width, height), "nxhip_resize")
         self.width, self.height = int(width), int(height)
@@ -555,6 +590,21 @@ class Context:
         t = KernelTimes()
         check(self.L.nxhip_read_kernel_times(self.h, C.byref(t), 1 if reset else 0), "nxhip_read_kernel_times")
         return {k: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, k in enumerate(KERNEL_CLASSES)}
+
+
+def tile_pixel_map(width, height, world, rank, tile_rows, tiled=True):
+    """the library's own tile split (nxhip_tile_pixel_map); no GPU needed"""
+    n = C.c_uint32(0)
+    check(lib().nxhip_tile_pixel_map(width, height, world, rank, tile_rows, 1 if tiled else 0, None, C.byref(n)), "nxhip_tile_pixel_map")
+    out = np.zeros(n.value, dtype=np.uint32)
+    check(lib().nxhip_tile_pixel_map(width, height, world, rank, tile_rows, 1 if tiled else 0, _ptr(out), C.byref(n)), "nxhip_tile_pixel_map")
+    return out
+
+
+def mgpu_unique_id():
+    uid = np.zeros(128, dtype=np.uint8)
+    check(lib().nxhip_mgpu_unique_id(_ptr(uid)), "nxhip_mgpu_unique_id")
+    return uid.tobytes()
 
 
 def device_count():

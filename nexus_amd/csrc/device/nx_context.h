@@ -111,6 +111,13 @@ struct nxhip_ctx {
     hipGraphExec_t graphExec = nullptr;
     bool graphValid = false;
 
+    // multi-GPU tile split (nxhip_multigpu.hip): RCCL communicator (opaque), root-side gather / full-image buffers
+    void* mgpuComm = nullptr;
+    bool mgpuOwnsComm = false;
+    int mgpuWorld = 1, mgpuRank = 0;
+    uint32_t mgpuTileRows = 0;
+    nxd::DevBuf mgpuGathered, mgpuMaps, mgpuFullAccum, mgpuFullRgba8;
+
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;
     int shadeBlocksPerCU = 4, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
 };

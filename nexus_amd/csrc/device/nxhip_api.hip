@@ -292,6 +292,7 @@ void nxhip_destroy(nxhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)nxhip_mgpu_shutdown(c);
     invalidate_graph(c);
     for (auto& t : c->timerPool) {
         if (t.start) (void)hipEventDestroy(t.start);

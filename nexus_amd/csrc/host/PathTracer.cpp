@@ -97,6 +97,27 @@ void PathTracer::Render(const Scene&)
     m_FrameNumber++;
     Check(nxhip_render_frame(m_Ctx), "nxhip_render_frame");
     Check(nxhip_accumulate(m_Ctx), "nxhip_accumulate");
+    if (m_TileSplit) Check(nxhip_mgpu_gather(m_Ctx), "nxhip_mgpu_gather");
+}
+
+void PathTracer::CreateTileSplitId(void* id128) { Check(nxhip_mgpu_unique_id(id128), "nxhip_mgpu_unique_id"); }
+
+void PathTracer::EnableTileSplit(int worldSize, int rank, const void* id128, uint32_t tileRows)
+{
+    Check(nxhip_mgpu_init(m_Ctx, worldSize, rank, id128, tileRows), "nxhip_mgpu_init");
+    m_TileSplit = true;
+    m_Rank = rank;
+    m_FrameNumber = 0;
+}
+
+void PathTracer::DisableTileSplit()
+{
+    if (!m_TileSplit) return;
+    Check(nxhip_mgpu_shutdown(m_Ctx), "nxhip_mgpu_shutdown");
+    Check(nxhip_set_pixel_map(m_Ctx, nullptr, 0), "nxhip_set_pixel_map");
+    m_TileSplit = false;
+    m_Rank = 0;
+    m_FrameNumber = 0;
 }
 
 void PathTracer::SetPixelQuery(uint32_t x, uint32_t y)
@@ -116,7 +137,8 @@ int32_t PathTracer::GetSelectedInstance()
 const std::vector<uint32_t>& PathTracer::GetPixelBuffer()
 {
     m_Pixels.resize(static_cast<size_t>(m_ViewportWidth) * m_ViewportHeight);
-    Check(nxhip_read_rgba8(m_Ctx, m_Pixels.data()), "nxhip_read_rgba8");
+    if (m_TileSplit) Check(nxhip_mgpu_read_rgba8(m_Ctx, m_Pixels.data()), "nxhip_mgpu_read_rgba8");  // rank 0: the assembled frame
+    else Check(nxhip_read_rgba8(m_Ctx, m_Pixels.data()), "nxhip_read_rgba8");
     return m_Pixels;
 }
 
