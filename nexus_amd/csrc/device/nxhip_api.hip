@@ -88,6 +88,9 @@ static int fail_invalid(const char* msg)
 
 static void invalidate_graph(nxhip_ctx* c)
 {
+    // a replay may still be executing (render calls are asynchronous): destroying its exec, graph and timing events
+    // under it is not allowed.  Not a hot path: settings / mode / timing changes only.
+    if (c->graphExec && c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     c->graphExec = nullptr;
@@ -111,25 +114,24 @@ static int upload_state(nxhip_ctx* c)
     return NXHIP_OK;
 }
 
-// Queue / path-state buffers for n paths (contents undefined), and the device-state pointers to them.
+// Queue / path-state buffers for n paths (contents undefined), and the device-state pointers to them.  All or nothing:
+// the new set is allocated beside the old one and swapped in only when every allocation has succeeded, so a failed
+// growth (out of device memory half-way through 25 buffers) leaves the context exactly as it was, still able to render
+// at its previous capacity.
 static int alloc_queues(nxhip_ctx* c, size_t n)
 {
-    NX_ALLOC(c->throughputPdf, n * 16);
-    NX_ALLOC(c->radiance, n * 16);
-    NX_ALLOC(c->rayOrigin, n * 16);
-    NX_ALLOC(c->trRayO, n * 16);
-    NX_ALLOC(c->trRayD, n * 16);
-    NX_ALLOC(c->trHit, n * 16);
-    NX_ALLOC(c->trHitInst, n * 4);
-    NX_ALLOC(c->shRayO, n * 16);
-    NX_ALLOC(c->shRayD, n * 16);
-    NX_ALLOC(c->shRadiance, n * 16);
-    for (int m = 0; m < 4; m++) {
-        NX_ALLOC(c->mqHit[m], n * 16);
-        NX_ALLOC(c->mqDirInst[m], n * 16);
-        NX_ALLOC(c->mqPixel[m], n * 4);
-    }
-    NX_HIP(hipMemsetAsync(c->radiance.p, 0, n * 16, c->stream));
+    DevBuf* const slots[] = {&c->throughputPdf, &c->radiance, &c->rayOrigin, &c->trRayO, &c->trRayD, &c->trHit, &c->trHitInst, &c->shRayO, &c->shRayD, &c->shRadiance,
+                             &c->mqHit[0], &c->mqDirInst[0], &c->mqPixel[0], &c->mqHit[1], &c->mqDirInst[1], &c->mqPixel[1],
+                             &c->mqHit[2], &c->mqDirInst[2], &c->mqPixel[2], &c->mqHit[3], &c->mqDirInst[3], &c->mqPixel[3]};
+    const size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 4, 16, 16, 4, 16, 16, 4, 16, 16, 4};
+    constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
+    static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
+    DevBuf fresh[kCount];
+    for (int i = 0; i < kCount; i++)
+        if (!fresh[i].alloc(n * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    NX_HIP(hipMemsetAsync(fresh[1].p, 0, n * 16, c->stream));     // radiance
+    NX_HIP(hipStreamSynchronize(c->stream));                      // nothing in flight may still use the old buffers
+    for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
     c->pathCapacity = n;
     c->radianceBoundCapacity = 0;
     DeviceState& h = c->h;
@@ -149,10 +151,12 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
     const size_t n = (size_t)std::max<uint32_t>(localCount, 1u) * c->framesPerPass;
     const size_t full = std::max<size_t>((size_t)c->width * c->height, localCount);
     if (n > 0x7fffffffull) return fail_invalid("more than 2^31 paths (pixels x frames per pass): lower nxhip_set_frames_per_pass first");
+    DevBuf freshAccum, freshRgba;  // all or nothing, as alloc_queues
+    if (!freshAccum.alloc(full * 16) || !freshRgba.alloc(full * 4)) return NXHIP_ERR_HIP;
     const int rc = alloc_queues(c, n);
     if (rc != NXHIP_OK) return rc;
-    NX_ALLOC(c->accumulation, full * 16);
-    NX_ALLOC(c->rgba8, full * 4);
+    c->accumulation = std::move(freshAccum);
+    c->rgba8 = std::move(freshRgba);
     NX_HIP(hipMemsetAsync(c->accumulation.p, 0, full * 16, c->stream));
     NX_HIP(hipMemsetAsync(c->rgba8.p, 0, full * 4, c->stream));
     c->localCount = localCount;
@@ -628,21 +632,26 @@ int nxhip_set_pixel_map(nxhip_ctx* c, const uint32_t* pixelMap, uint32_t localCo
     NX_HIP(hipSetDevice(c->device));
     NX_HIP(hipStreamSynchronize(c->stream));
     const uint32_t full = c->width * c->height;
+    // the queues are re-allocated first (all or nothing): a failure leaves the previous pixel set, map and queues in place
     if (!pixelMap) {
-        c->pixelMap.release();
-        c->h.pixelMap = nullptr;
         const int rc = alloc_paths(c, full);
         if (rc != NXHIP_OK) return rc;
+        c->pixelMap.release();
+        c->h.pixelMap = nullptr;
+        c->stateDirty = true;
         return set_frame_number_device(c, 0);
     }
     if (localCount == 0 || localCount > full) return fail_invalid("nxhip_set_pixel_map: localCount out of range");
     for (uint32_t i = 0; i < localCount; i++)
         if (pixelMap[i] >= full) return fail_invalid("nxhip_set_pixel_map: pixel index out of range");
-    NX_ALLOC(c->pixelMap, (size_t)localCount * 4);
-    NX_HIP(hipMemcpy(c->pixelMap.p, pixelMap, (size_t)localCount * 4, hipMemcpyHostToDevice));
-    c->h.pixelMap = c->pixelMap.as<uint32_t>();
+    DevBuf freshMap;
+    NX_ALLOC(freshMap, (size_t)localCount * 4);
+    NX_HIP(hipMemcpy(freshMap.p, pixelMap, (size_t)localCount * 4, hipMemcpyHostToDevice));
     const int rc = alloc_paths(c, localCount);
     if (rc != NXHIP_OK) return rc;
+    c->pixelMap = std::move(freshMap);
+    c->h.pixelMap = c->pixelMap.as<uint32_t>();
+    c->stateDirty = true;
     return set_frame_number_device(c, 0);
 }
 
@@ -1194,10 +1203,10 @@ try {
         NX_HIP(hipMemcpyAsync(c->shRayO.p, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         NX_HIP(hipMemcpyAsync(c->shRayD.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         NX_HIP(hipMemcpyAsync(c->shRadiance.p, rad.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        NX_HIP(hipMemsetAsync(c->radiance.p, 0, (size_t)n * 16, c->stream));
+        NX_HIP(hipMemsetAsync(c->h.radiance, 0, (size_t)n * 16, c->stream));  // the buffer the kernel adds into (own or bound)
         rc = run_trace_chunk(c, true, n);
         if (rc != NXHIP_OK) return rc;
-        NX_HIP(hipMemcpyAsync(res.data(), c->radiance.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        NX_HIP(hipMemcpyAsync(res.data(), c->h.radiance, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
         NX_HIP(hipStreamSynchronize(c->stream));
         for (uint32_t i = 0; i < n; i++) occluded[first + i] = res[i].x == 1.0f ? 0 : 1;
     }

@@ -148,3 +148,28 @@ def test_contexts_release_their_device_memory():
     after = free_bytes()
     # one context of this size holds about 60 MB: leaking it would cost 1.4 GB over these cycles; the runtime's pools wobble by a few MB
     assert before - after < 64 << 20, (before, after)
+
+
+def test_a_failed_queue_growth_leaves_the_context_usable(gpu_ctx_factory):
+    """Out of device memory half-way through the queue buffers (1 M pixels x 1024 frames per pass is about 350 GB of queues):
+    the call fails, nothing is left dangling, and the context keeps rendering at its previous pass size."""
+    import numpy as np
+    from nexus_amd import pod
+    from tests import scene_helpers as SH
+
+    W = H = 1024
+    scene = SH.cornell_scene(W, H, path_length=2)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    ctx.render_frame()
+    ctx.accumulate()
+    before = ctx.read_accumulation()
+    with pytest.raises(capi.NexusError):
+        ctx.set_frames_per_pass(1024)
+    assert ctx.frames_per_pass == 1
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    ctx.accumulate()
+    after = ctx.read_accumulation()
+    assert np.array_equal(before.view(np.uint32), after.view(np.uint32))

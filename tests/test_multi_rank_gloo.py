@@ -3,7 +3,10 @@ import os
 import subprocess
 import sys
 
+import socket
+
 import numpy as np
+import pytest
 
 from nexus_amd import multigpu, pod
 from tests import oracle_lib as O
@@ -23,10 +26,16 @@ def test_tile_maps_partition_the_image():
         assert np.array_equal(multigpu.reassemble(W, H, G, t, tiles)[:, 0], np.arange(W * H, dtype=np.float32))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_two_rank_gloo_gather_equals_single_rank(tmp_path):
     out = str(tmp_path / "acc.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
            os.path.join(ROOT, "tests", "_gloo_worker.py"), out]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -42,3 +51,21 @@ def test_two_rank_gloo_gather_equals_single_rank(tmp_path):
     assert got.shape[0] == 2
     assert np.array_equal(got[0].view(np.uint32), acc.view(np.uint32)), "radiance gather + root accumulate"
     assert np.array_equal(got[1].view(np.uint32), acc.view(np.uint32)), "per-rank accumulation + tile gather"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
+    """bench.py's own N > 1 code path (zero-copy torch view of the accumulation, per-pass gather, compose on the root,
+    pass-size changes across ranks) as fresh child processes: 2 ranks sharing the one GPU of the box over gloo.  The PNG
+    must equal the 1-rank PNG byte for byte (pixel-keyed RNG)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NX_BENCH_BACKEND="gloo", NX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "5", "--warmup", "2", "--reps", "1", "--frames-per-pass", "2", "--width", "256", "--height", "160",
+              "--no-cpu-baseline", "--no-roofline"]
+    one, two = str(tmp_path / "one.png"), str(tmp_path / "two.png")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--png", one], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common + ["--png", two]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert open(one, "rb").read() == open(two, "rb").read()
