@@ -29,7 +29,7 @@ $(OBJDIR)/%.o: %.cpp $(HDRS)
 
 $(OUT): $(DEV_OBJS) $(HOST_OBJS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(LDEXTRA) -o $@ $^ -lpthread
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(LDEXTRA) -o $@ $^ -lpthread -lz
 
 oracle:
 	$(MAKE) -C oracle liboracle.so

@@ -26,6 +26,12 @@ struct LoadedScene {
     std::vector<std::string> meshNames;
     std::vector<Material> materials;
     std::vector<LoadedInstance> instances;
+    // Images the materials refer to, decoded to RGBA8 (glTF baseColorTexture -> DIFFUSE, emissiveTexture -> EMISSIVE, as
+    // Assimp presents them to OBJLoader.cpp:115-160), and per material the index into `textures` (-1: none).  The
+    // materials' diffuseMapId / emissiveMapId stay -1 here: ids are handed out by the AssetManager in LoadOBJ.
+    std::vector<Texture> textures;
+    std::vector<int> materialDiffuseTexture, materialEmissiveTexture;
+    std::vector<std::string> warnings;  // images that could not be decoded (the reference prints and carries on, IMGLoader.cpp:24-25)
 };
 
 class OBJLoader {

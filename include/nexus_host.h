@@ -68,6 +68,19 @@ uint32_t nxh_loaded_material_count(const nxh_loaded_scene *s);
 int nxh_loaded_materials(const nxh_loaded_scene *s, nx_material *dst);
 uint32_t nxh_loaded_instance_count(const nxh_loaded_scene *s);
 int nxh_loaded_instances(const nxh_loaded_scene *s, nx_loaded_instance *dst);
+/* Images the file's materials refer to (glTF baseColorTexture -> kind 0 diffuse, emissiveTexture -> kind 1 emissive; what
+ * OBJLoader.cpp:115-160 creates through Assimp + stb_image), decoded to RGBA8 with row 0 = top row.  Per material the index
+ * of its diffuse / emissive texture in this list, -1 for none.  An image that cannot be decoded (PNG only) is dropped with
+ * a warning, as the reference prints and carries on (IMGLoader.cpp:24-25). */
+uint32_t nxh_loaded_texture_count(const nxh_loaded_scene *s);
+int nxh_loaded_texture_info(const nxh_loaded_scene *s, uint32_t index, uint32_t *width, uint32_t *height, int32_t *kind);
+int nxh_loaded_texture_pixels(const nxh_loaded_scene *s, uint32_t index, uint8_t *dstRgba8);
+int nxh_loaded_material_textures(const nxh_loaded_scene *s, int32_t *diffuseTexture, int32_t *emissiveTexture);
+uint32_t nxh_loaded_warning_count(const nxh_loaded_scene *s);
+const char *nxh_loaded_warning(const nxh_loaded_scene *s, uint32_t index);
+/* IMGLoader::LoadIMG (Assets/IMGLoader.cpp:17-41: stbi_load with 4 channels) for PNG data: RGBA8, row 0 first.
+ * dstRgba8 may be NULL to query the size first; *channels = channels of the file (1-4). */
+int nxh_decode_png(const uint8_t *data, size_t size, uint32_t *width, uint32_t *height, uint32_t *channels, uint8_t *dstRgba8, size_t dstCapacity);
 
 typedef struct nxs_scene nxs_scene;
 typedef struct nxs_pathtracer nxs_pathtracer;

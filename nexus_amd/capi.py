@@ -31,7 +31,8 @@ HIP_SYMBOLS = [
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
     "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
-    "nxh_instance_init", "nxh_camera_init",
+    "nxh_instance_init", "nxh_camera_init", "nxh_loaded_texture_count", "nxh_loaded_texture_info", "nxh_loaded_texture_pixels",
+    "nxh_loaded_material_textures", "nxh_loaded_warning_count", "nxh_loaded_warning", "nxh_decode_png",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
     "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
@@ -334,6 +335,54 @@ def load_scene_file(path):
     finally:
         L.nxh_loaded_scene_free(h)
     return meshes, mats, insts
+
+
+def load_scene_textures(path):
+    """The images of a scene file as the C++ reader decodes them: (textures [(kind, HxWx4 uint8)], diffuse texture index
+    per material, emissive texture index per material, warnings)."""
+    L = lib()
+    h = C.c_void_p()
+    if L.nxh_load_scene_file(str(path).encode(), C.byref(h)) != 0:
+        raise NexusError("nxh_load_scene_file: " + L.nxs_last_error().decode())
+    try:
+        L.nxh_loaded_texture_count.argtypes = [C.c_void_p]
+        L.nxh_loaded_texture_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        L.nxh_loaded_texture_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.nxh_loaded_material_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nxh_loaded_warning_count.argtypes = [C.c_void_p]
+        L.nxh_loaded_warning.argtypes = [C.c_void_p, C.c_uint32]
+        L.nxh_loaded_warning.restype = C.c_char_p
+        texs = []
+        for i in range(L.nxh_loaded_texture_count(h)):
+            w, hh, k = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+            if L.nxh_loaded_texture_info(h, i, C.byref(w), C.byref(hh), C.byref(k)) != 0:
+                raise NexusError(L.nxs_last_error().decode())
+            px = np.zeros((hh.value, w.value, 4), dtype=np.uint8)
+            if L.nxh_loaded_texture_pixels(h, i, _ptr(px)) != 0:
+                raise NexusError(L.nxs_last_error().decode())
+            texs.append(("emissive" if k.value == 1 else "diffuse", px))
+        n = L.nxh_loaded_material_count(h)
+        dt, et = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        if L.nxh_loaded_material_textures(h, _ptr(dt), _ptr(et)) != 0:
+            raise NexusError(L.nxs_last_error().decode())
+        warns = [L.nxh_loaded_warning(h, i).decode() for i in range(L.nxh_loaded_warning_count(h))]
+    finally:
+        L.nxh_loaded_scene_free(h)
+    return texs, dt, et, warns
+
+
+def decode_png(data):
+    """nexus::IMGLoader::LoadIMG through the C-ABI: (HxWx4 uint8, channels of the file)"""
+    L = lib()
+    L.nxh_decode_png.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    w, h, ch = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    if L.nxh_decode_png(_ptr(buf), len(buf), C.byref(w), C.byref(h), C.byref(ch), None, 0) != 0:
+        raise NexusError("nxh_decode_png: " + L.nxs_last_error().decode())
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    if L.nxh_decode_png(_ptr(buf), len(buf), C.byref(w), C.byref(h), C.byref(ch), _ptr(out), out.size) != 0:
+        raise NexusError("nxh_decode_png: " + L.nxs_last_error().decode())
+    return out, int(ch.value)
 
 
 class Context:

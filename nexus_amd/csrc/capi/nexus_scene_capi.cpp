@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "nexus/IMGLoader.h"
 #include "nexus/OBJLoader.h"
 #include "nexus/PathTracer.h"
 #include "nexus/Scene.h"
@@ -139,6 +140,53 @@ int nxh_loaded_instances(const nxh_loaded_scene* s, nx_loaded_instance* dst)
             store(dst[i].position, in.position);
             store(dst[i].rotation, in.rotation);
             store(dst[i].scale, in.scale);
+        }
+    });
+}
+
+uint32_t nxh_loaded_texture_count(const nxh_loaded_scene* s) { return static_cast<uint32_t>(s->ls.textures.size()); }
+int nxh_loaded_texture_info(const nxh_loaded_scene* s, uint32_t index, uint32_t* width, uint32_t* height, int32_t* kind)
+{
+    return guarded([&] {
+        if (index >= s->ls.textures.size()) throw std::runtime_error("nxh_loaded_texture_info: no such texture");
+        const Texture& t = s->ls.textures[index];
+        if (width) *width = t.width;
+        if (height) *height = t.height;
+        if (kind) *kind = t.type == Texture::Type::EMISSIVE ? 1 : 0;
+    });
+}
+int nxh_loaded_texture_pixels(const nxh_loaded_scene* s, uint32_t index, uint8_t* dstRgba8)
+{
+    return guarded([&] {
+        if (index >= s->ls.textures.size() || !dstRgba8) throw std::runtime_error("nxh_loaded_texture_pixels: bad argument");
+        const Texture& t = s->ls.textures[index];
+        std::memcpy(dstRgba8, t.pixels.data(), t.pixels.size());
+    });
+}
+int nxh_loaded_material_textures(const nxh_loaded_scene* s, int32_t* diffuseTexture, int32_t* emissiveTexture)
+{
+    return guarded([&] {
+        if (!diffuseTexture || !emissiveTexture) throw std::runtime_error("nxh_loaded_material_textures: null destination");
+        for (size_t i = 0; i < s->ls.materials.size(); i++) {
+            diffuseTexture[i] = s->ls.materialDiffuseTexture[i];
+            emissiveTexture[i] = s->ls.materialEmissiveTexture[i];
+        }
+    });
+}
+uint32_t nxh_loaded_warning_count(const nxh_loaded_scene* s) { return static_cast<uint32_t>(s->ls.warnings.size()); }
+const char* nxh_loaded_warning(const nxh_loaded_scene* s, uint32_t index) { return index < s->ls.warnings.size() ? s->ls.warnings[index].c_str() : ""; }
+
+int nxh_decode_png(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* dstRgba8, size_t dstCapacity)
+{
+    return guarded([&] {
+        if (!data || !width || !height) throw std::runtime_error("nxh_decode_png: null argument");
+        const Texture t = IMGLoader::LoadIMG(data, size);
+        *width = t.width;
+        *height = t.height;
+        if (channels) *channels = t.channels;
+        if (dstRgba8) {
+            if (dstCapacity < t.pixels.size()) throw std::runtime_error("nxh_decode_png: destination too small");
+            std::memcpy(dstRgba8, t.pixels.data(), t.pixels.size());
         }
     });
 }

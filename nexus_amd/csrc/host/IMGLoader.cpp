@@ -1,0 +1,162 @@
+// IMGLoader.cpp — PNG decoder behind nexus/IMGLoader.h (the reference's IMGLoader.cpp:17-41 calls stbi_load with 4 channels).
+#include "nexus/IMGLoader.h"
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <vector>
+
+namespace nexus {
+
+namespace {
+
+[[noreturn]] void fail(const std::string& msg) { throw std::runtime_error("IMGLoader: " + msg); }
+
+uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); }
+
+int paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+}  // namespace
+
+Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
+{
+    static const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size >= 3 && data[0] == 0xff && data[1] == 0xd8) fail("JPEG images are not supported (PNG only)");
+    if (size < 8 || std::memcmp(data, kSig, 8) != 0) fail("not a PNG file");
+    uint32_t width = 0, height = 0;
+    int depth = 0, colour = -1;
+    std::vector<unsigned char> idat, palette, trns;
+    bool seenHeader = false, seenEnd = false;
+    for (size_t off = 8; off + 12 <= size && !seenEnd;) {
+        const uint32_t len = be32(data + off);
+        const unsigned char* type = data + off + 4;
+        const unsigned char* body = data + off + 8;
+        if (len > size - off - 12) fail("chunk runs past the end of the file");
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) fail("bad IHDR");
+            width = be32(body);
+            height = be32(body + 4);
+            depth = body[8];
+            colour = body[9];
+            if (body[10] != 0 || body[11] != 0) fail("unknown compression / filter method");
+            if (body[12] != 0) fail("interlaced PNG files are not supported");
+            seenHeader = true;
+        } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(type, "IEND", 4)) seenEnd = true;
+        off += 12 + static_cast<size_t>(len);
+    }
+    if (!seenHeader || idat.empty()) fail("no IHDR / IDAT chunk");
+    if (width == 0 || height == 0 || width > (1u << 15) || height > (1u << 15)) fail("unreasonable image size");
+    const int samples = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
+    if (!samples) fail("unknown colour type");
+    const bool depthOk = (colour == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                         (colour == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                         ((colour == 2 || colour == 4 || colour == 6) && (depth == 8 || depth == 16));
+    if (!depthOk) fail("bit depth not allowed for this colour type");
+    if (colour == 3 && (palette.size() < 3 || palette.size() % 3)) fail("palette image without a valid PLTE chunk");
+
+    const size_t bitsPerPixel = static_cast<size_t>(samples) * depth;
+    const size_t stride = (static_cast<size_t>(width) * bitsPerPixel + 7) / 8;
+    const size_t bpp = std::max<size_t>(1, bitsPerPixel / 8);  // filter distance in bytes
+    std::vector<unsigned char> raw((stride + 1) * height);
+    uLongf rawLen = static_cast<uLongf>(raw.size());
+    const int zrc = uncompress(raw.data(), &rawLen, idat.data(), static_cast<uLong>(idat.size()));
+    if (zrc != Z_OK || rawLen != raw.size()) fail("corrupt image data (zlib)");
+
+    // undo the scanline filters in place (filter byte first on every line)
+    std::vector<unsigned char> prev(stride, 0);
+    for (uint32_t y = 0; y < height; y++) {
+        unsigned char* line = raw.data() + (stride + 1) * y;
+        const int filter = line[0];
+        unsigned char* cur = line + 1;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = cur[i];
+            switch (filter) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) / 2; break;
+            case 4: v += paeth(a, b, c); break;
+            default: fail("unknown scanline filter");
+            }
+            cur[i] = static_cast<unsigned char>(v);
+        }
+        std::memcpy(prev.data(), cur, stride);
+    }
+
+    Texture tex;
+    tex.width = width;
+    tex.height = height;
+    tex.channels = static_cast<uint32_t>(colour == 3 ? (trns.empty() ? 3 : 4) : samples + ((colour == 0 || colour == 2) && !trns.empty() ? 1 : 0));
+    tex.pixels.resize(static_cast<size_t>(width) * height * 4);
+    auto sample = [&](const unsigned char* row, size_t index) -> uint32_t {  // sample `index` of a row, full bit depth
+        if (depth == 8) return row[index];
+        if (depth == 16) return (uint32_t(row[2 * index]) << 8) | row[2 * index + 1];
+        const size_t bit = index * depth;
+        return (row[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1u);
+    };
+    auto to8 = [&](uint32_t v) -> unsigned char {  // stb_image: 16 -> 8 keeps the high byte; 1/2/4-bit grey is scaled to 0..255
+        if (depth == 16) return static_cast<unsigned char>(v >> 8);
+        if (depth == 8) return static_cast<unsigned char>(v);
+        return static_cast<unsigned char>(v * (255u / ((1u << depth) - 1u)));
+    };
+    uint32_t key[3] = {0, 0, 0};
+    const bool haveKey = (colour == 0 && trns.size() >= 2) || (colour == 2 && trns.size() >= 6);
+    if (haveKey)
+        for (int k = 0; k < (colour == 0 ? 1 : 3); k++) key[k] = (uint32_t(trns[2 * k]) << 8) | trns[2 * k + 1];
+    for (uint32_t y = 0; y < height; y++) {
+        const unsigned char* row = raw.data() + (stride + 1) * y + 1;
+        unsigned char* out = tex.pixels.data() + static_cast<size_t>(y) * width * 4;
+        for (uint32_t x = 0; x < width; x++, out += 4) {
+            switch (colour) {
+            case 0: {
+                const uint32_t g = sample(row, x);
+                out[0] = out[1] = out[2] = to8(g);
+                out[3] = haveKey && g == key[0] ? 0 : 255;
+                break;
+            }
+            case 2: {
+                const uint32_t r = sample(row, 3 * x), g = sample(row, 3 * x + 1), b = sample(row, 3 * x + 2);
+                out[0] = to8(r); out[1] = to8(g); out[2] = to8(b);
+                out[3] = haveKey && r == key[0] && g == key[1] && b == key[2] ? 0 : 255;
+                break;
+            }
+            case 3: {
+                const uint32_t i = sample(row, x);
+                if (3 * static_cast<size_t>(i) + 2 >= palette.size()) fail("palette index out of range");
+                out[0] = palette[3 * i]; out[1] = palette[3 * i + 1]; out[2] = palette[3 * i + 2];
+                out[3] = i < trns.size() ? trns[i] : 255;
+                break;
+            }
+            case 4:
+                out[0] = out[1] = out[2] = to8(sample(row, 2 * x));
+                out[3] = to8(sample(row, 2 * x + 1));
+                break;
+            default:
+                for (int k = 0; k < 4; k++) out[k] = to8(sample(row, 4 * x + k));
+            }
+        }
+    }
+    return tex;
+}
+
+Texture IMGLoader::LoadIMG(const std::string& filepath)
+{
+    std::ifstream f(filepath, std::ios::binary);
+    if (!f) fail("cannot open " + filepath);
+    const std::vector<unsigned char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return LoadIMG(data.data(), data.size());
+}
+
+}  // namespace nexus

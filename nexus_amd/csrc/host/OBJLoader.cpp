@@ -4,6 +4,8 @@
 // and stored as float, like the Python reader in nexus_amd/loaders.py that the tests compare against.
 #include "nexus/OBJLoader.h"
 
+#include "nexus/IMGLoader.h"
+
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -377,13 +379,57 @@ LoadedScene parse_glb(const std::string& file)
     };
 
     LoadedScene out;
+    // texture index -> decoded image, decoded once however many materials share it
+    std::map<std::pair<size_t, int>, int> decoded;  // (glTF texture, kind) -> index into out.textures
+    auto load_texture = [&](const Json& texRef, Texture::Type kind) -> int {
+        const size_t ti = static_cast<size_t>(texRef.at("index").num);
+        const auto key = std::make_pair(ti, kind == Texture::Type::DIFFUSE ? 0 : 1);
+        const auto hit = decoded.find(key);
+        if (hit != decoded.end()) return hit->second;
+        int result = -1;
+        try {
+            const Json& tex = doc.at("textures").at(ti);
+            const Json& img = doc.at("images").at(static_cast<size_t>(tex.at("source").num));
+            Texture t;
+            if (const Json* bvRef = img.find("bufferView")) {
+                const Json& bv = doc.at("bufferViews").at(static_cast<size_t>(bvRef->num));
+                const size_t start = static_cast<size_t>(bv.number("byteOffset", 0)), len = static_cast<size_t>(bv.at("byteLength").num);
+                if (!blob || start + len > blobLen) fail("glb: image runs past the binary chunk");
+                t = IMGLoader::LoadIMG(blob + start, len);
+            } else if (const Json* uri = img.find("uri")) {
+                if (uri->str.compare(0, 5, "data:") == 0) fail("glb: data: URIs are not supported for images");
+                const size_t slash = file.find_last_of("/\\");
+                t = IMGLoader::LoadIMG((slash == std::string::npos ? std::string() : file.substr(0, slash + 1)) + uri->str);
+            } else {
+                fail("glb: image without bufferView or uri");
+            }
+            t.type = kind;
+            result = static_cast<int>(out.textures.size());
+            out.textures.push_back(std::move(t));
+        } catch (const std::exception& e) {
+            out.warnings.push_back(std::string("texture ") + std::to_string(ti) + ": " + e.what());
+        }
+        decoded[key] = result;
+        return result;
+    };
     if (const Json* mats = doc.find("materials"))
-        for (size_t i = 0; i < mats->size(); i++) out.materials.push_back(gltf_material(mats->at(i)));
+        for (size_t i = 0; i < mats->size(); i++) {
+            const Json& m = mats->at(i);
+            out.materials.push_back(gltf_material(m));
+            int dt = -1, et = -1;
+            if (const Json* pbr = m.find("pbrMetallicRoughness"))
+                if (const Json* t = pbr->find("baseColorTexture")) dt = load_texture(*t, Texture::Type::DIFFUSE);
+            if (const Json* t = m.find("emissiveTexture")) et = load_texture(*t, Texture::Type::EMISSIVE);
+            out.materialDiffuseTexture.push_back(dt);
+            out.materialEmissiveTexture.push_back(et);
+        }
     if (out.materials.empty()) {
         Material m;  // pod.make_material() defaults
         m.diffuse.albedo[0] = m.diffuse.albedo[1] = m.diffuse.albedo[2] = 0.8f;
         m.plastic.ior = 1.45f;
         out.materials.push_back(m);
+        out.materialDiffuseTexture.push_back(-1);
+        out.materialEmissiveTexture.push_back(-1);
     }
 
     // one mesh per primitive (what Assimp hands the reference, OBJLoader.cpp:165-181)
@@ -550,6 +596,8 @@ LoadedScene parse_obj(const std::string& file)
     set_albedo_like(m, grey, 1.0 - std::sqrt(20.0) / 31.62278, 1.45);
     m.intensity = 0.0f;
     out.materials.push_back(m);
+    out.materialDiffuseTexture.push_back(-1);
+    out.materialEmissiveTexture.push_back(-1);
     LoadedInstance inst;
     inst.name = file;
     out.instances.push_back(inst);
@@ -578,7 +626,15 @@ void OBJLoader::LoadOBJ(const std::string& path, const std::string& filename, Sc
 {
     const LoadedScene ls = Parse(path + filename);
     const int materialBase = static_cast<int>(assetManager->GetMaterials().size());
-    for (const Material& m : ls.materials) assetManager->AddMaterial(m);
+    // textures first: a material carries the id its map got in the manager's diffuse / emissive list (OBJLoader.cpp:134-135, 157-158)
+    std::vector<int> textureIds(ls.textures.size(), -1);
+    for (size_t i = 0; i < ls.textures.size(); i++) textureIds[i] = assetManager->AddTexture(ls.textures[i]);
+    for (size_t i = 0; i < ls.materials.size(); i++) {
+        Material m = ls.materials[i];
+        if (ls.materialDiffuseTexture[i] >= 0) m.diffuseMapId = textureIds[static_cast<size_t>(ls.materialDiffuseTexture[i])];
+        if (ls.materialEmissiveTexture[i] >= 0) m.emissiveMapId = textureIds[static_cast<size_t>(ls.materialEmissiveTexture[i])];
+        assetManager->AddMaterial(m);
+    }
     std::vector<int32_t> meshIds;
     for (size_t i = 0; i < ls.meshes.size(); i++) {
         const int32_t bvhId = assetManager->CreateBVH(ls.meshes[i]);

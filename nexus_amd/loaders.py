@@ -10,7 +10,9 @@ glTF roughnessFactor — Assimp maps it to shininess (1-r)^2*1000 and the refere
 1 - sqrt(shininess)/31.62278).
 """
 import json
+import os
 import struct
+import zlib
 
 import numpy as np
 
@@ -70,6 +72,125 @@ class LoadedScene:
         self.materials = np.zeros(0, dtype=pod.MAT_DT)
         self.material_names = []
         self.instances = []
+        self.textures = []            # list of (kind "diffuse" / "emissive", HxWx4 uint8 RGBA, row 0 = top)
+        self.material_diffuse_texture = []   # per material: index into textures, -1 = none
+        self.material_emissive_texture = []
+        self.warnings = []
+
+
+def decode_png(data):
+    """PNG (ISO/IEC 15948) -> (HxWx4 uint8, channels of the file), what stbi_load(..., 4) returns and the reference's
+    IMGLoader hands to Texture (Assets/IMGLoader.cpp:17-41): all colour types, 1-16 bits, palette / colour-key
+    transparency, 16-bit samples reduced to their high byte; no Adam7 interlacing."""
+    data = bytes(data)
+    if data[:2] == b"\xff\xd8":
+        raise ValueError("JPEG images are not supported (PNG only)")
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file")
+    off, idat, palette, trns, hdr = 8, b"", b"", b"", None
+    while off + 12 <= len(data):
+        (n,), typ = struct.unpack_from(">I", data, off), data[off + 4: off + 8]
+        body = data[off + 8: off + 8 + n]
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"PLTE":
+            palette = body
+        elif typ == b"tRNS":
+            trns = body
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            break
+        off += 12 + n
+    if hdr is None or not idat:
+        raise ValueError("no IHDR / IDAT chunk")
+    w, h, depth, colour, _comp, _filt, interlace = hdr
+    if interlace:
+        raise ValueError("interlaced PNG files are not supported")
+    samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    bits = samples * depth
+    stride = (w * bits + 7) // 8
+    bpp = max(1, bits // 8)
+    raw = zlib.decompress(idat)
+    if len(raw) != (stride + 1) * h:
+        raise ValueError("corrupt image data")
+    rows = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        f = raw[(stride + 1) * y]
+        cur = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=(stride + 1) * y + 1).astype(np.int32)
+        if f == 0:
+            pass
+        elif f == 2:
+            cur = (cur + prev) & 255
+        else:  # 1, 3, 4 depend on the already reconstructed byte bpp to the left: a scan
+            out = cur.copy()
+            for i in range(stride):
+                a = out[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if f == 1:
+                    out[i] = (out[i] + a) & 255
+                elif f == 3:
+                    out[i] = (out[i] + (a + b) // 2) & 255
+                elif f == 4:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    out[i] = (out[i] + (a if (pa <= pb and pa <= pc) else (b if pb <= pc else c))) & 255
+                else:
+                    raise ValueError("unknown scanline filter")
+            cur = out
+        rows[y] = cur
+        prev = cur
+    if depth == 8:
+        smp = rows[:, : w * samples].astype(np.uint32)
+    elif depth == 16:
+        smp = (rows[:, : 2 * w * samples: 2].astype(np.uint32) << 8) | rows[:, 1: 2 * w * samples: 2]
+    else:
+        bitsarr = np.unpackbits(rows, axis=1)[:, : w * samples * depth].reshape(h, w * samples, depth)
+        smp = np.zeros((h, w * samples), dtype=np.uint32)
+        for k in range(depth):
+            smp = (smp << 1) | bitsarr[:, :, k]
+    smp = smp.reshape(h, w, samples)
+
+    def to8(v):
+        if depth == 16:
+            return (v >> 8).astype(np.uint8)
+        if depth == 8:
+            return v.astype(np.uint8)
+        return (v * (255 // ((1 << depth) - 1))).astype(np.uint8)
+
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    out[..., 3] = 255
+    channels = samples
+    if colour == 0:
+        out[..., 0] = out[..., 1] = out[..., 2] = to8(smp[..., 0])
+        if len(trns) >= 2:
+            key = struct.unpack(">H", trns[:2])[0]
+            out[..., 3] = np.where(smp[..., 0] == key, 0, 255)
+            channels = 2
+    elif colour == 2:
+        out[..., :3] = to8(smp)
+        if len(trns) >= 6:
+            key = struct.unpack(">HHH", trns[:6])
+            out[..., 3] = np.where((smp[..., 0] == key[0]) & (smp[..., 1] == key[1]) & (smp[..., 2] == key[2]), 0, 255)
+            channels = 4
+    elif colour == 3:
+        pal = np.frombuffer(palette, dtype=np.uint8).reshape(-1, 3)
+        idx = smp[..., 0]
+        if idx.max() >= len(pal):
+            raise ValueError("palette index out of range")
+        out[..., :3] = pal[idx]
+        alpha = np.full(256, 255, dtype=np.uint8)
+        alpha[: len(trns)] = np.frombuffer(trns, dtype=np.uint8)
+        out[..., 3] = alpha[idx]
+        channels = 4 if trns else 3
+    elif colour == 4:
+        out[..., 0] = out[..., 1] = out[..., 2] = to8(smp[..., 0])
+        out[..., 3] = to8(smp[..., 1])
+    else:
+        out[...] = to8(smp)
+    return out, channels
 
 
 def _gltf_material(m):
@@ -121,6 +242,37 @@ def load_glb(path):
         return arr
 
     out = LoadedScene()
+    decoded = {}
+
+    def load_texture(ref, kind):
+        key = (ref["index"], kind)
+        if key in decoded:
+            return decoded[key]
+        result = -1
+        try:
+            img = doc["images"][doc["textures"][ref["index"]]["source"]]
+            if "bufferView" in img:
+                bv = doc["bufferViews"][img["bufferView"]]
+                raw = blob[bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]]
+            elif "uri" in img and not img["uri"].startswith("data:"):
+                raw = open(os.path.join(os.path.dirname(path), img["uri"]), "rb").read()
+            else:
+                raise ValueError("image without bufferView or file uri")
+            px, _ch = decode_png(raw)
+            result = len(out.textures)
+            out.textures.append((kind, px))
+        except Exception as e:  # the reference prints and carries on (IMGLoader.cpp:24-25)
+            out.warnings.append("texture %d: %s" % (ref["index"], e))
+        decoded[key] = result
+        return result
+
+    for m in doc.get("materials", []):
+        bt = m.get("pbrMetallicRoughness", {}).get("baseColorTexture")
+        et = m.get("emissiveTexture")
+        out.material_diffuse_texture.append(load_texture(bt, "diffuse") if bt else -1)
+        out.material_emissive_texture.append(load_texture(et, "emissive") if et else -1)
+    if not doc.get("materials"):
+        out.material_diffuse_texture, out.material_emissive_texture = [-1], [-1]
     mats = [_gltf_material(m) for m in doc.get("materials", [])]
     out.material_names = [m.get("name", "") for m in doc.get("materials", [])]
     out.materials = np.array(mats, dtype=pod.MAT_DT) if mats else np.array([pod.make_material()], dtype=pod.MAT_DT)
@@ -207,5 +359,6 @@ def load_obj(path):
     out.mesh_names = [path]
     out.materials = np.array([pod.make_material(type=pod.MAT_PLASTIC, albedo=(0.6, 0.6, 0.6), roughness=1.0 - np.sqrt(20.0) / 31.62278)], dtype=pod.MAT_DT)
     out.material_names = ["default"]
+    out.material_diffuse_texture, out.material_emissive_texture = [-1], [-1]
     out.instances = [dict(mesh=0, material=0, position=np.zeros(3, np.float32), rotation=np.zeros(3, np.float32), scale=np.ones(3, np.float32), name=path)]
     return out

@@ -66,6 +66,31 @@ def cornell_scene(width=512, height=512, path_length=4, force_diffuse=True, use_
     return sc
 
 
+def glb_scene(path, width, height, path_length=4, eye=(0.0, 1.0, 3.9), forward=(0.0, 0.0, -1.0), hfov=40.0, use_mis=True):
+    """A .glb read by the Python reader (nexus_amd.loaders), materials and textures as the file gives them: what
+    Scene::CreateMeshInstanceFromFile builds (Scene.cpp:83-91), as a BuiltScene."""
+    from nexus_amd import loaders
+
+    ls = loaders.load_glb(path)
+    mats = ls.materials.copy()
+    kinds = {"diffuse": [], "emissive": []}
+    tex_id = []
+    for kind, px in ls.textures:  # ids are positions in the per-kind lists, as AssetManager::AddTexture hands them out
+        tex_id.append(len(kinds[kind]))
+        kinds[kind].append(px)
+    for i in range(len(mats)):
+        if ls.material_diffuse_texture[i] >= 0:
+            mats["diffuseMapId"][i] = tex_id[ls.material_diffuse_texture[i]]
+        if ls.material_emissive_texture[i] >= 0:
+            mats["emissiveMapId"][i] = tex_id[ls.material_emissive_texture[i]]
+    placements = [(inst["mesh"], inst["material"], capi.mat4_from_trs(inst["position"], inst["rotation"], inst["scale"])) for inst in ls.instances]
+    cam = capi.camera_init(eye, forward, hfov, width, height, 5.0, 0.0)
+    settings = O.make_settings(use_mis=use_mis, path_length=path_length, background=(1, 1, 1), background_intensity=0.0)
+    sc = BuiltScene(ls.meshes, placements, materials=mats, camera=cam, settings=settings, diffuse_maps=kinds["diffuse"], emissive_maps=kinds["emissive"])
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc
+
+
 def material_zoo_scene(width=96, height=64, path_length=5, hdr=True, textures=True):
     """Every material type, an emissive-textured light, diffuse texture with alpha, opacity < 1, instanced + rotated BLAS,
     equirectangular background."""

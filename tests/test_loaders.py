@@ -111,3 +111,206 @@ def test_cpp_reader_rejects_bad_input(tmp_path):
         capi.load_scene_file(str(idx))
     with pytest.raises(capi.NexusError):
         capi.load_scene_file(str(tmp_path / "scene.fbx"))
+
+
+# ---- cornell_box_sphere.glb: the second data file the reference ships (assets/demo_scenes/cornell_box_sphere) -------
+
+def test_sphere_glb_facts_and_cpp_reader():
+    """2 188 triangles, two transmissive spheres (ior 1.45 and 2.5) that become DIELECTRIC through
+    transmissionFactor > 0 (OBJLoader.cpp:97-102)."""
+    from nexus_amd import capi
+
+    path = os.path.join(SH.GOLDEN, "cornell_box_sphere.glb")
+    ls = loaders.load_glb(path)
+    assert sum(len(m) for m in ls.meshes) == 2188
+    glass = [m for m in ls.materials if m["type"] == pod.MAT_DIELECTRIC]
+    assert len(glass) == 2
+    assert sorted(round(float(m["u"][4]), 3) for m in glass) == [1.45, 2.5]           # plastic/dielectric ior slot
+    assert all(m["type"] in (pod.MAT_PLASTIC, pod.MAT_DIELECTRIC) for m in ls.materials)
+    lights = [m for m in ls.materials if float(m["intensity"]) * float(np.max(m["emissive"])) > 0.0]
+    assert len(lights) == 1
+    assert ls.textures == [] and ls.warnings == []
+    _same_scene(capi.load_scene_file(path), ls)
+
+
+# ---- images: the PNG decoder (C++ nexus::IMGLoader and its Python twin) ---------------------------------------------
+
+def _png(width, height, colour, depth, samples, rng, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """Encode a random image with the given colour type / bit depth, cycling through the scanline filters; returns
+    (file bytes, sample array [h][w][samples] at full bit depth)."""
+    import struct
+    import zlib
+
+    maxv = (1 << depth) - 1 if colour != 3 else len(palette) // 3 - 1
+    smp = rng.randint(0, maxv + 1, size=(height, width, samples)).astype(np.uint32)
+    bits = samples * depth
+    stride = (width * bits + 7) // 8
+    bpp = max(1, bits // 8)
+    rows = np.zeros((height, stride), dtype=np.uint8)
+    for y in range(height):
+        flat = smp[y].reshape(-1)
+        if depth == 8:
+            rows[y] = flat
+        elif depth == 16:
+            rows[y, 0::2] = flat >> 8
+            rows[y, 1::2] = flat & 255
+        else:
+            b = np.zeros(stride * 8, dtype=np.uint8)
+            for k in range(depth):
+                b[k: len(flat) * depth: depth] = (flat >> (depth - 1 - k)) & 1
+            rows[y] = np.packbits(b)
+    raw = bytearray()
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(height):
+        f = filters[y % len(filters)]
+        cur = rows[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if stride > bpp else np.zeros(stride, np.int32)
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, np.int32)
+        if f == 0:
+            enc = cur
+        elif f == 1:
+            enc = cur - left
+        elif f == 2:
+            enc = cur - prev
+        elif f == 3:
+            enc = cur - (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            enc = cur - pred
+        raw.append(f)
+        raw += bytes((enc & 255).astype(np.uint8))
+        prev = cur
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, colour, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(bytes(raw), 6)
+    out += chunk(b"IDAT", comp[: len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    return out, smp
+
+
+def _to8(v, depth):
+    return (v >> 8).astype(np.uint8) if depth == 16 else v.astype(np.uint8) if depth == 8 else (v * (255 // ((1 << depth) - 1))).astype(np.uint8)
+
+
+def test_png_decoders_agree_with_the_encoded_samples():
+    from nexus_amd import capi
+
+    rng = np.random.RandomState(11)
+    cases = [(0, d, 1) for d in (1, 2, 4, 8, 16)] + [(2, 8, 3), (2, 16, 3), (4, 8, 2), (4, 16, 2), (6, 8, 4), (6, 16, 4)] + [(3, d, 1) for d in (1, 2, 4, 8)]
+    for colour, depth, samples in cases:
+        for (w, h) in ((1, 1), (5, 7), (33, 9)):
+            palette = trns = None
+            if colour == 3:
+                n = 1 << depth
+                palette = rng.randint(0, 256, size=3 * n).astype(np.uint8)
+                trns = rng.randint(0, 256, size=n // 2 + 1).astype(np.uint8)
+            data, smp = _png(w, h, colour, depth, samples, rng, palette, trns)
+            want = np.zeros((h, w, 4), dtype=np.uint8)
+            want[..., 3] = 255
+            if colour == 0:
+                want[..., 0] = want[..., 1] = want[..., 2] = _to8(smp[..., 0], depth)
+            elif colour == 2:
+                want[..., :3] = _to8(smp, depth)
+            elif colour == 3:
+                pal = palette.reshape(-1, 3)
+                want[..., :3] = pal[smp[..., 0]]
+                alpha = np.full(256, 255, np.uint8)
+                alpha[: len(trns)] = trns
+                want[..., 3] = alpha[smp[..., 0]]
+            elif colour == 4:
+                want[..., 0] = want[..., 1] = want[..., 2] = _to8(smp[..., 0], depth)
+                want[..., 3] = _to8(smp[..., 1], depth)
+            else:
+                want[...] = _to8(smp, depth)
+            py, _ = loaders.decode_png(data)
+            cpp, _ = capi.decode_png(data)
+            assert np.array_equal(py, want), (colour, depth, w, h)
+            assert np.array_equal(cpp, want), (colour, depth, w, h)
+    # colour-key transparency (tRNS on grey / RGB) and what must be refused
+    import struct
+    data, smp2 = _png(6, 4, 2, 8, 3, np.random.RandomState(5), trns=struct.pack(">HHH", 7, 7, 7))
+    for dec in (loaders.decode_png, capi.decode_png):
+        img, ch = dec(data)
+        assert ch == 4 and np.array_equal(img[..., 3] == 0, np.all(smp2 == 7, axis=-1))
+    with pytest.raises(Exception):
+        capi.decode_png(b"\xff\xd8\xff\xe0 not a png")
+    with pytest.raises(Exception):
+        capi.decode_png(data[:40])
+    bad = bytearray(data)
+    bad[8 + 8 + 12] = 1  # interlace flag of IHDR
+    with pytest.raises(Exception):
+        capi.decode_png(bytes(bad))
+
+
+def _textured_glb(path, rng):
+    """A two-triangle quad with UVs, a base-colour texture and an emissive texture (PNG, embedded through bufferViews)."""
+    import json
+    import struct
+
+    base_png, _ = _png(16, 8, 6, 8, 4, rng)
+    emis_png, _ = _png(4, 4, 2, 8, 3, rng)
+    pos = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    nrm = np.tile(np.array([0, 1, 0], np.float32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    parts, views = [], []
+    for b in (pos.tobytes(), nrm.tobytes(), uv.tobytes(), idx.tobytes(), base_png, emis_png):
+        off = sum(len(p) for p in parts)
+        parts.append(b + b"\0" * (-len(b) % 4))
+        views.append({"buffer": 0, "byteOffset": off, "byteLength": len(b)})
+    blob = b"".join(parts)
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0, "name": "quad"}],
+        "meshes": [{"name": "quad", "primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]}],
+        "materials": [{"name": "tex", "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "baseColorTexture": {"index": 0}},
+                       "emissiveTexture": {"index": 1}, "emissiveFactor": [1, 1, 1]}],
+        "textures": [{"source": 0}, {"source": 1}], "images": [{"bufferView": 4, "mimeType": "image/png"}, {"bufferView": 5, "mimeType": "image/png"}],
+        "buffers": [{"byteLength": len(blob)}], "bufferViews": views,
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3", "min": [-1, 0, -1], "max": [1, 0, 1]},
+                      {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC2"},
+                      {"bufferView": 3, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+    }
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob
+    open(path, "wb").write(struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body)
+    return base_png, emis_png
+
+
+def test_glb_textures_cpp_equals_python_and_reach_the_asset_manager(tmp_path):
+    from nexus_amd import capi
+
+    path = str(tmp_path / "textured.glb")
+    base_png, emis_png = _textured_glb(path, np.random.RandomState(21))
+    py = loaders.load_glb(path)
+    assert [k for k, _ in py.textures] == ["diffuse", "emissive"] and py.material_diffuse_texture == [0] and py.material_emissive_texture == [1]
+    assert np.array_equal(py.textures[0][1], loaders.decode_png(base_png)[0]) and py.textures[0][1].shape == (8, 16, 4)
+    texs, dt, et, warns = capi.load_scene_textures(path)
+    assert warns == [] and list(dt) == [0] and list(et) == [1]
+    for (ka, pa), (kb, pb) in zip(texs, py.textures):
+        assert ka == kb and np.array_equal(pa, pb)
+    _same_scene(capi.load_scene_file(path), py)
+    # Scene::CreateMeshInstanceFromFile: the maps get ids in the manager's diffuse / emissive lists and the material carries them;
+    # an emissive map makes the instance a light (Scene.cpp:166-175)
+    sc = capi.Scene(32, 32)
+    sc.load_file(str(tmp_path) + os.sep, "textured.glb")
+    sc.update()
+    assert sc.light_count() == 1
+    # a JPEG (or anything that is not a PNG) is dropped with a warning, the scene still loads
+    raw = bytearray(open(path, "rb").read())
+    at = raw.find(base_png[:8])
+    raw[at: at + 4] = b"\xff\xd8\xff\xe0"
+    broken = str(tmp_path / "jpeg.glb")
+    open(broken, "wb").write(bytes(raw))
+    texs, dt, et, warns = capi.load_scene_textures(broken)
+    assert len(texs) == 1 and list(dt) == [-1] and list(et) == [0] and len(warns) == 1 and "JPEG" in warns[0]
+    assert loaders.load_glb(broken).material_diffuse_texture == [-1]
