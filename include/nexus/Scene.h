@@ -60,6 +60,10 @@ public:
 
     // what the device has not seen yet (set here, cleared by PathTracer::UpdateDeviceScene)
     mutable bool tlasDirty = true, lightsDirty = true, hdrDirty = false;
+    // With SetTlasRefit(true): BVH-instance ids whose transform (and nothing else) changed since the device last saw the TLAS.
+    // PathTracer::UpdateDeviceScene hands them to nxhip_set_instance_transforms — inverse, bounds, traversal records and the
+    // TLAS refit happen in HBM — instead of uploading the tree again.
+    mutable std::vector<uint32_t> movedInstances;
 
 private:
     // derive / drop the MESH_LIGHT of instance `index` from its material (Scene.cpp:142-176)

@@ -55,6 +55,16 @@ int nxhip_clear_blas(nxhip_ctx *ctx);
 /* TLAS::UpdateDeviceData — Geometry/BVH/TLAS.cpp:93-100 (symbols `tlas`, `blas`). */
 int nxhip_set_tlas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const uint32_t *instanceIdx,
                    const nx_bvh_instance *instances, uint32_t instanceCount);
+/* Dynamic transforms without a host round trip of the scene.  Replaces, for instances that
+ * already exist, MeshInstance::SetTransform -> BVHInstance::SetTransform -> TLAS::Build -> TLAS::UpdateDeviceData
+ * (Geometry/BVH/BVHInstance.cpp:4-29, Scene/Scene.cpp:29-55, Geometry/BVH/TLAS.cpp:13-100: an O(n^2) agglomerative rebuild
+ * on the CPU per edit).  transforms16: count row-major object-to-world matrices.  On the device: inverse matrix and world
+ * bounds of every listed instance (bit-identical to nexus::BVHInstance::SetTransform), its traversal record, then a
+ * bottom-up refit of the TLAS BVH8 with unchanged topology (bit-identical to nexus::collapse::Refit / nxh_tlas_refit).
+ * Runs on the context's stream after the frames already issued. */
+int nxhip_set_instance_transforms(nxhip_ctx *ctx, const uint32_t *instanceIds, const float *transforms16, uint32_t count);
+/* Read the device's TLAS nodes / instance table back (tests; either destination may be NULL). */
+int nxhip_read_tlas(nxhip_ctx *ctx, nx_bvh8_node *nodes, uint32_t nodeCapacity, nx_bvh_instance *instances, uint32_t instanceCapacity);
 /* AssetManager device materials — Assets/AssetManager.cpp:57-62,106-116 */
 int nxhip_set_materials(nxhip_ctx *ctx, const nx_material *materials, uint32_t count);
 /* Scene::m_DeviceLights — Scene/Scene.cpp:142-176 */

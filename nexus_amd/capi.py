@@ -25,6 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
 ]
@@ -130,6 +131,8 @@ def lib():
     L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
     L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.nxhip_read_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.c_int]
+    L.nxhip_set_instance_transforms.argtypes = [vp, vp, vp, u32]
+    L.nxhip_read_tlas.argtypes = [vp, vp, u32, vp, u32]
     L.nxhip_tile_pixel_map.argtypes = [u32, u32, C.c_int, C.c_int, u32, C.c_int, vp, C.POINTER(u32)]
     L.nxhip_mgpu_unique_id.argtypes = [vp]
     L.nxhip_mgpu_init.argtypes = [vp, C.c_int, C.c_int, vp, u32]
@@ -470,6 +473,18 @@ class Context:
             pm = np.ascontiguousarray(pixel_map, dtype=np.uint32)
             check(self.L.nxhip_set_pixel_map(self.h, _ptr(pm), len(pm)), "nxhip_set_pixel_map")
             self.local_count = len(pm)
+
+    def set_instance_transforms(self, instance_ids, transforms16):
+        """move existing instances on the device (inverse, bounds, traversal records, TLAS refit): no scene re-upload"""
+        ids = np.ascontiguousarray(instance_ids, dtype=np.uint32)
+        m = np.ascontiguousarray(transforms16, dtype=np.float32).reshape(len(ids), 16)
+        check(self.L.nxhip_set_instance_transforms(self.h, _ptr(ids), _ptr(m), len(ids)), "nxhip_set_instance_transforms")
+
+    def read_tlas(self, node_count, instance_count):
+        nodes = np.zeros(node_count, dtype=pod.NODE_DT)
+        insts = np.zeros(instance_count, dtype=pod.INST_DT)
+        check(self.L.nxhip_read_tlas(self.h, _ptr(nodes), node_count, _ptr(insts), instance_count), "nxhip_read_tlas")
+        return nodes, insts
 
     # ---- native multi-GPU tile split (RCCL inside the library; bench.py's N > 1 path uses torch.distributed instead)
     def mgpu_init(self, world, rank, unique_id, tile_rows):

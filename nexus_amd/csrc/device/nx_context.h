@@ -85,6 +85,10 @@ struct nxhip_ctx {
     std::vector<nx_light> hostLights;
     std::vector<uint32_t> hostInstIdx;  // TLAS leaf order
     nxd::DevBuf materials, lights;
+    // device-side dynamic transforms (nx_refit.hip): TLAS nodes grouped by depth (deepest first), leaf slot of every instance,
+    // per-node box scratch, staging for the ids / matrices of one call
+    nxd::DevBuf refitOrder, refitLevelStart, leafOfInstance, refitBoxes, refitIds, refitMatrices;
+    uint32_t refitLevels = 0, tlasNodeCount = 0;
     std::vector<nxd::TextureHost> diffuseMaps, emissiveMaps;
     nxd::TextureHost hdrMap;
     nxd::DevBuf diffuseTable, emissiveTable, srgbLut;

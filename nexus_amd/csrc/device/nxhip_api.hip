@@ -23,6 +23,8 @@ const void* accumulate_kernel_ptr();
 const void* compose_kernel_ptr();
 const void* bsdf_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
+const void* instance_transform_kernel_ptr();
+const void* tlas_refit_kernel_ptr();
 
 static thread_local std::string g_lastError;
 
@@ -495,10 +497,103 @@ try {
     c->h.instances = c->instances.as<nx_bvh_instance>();
     c->h.instanceCount = instanceCount;
     c->stateDirty = true;
+    {
+        // schedule of the device-side refit (nxhip_set_instance_transforms): node indices grouped by depth, deepest first
+        std::vector<uint32_t> depth(nodeCount, 0u);
+        uint32_t maxDepth = 0;
+        for (uint32_t i = 0; i < nodeCount; i++) {  // children follow their parent in the array: one ascending sweep
+            const nx_bvh8_node& n = nodes[i];
+            const uint32_t inner = (uint32_t)__builtin_popcount(n.imask);
+            for (uint32_t k = 0; k < inner; k++) {
+                if (n.childBaseIdx + k <= i) return fail_invalid("nxhip_set_tlas: child nodes must follow their parent");
+                depth[n.childBaseIdx + k] = depth[i] + 1;
+                maxDepth = std::max(maxDepth, depth[i] + 1);
+            }
+        }
+        std::vector<uint32_t> levelStart(maxDepth + 2, 0u), order(nodeCount);
+        for (uint32_t i = 0; i < nodeCount; i++) levelStart[(maxDepth - depth[i]) + 1]++;
+        for (uint32_t l = 0; l <= maxDepth; l++) levelStart[l + 1] += levelStart[l];
+        std::vector<uint32_t> cursor(levelStart.begin(), levelStart.end() - 1);
+        for (uint32_t i = 0; i < nodeCount; i++) order[cursor[maxDepth - depth[i]]++] = i;
+        std::vector<uint32_t> leafOf(instanceCount, 0u);
+        for (uint32_t k = 0; k < instanceCount; k++) leafOf[instanceIdx[k]] = k;
+        NX_ALLOC(c->refitOrder, (size_t)nodeCount * 4);
+        NX_ALLOC(c->refitLevelStart, levelStart.size() * 4);
+        NX_ALLOC(c->leafOfInstance, (size_t)instanceCount * 4);
+        NX_ALLOC(c->refitBoxes, (size_t)nodeCount * 24);
+        NX_HIP(hipMemcpy(c->refitOrder.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        NX_HIP(hipMemcpy(c->refitLevelStart.p, levelStart.data(), levelStart.size() * 4, hipMemcpyHostToDevice));
+        NX_HIP(hipMemcpy(c->leafOfInstance.p, leafOf.data(), leafOf.size() * 4, hipMemcpyHostToDevice));
+        c->refitLevels = maxDepth + 1;
+        c->tlasNodeCount = nodeCount;
+    }
     return refresh_inst_trav(c);
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_set_tlas: ") + e.what());
     return NXHIP_ERR_INVALID;
+}
+
+int nxhip_set_instance_transforms(nxhip_ctx* c, const uint32_t* instanceIds, const float* transforms16, uint32_t count)
+try {
+    NX_CHECK_CTX(c);
+    if (count == 0) return NXHIP_OK;
+    if (!instanceIds || !transforms16) return fail_invalid("nxhip_set_instance_transforms: null argument");
+    if (!c->h.tlasNodes || c->refitLevels == 0) return fail_invalid("nxhip_set_instance_transforms: no TLAS has been set");
+    for (uint32_t i = 0; i < count; i++)
+        if (instanceIds[i] >= c->h.instanceCount) return fail_invalid("nxhip_set_instance_transforms: instance id out of range");
+    NX_HIP(hipSetDevice(c->device));
+    int rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
+    if (c->refitIds.bytes < (size_t)count * 4) NX_ALLOC(c->refitIds, (size_t)count * 4);
+    if (c->refitMatrices.bytes < (size_t)count * 64) NX_ALLOC(c->refitMatrices, (size_t)count * 64);
+    // stream order does the rest: a frame already in flight finishes with the old placement, the next one sees the new
+    NX_HIP(hipMemcpyAsync(c->refitIds.p, instanceIds, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    NX_HIP(hipMemcpyAsync(c->refitMatrices.p, transforms16, (size_t)count * 64, hipMemcpyHostToDevice, c->stream));
+    {
+        const DeviceState* S = c->dState.as<DeviceState>();
+        nx_bvh_instance* inst = c->instances.as<nx_bvh_instance>();
+        InstTrav* trav = c->instTrav.as<InstTrav>();
+        const uint32_t* leafOf = c->leafOfInstance.as<uint32_t>();
+        const uint32_t* ids = c->refitIds.as<uint32_t>();
+        const float* mats = c->refitMatrices.as<float>();
+        void* args[7] = {(void*)&S, (void*)&inst, (void*)&trav, (void*)&leafOf, (void*)&ids, (void*)&mats, (void*)&count};
+        const unsigned grid = std::min<unsigned>((count + 255u) / 256u, (unsigned)c->wideBlocks);
+        NX_HIP(hipLaunchKernel(instance_transform_kernel_ptr(), dim3(grid), dim3(256), args, 0, c->stream));
+    }
+    {
+        nx_bvh8_node* nodes = c->tlasNodes.as<nx_bvh8_node>();
+        const uint32_t* primIdx = c->tlasInstIdx.as<uint32_t>();
+        const nx_bvh_instance* inst = c->instances.as<nx_bvh_instance>();
+        const uint32_t* order = c->refitOrder.as<uint32_t>();
+        const uint32_t* levelStart = c->refitLevelStart.as<uint32_t>();
+        const uint32_t levels = c->refitLevels;
+        void* boxes = c->refitBoxes.p;
+        void* args[7] = {(void*)&nodes, (void*)&primIdx, (void*)&inst, (void*)&order, (void*)&levelStart, (void*)&levels, (void*)&boxes};
+        NX_HIP(hipLaunchKernel(tlas_refit_kernel_ptr(), dim3(1), dim3(1024), args, 0, c->stream));
+    }
+    // pageable host arrays: the copies above are staged before hipMemcpyAsync returns on this runtime, but that is not a
+    // documented guarantee — wait, the call is not on the per-frame path
+    NX_HIP(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < count; i++) std::memcpy(c->hostInstances[instanceIds[i]].transform.cell, transforms16 + 16 * (size_t)i, 64);
+    return NXHIP_OK;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_set_instance_transforms: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
+int nxhip_read_tlas(nxhip_ctx* c, nx_bvh8_node* nodes, uint32_t nodeCapacity, nx_bvh_instance* instances, uint32_t instanceCapacity)
+{
+    NX_CHECK_CTX(c);
+    if (!c->h.tlasNodes) return fail_invalid("nxhip_read_tlas: no TLAS has been set");
+    if ((nodes && nodeCapacity < c->tlasNodeCount) || (instances && instanceCapacity < c->h.instanceCount)) return fail_invalid("nxhip_read_tlas: destination too small");
+    NX_HIP(hipSetDevice(c->device));
+    NX_HIP(hipStreamSynchronize(c->stream));
+    if (nodes) {
+        if (kNodeStride == 5) NX_HIP(hipMemcpy(nodes, c->tlasNodes.p, (size_t)c->tlasNodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+        else return fail_invalid("nxhip_read_tlas: built with padded node records");
+    }
+    if (instances) NX_HIP(hipMemcpy(instances, c->instances.p, (size_t)c->h.instanceCount * sizeof(nx_bvh_instance), hipMemcpyDeviceToHost));
+    return NXHIP_OK;
 }
 
 int nxhip_set_materials(nxhip_ctx* c, const nx_material* materials, uint32_t count)

@@ -2,6 +2,7 @@
 // CUDA graph (/root/reference/Nexus/src/Renderer/PathTracer.cpp:5-317), this class forwards to the C-ABI device layer.
 #include "nexus/PathTracer.h"
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -82,6 +83,19 @@ void PathTracer::UpdateDeviceScene(const Scene& scene)
         Check(nxhip_set_tlas(m_Ctx, tlas.bvh8.nodes.data(), static_cast<uint32_t>(tlas.bvh8.nodes.size()), tlas.bvh8.triangleIdx.data(), inst.data(),
                              static_cast<uint32_t>(inst.size())), "nxhip_set_tlas");
         scene.tlasDirty = false;
+        scene.movedInstances.clear();
+    } else if (!scene.movedInstances.empty()) {
+        // dynamic transforms: the device recomputes inverse, bounds and traversal records of the moved instances and refits
+        // its TLAS in place (nx_refit.hip); the tree is not uploaded again
+        const std::vector<BVHInstance>& inst = scene.GetBVHInstances();
+        std::vector<float> matrices(scene.movedInstances.size() * 16);
+        for (size_t k = 0; k < scene.movedInstances.size(); k++) {
+            const Mat4 m = inst[scene.movedInstances[k]].GetTransform();
+            std::memcpy(&matrices[16 * k], m.cell, 64);
+        }
+        Check(nxhip_set_instance_transforms(m_Ctx, scene.movedInstances.data(), matrices.data(), static_cast<uint32_t>(scene.movedInstances.size())),
+              "nxhip_set_instance_transforms");
+        scene.movedInstances.clear();
     }
     if (scene.lightsDirty) {
         Check(nxhip_set_lights(m_Ctx, scene.GetLights().data(), static_cast<uint32_t>(scene.GetLights().size())), "nxhip_set_lights");

@@ -39,12 +39,16 @@ void Scene::Update()
 
     const std::vector<Mesh>& meshes = m_AssetManager.GetMeshes();
     std::vector<BVH8>& blases = m_AssetManager.GetBVHs();
+    std::vector<uint32_t> moved;
+    bool onlyTransforms = true;  // nothing but the placement of existing instances changed
     for (const uint32_t id : m_InvalidMeshInstances) {
         const MeshInstance& edited = m_MeshInstances[id];
         BVHInstance& placed = m_BVHInstances[static_cast<size_t>(edited.bvhInstanceIdx)];
         placed.SetBvh(&blases[static_cast<size_t>(meshes[placed.GetBvhIdx()].bvhId)]);  // the vector may have grown since
         placed.SetTransform(edited.position, edited.rotation, edited.scale);
+        moved.push_back(static_cast<uint32_t>(edited.bvhInstanceIdx));
         if (edited.materialId == -1) continue;
+        if (placed.GetMaterialId() != edited.materialId) onlyTransforms = false;
         placed.AssignMaterial(edited.materialId);
         UpdateInstanceLighting(id);
     }
@@ -53,12 +57,18 @@ void Scene::Update()
     if (!m_Tlas) m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
     m_Tlas->SetBVHInstances(m_BVHInstances);
     const bool sameInstances = m_TlasBuiltFor == m_BVHInstances.size();
-    if (!(m_TlasRefit && sameInstances && m_Tlas->Refit())) {
+    if (m_TlasRefit && sameInstances && m_Tlas->Refit()) {
+        // the host copy of the tree is refitted too (O(n)), so that it stays what the device holds; the device is told
+        // only which instances moved, unless it has yet to see this tree at all
+        if (onlyTransforms && !tlasDirty) movedInstances.insert(movedInstances.end(), moved.begin(), moved.end());
+        else tlasDirty = true;
+    } else {
         m_Tlas->Build();
         m_Tlas->Convert();
         m_TlasBuiltFor = m_BVHInstances.size();
+        tlasDirty = true;
     }
-    tlasDirty = true;
+    if (tlasDirty) movedInstances.clear();
     m_Invalid = false;
 }
 

@@ -79,3 +79,34 @@ def test_gpu_traces_a_refitted_tlas_like_the_oracle(gpu_ctx_factory):
     scene.upload(ctx)
     rays = _rays(30000, 31)
     assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_inst,n_moved", [(60, 60), (1000, 1000), (1000, 37), (1, 1)])
+def test_device_side_refit_equals_the_host_refit_and_traces_like_the_oracle(gpu_ctx_factory, n_inst, n_moved):
+    """nxhip_set_instance_transforms: the instance records and the refitted TLAS left in HBM are, byte for byte, what
+    nexus::BVHInstance::SetTransform + nexus::collapse::Refit produce on the host; rays traced through them equal the oracle
+    tracing the host-refitted scene."""
+    scene = SH.instanced_scene(seed=8, n_inst=n_inst)
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    rng = np.random.RandomState(17)
+    ids = rng.permutation(n_inst)[:n_moved].astype(np.uint32)
+    xfs = np.array([capi.mat4_from_trs(rng.uniform(-2.5, 2.5, 3), rng.uniform(0, 360, 3), rng.uniform(0.4, 1.6, 3)) for _ in ids], dtype=np.float32)
+    before = ctx.trace_batch(_rays(2000, 3))
+    ctx.set_instance_transforms(ids, xfs)
+    want_inst = scene.instances.copy()
+    for i, xf in zip(ids, xfs):
+        old = scene.instances[i]
+        want_inst[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), xf, scene.blas[int(old["bvhIdx"])][0][0])
+    want_nodes = capi.tlas_refit(scene.tlas_nodes, scene.tlas_idx, want_inst)
+    got_nodes, got_inst = ctx.read_tlas(len(scene.tlas_nodes), n_inst)
+    assert got_inst.tobytes() == want_inst.tobytes()
+    assert got_nodes.tobytes() == want_nodes.tobytes()
+    scene.instances, scene.tlas_nodes = want_inst, want_nodes
+    rays = _rays(20000, 41)
+    got = ctx.trace_batch(rays)
+    assert SH.hit_records_equal(got, scene.oracle().trace_closest(rays))
+    assert not SH.hit_records_equal(ctx.trace_batch(_rays(2000, 3)), before) or n_inst == 1
+    with pytest.raises(capi.NexusError):
+        ctx.set_instance_transforms(np.array([n_inst], np.uint32), xfs[:1])
