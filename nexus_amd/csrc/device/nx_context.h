@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -60,20 +61,50 @@ struct KernelTimer {
 
 }  // namespace nxd
 
-struct nxhip_ctx {
-    int device = 0;
+namespace nxd {
+
+// Everything ONE in-flight pass owns: its path state and queues, its device-state block (scene pointers + these queues),
+// counters, frame words, the stream it runs on and its instance of the pass graph.  A context is slot 0 (on the context's
+// own stream); nxhip_set_passes_in_flight(R > 1) adds R - 1 more so that consecutive passes overlap on the GPU: the drain
+// phase of one pass (a few long rays, most SIMDs idle) is filled by the bulk of the next.
+struct PassSlot {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
+    DevBuf throughputPdf, radiance, rayOrigin;
+    DevBuf trRayO, trRayD, trHit, trHitInst;
+    DevBuf shRayO, shRayD, shRadiance;
+    DevBuf mqHit[4], mqDirInst[4], mqPixel[4];
+    DevBuf counters, frame, dState;
+    size_t pathCapacity = 0;  // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graphExec = nullptr;
+    bool graphValid = false;
+    // pass bookkeeping (slots >= 1 and slot 0 alike)
+    hipEvent_t done = nullptr, accumulated = nullptr;
+    bool awaitingAccumulate = false;   // holds a rendered pass that nxhip_accumulate has not consumed yet
+    bool accumulateRecorded = false;   // `accumulated` was recorded after the last use: the next use must wait for it
+    uint32_t frames = 0, frameLast = 0;  // of the pass it holds
+    DeviceState view{};  // host mirror of this slot's device-state block
+};
+
+}  // namespace nxd
+
+struct nxhip_ctx : nxd::PassSlot {
+    int device = 0;
     hipStream_t stream2 = nullptr;  // second branch of the per-bounce fork (shadow trace)
     int numCUs = 0;
+    // passes in flight: slot 0 is the context itself, extra[k] is slot k + 1
+    std::vector<std::unique_ptr<nxd::PassSlot>> extra;
+    uint32_t passesInFlight = 1;
+    uint32_t nextSlot = 0;                 // slot the next rendered pass goes to
+    std::vector<nxd::PassSlot*> pending;   // rendered, not yet accumulated, oldest first
+    nxd::PassSlot* lastRendered = nullptr;
 
     uint32_t width = 0, height = 0, localCount = 0;
     uint32_t framesPerPass = 1, pathCount = 0;
-    size_t pathCapacity = 0;           // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
     size_t radianceBoundCapacity = 0;  // float4 capacity of an externally bound radiance buffer, 0 = own buffer
 
-    nxd::DeviceState h{};  // host mirror, uploaded to dState when dirty
-    nxd::DevBuf dState;
+    nxd::DeviceState h{};  // host mirror (scene + slot 0's queues), uploaded to every slot's dState when dirty
     bool stateDirty = true;
 
     // scene
@@ -93,11 +124,8 @@ struct nxhip_ctx {
     nxd::TextureHost hdrMap;
     nxd::DevBuf diffuseTable, emissiveTable, srgbLut;
     // paths / queues
-    nxd::DevBuf pixelMap, throughputPdf, radiance, rayOrigin, accumulation, rgba8;
-    nxd::DevBuf trRayO, trRayD, trHit, trHitInst;
-    nxd::DevBuf shRayO, shRayD, shRadiance;
-    nxd::DevBuf mqHit[4], mqDirInst[4], mqPixel[4];
-    nxd::DevBuf counters, frame, traceStats;
+    nxd::DevBuf pixelMap, accumulation, rgba8;
+    nxd::DevBuf traceStats;
 
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
     bool statsEnabled = false;
@@ -109,11 +137,6 @@ struct nxhip_ctx {
     nxhip_kernel_times times{};
     std::vector<nxd::KernelTimer> timerPool;
     std::vector<int> timerClass;  // kernel class of timerPool[i]
-
-    // frame graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graphExec = nullptr;
-    bool graphValid = false;
 
     // multi-GPU tile split (nxhip_multigpu.hip): RCCL communicator (opaque), root-side gather / full-image buffers
     void* mgpuComm = nullptr;

@@ -126,12 +126,13 @@ NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pathIdx, uin
 }
 
 // ------------------------------------------------------------------------------------------------------
-// begin pass: the pass size (frames batched into this pass) arrives as a kernel argument and is published to the other
-// kernels through the device state, so a pass of a different size needs no host-side state upload or synchronisation;
-// frameNumber += frames, zero every counter, traceSize[0] = localCount * frames (GenerateKernel's thread 0 in the
-// reference, PathTracer.cu:112-113; the memset of PathTracer.cpp:263)
+// begin pass: the pass size (frames batched into this pass) and the number of its last frame arrive as kernel arguments and
+// are published to the other kernels through the device state, so neither a pass of a different size nor several passes
+// in flight (each in its own slot, numbered by the host) need a host-side state upload or a synchronisation.  Also: zero
+// every counter, traceSize[0] = localCount * frames (GenerateKernel's thread 0 in the reference, PathTracer.cu:112-113; the
+// memset of PathTracer.cpp:263; the frame counter of PathTracer.cpp:250).
 
-__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __restrict__ S, const uint32_t frames)
+__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __restrict__ S, const uint32_t frames, const uint32_t frameLast)
 {
     int* c = reinterpret_cast<int*>(S->counters);
     constexpr int n = (int)(sizeof(Counters) / sizeof(int));
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __
         S->framesPerPass = frames;
         S->pathCount = S->localCount * frames;
         S->counters->traceSize[0] = (int)(S->localCount * frames);
-        S->frame->frameNumber += frames;
+        S->frame->frameNumber = frameLast;
     }
 }
 

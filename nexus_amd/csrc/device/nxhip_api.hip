@@ -88,30 +88,72 @@ static int fail_invalid(const char* msg)
     return NXHIP_ERR_INVALID;
 }
 
+// slot k of the context: 0 is the context itself, k >= 1 the extra in-flight passes
+static PassSlot* slot_at(nxhip_ctx* c, uint32_t k) { return k == 0 ? static_cast<PassSlot*>(c) : c->extra[k - 1].get(); }
+static uint32_t slot_count(const nxhip_ctx* c) { return 1u + (uint32_t)c->extra.size(); }
+
+// Wait for everything the context has issued, on every slot's stream (scene edits, re-allocations, read-backs).
+static int sync_all(nxhip_ctx* c)
+{
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        PassSlot* s = slot_at(c, k);
+        if (s->stream) NX_HIP(hipStreamSynchronize(s->stream));
+    }
+    return NXHIP_OK;
+}
+#define NX_SYNC_ALL(c)                                  \
+    do {                                                \
+        const int rcSync_ = sync_all(c);                \
+        if (rcSync_ != NXHIP_OK) return rcSync_;        \
+    } while (0)
+
 static void invalidate_graph(nxhip_ctx* c)
 {
     // a replay may still be executing (render calls are asynchronous): destroying its exec, graph and timing events
     // under it is not allowed.  Not a hot path: settings / mode / timing changes only.
-    if (c->graphExec && c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graphExec = nullptr;
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        PassSlot* s = slot_at(c, k);
+        if (s->graphExec && s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
+        if (s->graph) (void)hipGraphDestroy(s->graph);
+        s->graphExec = nullptr;
+        s->graph = nullptr;
+        s->graphValid = false;
+    }
     for (auto& t : c->graphTimers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
     c->graphTimers.clear();
     c->graphTimerClass.clear();
-    c->graph = nullptr;
-    c->graphValid = false;
+}
+
+// The device-state block of a slot: the scene part of the host mirror plus the slot's own queues, counters and frame words.
+static void compose_view(nxhip_ctx* c, PassSlot* s)
+{
+    DeviceState& v = s->view;
+    v = c->h;
+    if (s != static_cast<PassSlot*>(c)) {
+        v.throughputPdf = s->throughputPdf.as<float4>();
+        v.radiance = s->radiance.as<float4>();
+        v.rayOrigin = s->rayOrigin.as<float4>();
+        v.trace = TraceQueue{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trHit.as<float4>(), s->trHitInst.as<uint32_t>()};
+        v.shadow = ShadowQueue{s->shRayO.as<float4>(), s->shRayD.as<float4>(), s->shRadiance.as<float4>()};
+        for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>(), s->mqPixel[m].as<uint32_t>()};
+    }
+    v.counters = s->counters.as<Counters>();
+    v.frame = s->frame.as<FrameState>();
 }
 
 static int upload_state(nxhip_ctx* c)
 {
     if (!c->stateDirty) return NXHIP_OK;
-    NX_HIP(hipMemcpyAsync(c->dState.p, &c->h, sizeof(DeviceState), hipMemcpyHostToDevice, c->stream));
-    // the host struct may be modified right after this call returns
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);  // no pass in flight may see half of an edit
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        PassSlot* s = slot_at(c, k);
+        compose_view(c, s);
+        NX_HIP(hipMemcpy(s->dState.p, &s->view, sizeof(DeviceState), hipMemcpyHostToDevice));
+    }
     c->stateDirty = false;
     return NXHIP_OK;
 }
@@ -120,30 +162,42 @@ static int upload_state(nxhip_ctx* c)
 // the new set is allocated beside the old one and swapped in only when every allocation has succeeded, so a failed
 // growth (out of device memory half-way through 25 buffers) leaves the context exactly as it was, still able to render
 // at its previous capacity.
-static int alloc_queues(nxhip_ctx* c, size_t n)
+static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
 {
-    DevBuf* const slots[] = {&c->throughputPdf, &c->radiance, &c->rayOrigin, &c->trRayO, &c->trRayD, &c->trHit, &c->trHitInst, &c->shRayO, &c->shRayD, &c->shRadiance,
-                             &c->mqHit[0], &c->mqDirInst[0], &c->mqPixel[0], &c->mqHit[1], &c->mqDirInst[1], &c->mqPixel[1],
-                             &c->mqHit[2], &c->mqDirInst[2], &c->mqPixel[2], &c->mqHit[3], &c->mqDirInst[3], &c->mqPixel[3]};
+    DevBuf* const slots[] = {&q->throughputPdf, &q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->shRayO, &q->shRayD, &q->shRadiance,
+                             &q->mqHit[0], &q->mqDirInst[0], &q->mqPixel[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqPixel[1],
+                             &q->mqHit[2], &q->mqDirInst[2], &q->mqPixel[2], &q->mqHit[3], &q->mqDirInst[3], &q->mqPixel[3]};
     const size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 4, 16, 16, 4, 16, 16, 4, 16, 16, 4};
     constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
     static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
     DevBuf fresh[kCount];
     for (int i = 0; i < kCount; i++)
         if (!fresh[i].alloc(n * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
-    NX_HIP(hipMemsetAsync(fresh[1].p, 0, n * 16, c->stream));     // radiance
-    NX_HIP(hipStreamSynchronize(c->stream));                      // nothing in flight may still use the old buffers
+    NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // radiance
+    NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
-    c->pathCapacity = n;
-    c->radianceBoundCapacity = 0;
-    DeviceState& h = c->h;
-    h.throughputPdf = c->throughputPdf.as<float4>();
-    h.radiance = c->radiance.as<float4>();
-    h.rayOrigin = c->rayOrigin.as<float4>();
-    h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
-    h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
-    for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
+    q->pathCapacity = n;
+    if (q == static_cast<PassSlot*>(c)) {
+        c->radianceBoundCapacity = 0;
+        DeviceState& h = c->h;
+        h.throughputPdf = c->throughputPdf.as<float4>();
+        h.radiance = c->radiance.as<float4>();
+        h.rayOrigin = c->rayOrigin.as<float4>();
+        h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
+        h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
+        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
+    }
     c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+// the same capacity in every slot (slot 0 last, so that a failure in an extra slot leaves slot 0 untouched)
+static int alloc_queues(nxhip_ctx* c, size_t n)
+{
+    for (uint32_t k = slot_count(c); k-- > 0;) {
+        const int rc = alloc_slot_queues(c, slot_at(c, k), n);
+        if (rc != NXHIP_OK) return rc;
+    }
     return NXHIP_OK;
 }
 
@@ -174,11 +228,12 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
     return NXHIP_OK;
 }
 
+// The frame counter lives on the host; every pass's begin_frame_kernel carries the number of its last frame.  Changing it
+// must not overtake passes already issued with the old numbering.
 static int set_frame_number_device(nxhip_ctx* c, uint32_t f)
 {
+    NX_SYNC_ALL(c);
     c->frameNumber = f;
-    NX_HIP(hipMemcpyAsync(&c->frame.as<FrameState>()->frameNumber, &c->frameNumber, 4, hipMemcpyHostToDevice, c->stream));
-    NX_HIP(hipStreamSynchronize(c->stream));
     return NXHIP_OK;
 }
 
@@ -297,9 +352,16 @@ void nxhip_destroy(nxhip_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     (void)nxhip_mgpu_shutdown(c);
     invalidate_graph(c);
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        PassSlot* q = slot_at(c, k);
+        if (q->done) (void)hipEventDestroy(q->done);
+        if (q->accumulated) (void)hipEventDestroy(q->accumulated);
+        if (k > 0 && q->ownsStream && q->stream) (void)hipStreamDestroy(q->stream);
+    }
+    c->extra.clear();
     for (auto& t : c->timerPool) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -312,7 +374,7 @@ void nxhip_destroy(nxhip_ctx* c)
 int nxhip_sync(nxhip_ctx* c)
 {
     NX_CHECK_CTX(c);
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     return NXHIP_OK;
 }
 
@@ -323,7 +385,7 @@ int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
     if ((uint64_t)width * height * c->framesPerPass > 0x7fffffffull)
         return fail_invalid("nxhip_resize: more than 2^31 paths (pixels x frames per pass): lower nxhip_set_frames_per_pass first");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     c->width = width;
     c->height = height;
     c->h.camera.resolution[0] = width;
@@ -358,7 +420,7 @@ static int refresh_blas_table(nxhip_ctx* c)
         table[i].nodeCount = b.nodeCount;
         table[i].triCount = b.triCount;
     }
-    NX_HIP(hipStreamSynchronize(c->stream));  // nothing may still read the old table
+    NX_SYNC_ALL(c);  // nothing may still read the old table
     NX_ALLOC(c->blasTable, table.size() * sizeof(BlasDev));
     NX_HIP(hipMemcpy(c->blasTable.p, table.data(), table.size() * sizeof(BlasDev), hipMemcpyHostToDevice));
     c->h.blas = c->blasTable.as<BlasDev>();
@@ -384,7 +446,7 @@ static int refresh_inst_trav(nxhip_ctx* c)
         trav[k].isect = c->blas[inst.bvhIdx].isect.as<float4>();
         trav[k].instIdx = i;
     }
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_ALLOC(c->instTrav, trav.size() * sizeof(InstTrav));
     NX_HIP(hipMemcpy(c->instTrav.p, trav.data(), trav.size() * sizeof(InstTrav), hipMemcpyHostToDevice));
     c->h.instTrav = c->instTrav.as<InstTrav>();
@@ -450,7 +512,7 @@ int nxhip_clear_blas(nxhip_ctx* c)
 try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     c->blas.clear();
     c->hostInstances.clear();
     c->hostInstIdx.clear();
@@ -482,7 +544,7 @@ try {
         if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_set_tlas: child index out of range");
         if (prims && (uint64_t)n.triangleBaseIdx + prims > instanceCount) return fail_invalid("nxhip_set_tlas: leaf range out of range");
     }
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
     NX_ALLOC(c->tlasNodes, padded.size() * sizeof(uint4));
     NX_ALLOC(c->tlasInstIdx, (size_t)instanceCount * 4);
@@ -544,6 +606,7 @@ try {
     NX_HIP(hipSetDevice(c->device));
     int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
+    if (slot_count(c) > 1) NX_SYNC_ALL(c);  // passes on the other slots' streams still traverse the old placement
     if (c->refitIds.bytes < (size_t)count * 4) NX_ALLOC(c->refitIds, (size_t)count * 4);
     if (c->refitMatrices.bytes < (size_t)count * 64) NX_ALLOC(c->refitMatrices, (size_t)count * 64);
     // stream order does the rest: a frame already in flight finishes with the old placement, the next one sees the new
@@ -573,7 +636,7 @@ try {
     }
     // pageable host arrays: the copies above are staged before hipMemcpyAsync returns on this runtime, but that is not a
     // documented guarantee — wait, the call is not on the per-frame path
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     for (uint32_t i = 0; i < count; i++) std::memcpy(c->hostInstances[instanceIds[i]].transform.cell, transforms16 + 16 * (size_t)i, 64);
     return NXHIP_OK;
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
@@ -587,7 +650,7 @@ int nxhip_read_tlas(nxhip_ctx* c, nx_bvh8_node* nodes, uint32_t nodeCapacity, nx
     if (!c->h.tlasNodes) return fail_invalid("nxhip_read_tlas: no TLAS has been set");
     if ((nodes && nodeCapacity < c->tlasNodeCount) || (instances && instanceCapacity < c->h.instanceCount)) return fail_invalid("nxhip_read_tlas: destination too small");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     if (nodes) {
         if (kNodeStride == 5) NX_HIP(hipMemcpy(nodes, c->tlasNodes.p, (size_t)c->tlasNodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
         else return fail_invalid("nxhip_read_tlas: built with padded node records");
@@ -601,7 +664,7 @@ try {
     NX_CHECK_CTX(c);
     if (!materials || count == 0) return fail_invalid("nxhip_set_materials: empty input");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_ALLOC(c->materials, (size_t)count * sizeof(nx_material));
     NX_HIP(hipMemcpy(c->materials.p, materials, (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
     c->hostMaterials.assign(materials, materials + count);
@@ -617,7 +680,7 @@ int nxhip_set_lights(nxhip_ctx* c, const nx_light* lights, uint32_t count)
 try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_ALLOC(c->lights, std::max<size_t>(1, count) * sizeof(nx_light));
     if (count) NX_HIP(hipMemcpy(c->lights.p, lights, (size_t)count * sizeof(nx_light), hipMemcpyHostToDevice));
     c->hostLights.assign(lights, lights + (lights ? count : 0));
@@ -641,7 +704,7 @@ static int refresh_texture_tables(nxhip_ctx* c)
         dst = table.as<TextureDev>();
         return NXHIP_OK;
     };
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     int rc = build(c->diffuseMaps, c->diffuseTable, c->h.diffuseMaps);
     if (rc != NXHIP_OK) return rc;
     rc = build(c->emissiveMaps, c->emissiveTable, c->h.emissiveMaps);
@@ -664,7 +727,7 @@ try {
     int32_t id = 0;
     if (kind == 0) { c->diffuseMaps.push_back(std::move(t)); id = (int32_t)c->diffuseMaps.size() - 1; }
     else if (kind == 1) { c->emissiveMaps.push_back(std::move(t)); id = (int32_t)c->emissiveMaps.size() - 1; }
-    else { NX_HIP(hipStreamSynchronize(c->stream)); c->hdrMap = std::move(t); }
+    else { NX_SYNC_ALL(c); c->hdrMap = std::move(t); }
     if (texId) *texId = id;
     return refresh_texture_tables(c);
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
@@ -676,7 +739,7 @@ int nxhip_clear_textures(nxhip_ctx* c)
 try {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     c->diffuseMaps.clear();
     c->emissiveMaps.clear();
     c->hdrMap = TextureHost();
@@ -725,7 +788,7 @@ int nxhip_set_pixel_map(nxhip_ctx* c, const uint32_t* pixelMap, uint32_t localCo
 {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     const uint32_t full = c->width * c->height;
     // the queues are re-allocated first (all or nothing): a failure leaves the previous pixel set, map and queues in place
     if (!pixelMap) {
@@ -817,20 +880,20 @@ Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceS
 
 // Every pass starts with begin_frame_kernel, launched outside the graph because its argument (the pass size) may change from
 // pass to pass.
-int launch_begin_frame(nxhip_ctx* c)
+int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t frameLast)
 {
-    DeviceState* S = c->dState.as<DeviceState>();
-    uint32_t frames = c->framesPerPass;
-    void* args[2] = {(void*)&S, (void*)&frames};
-    NX_HIP(hipLaunchKernel(begin_frame_kernel_ptr(), dim3(1), dim3(kWideBlockThreads), args, 0, c->stream));
+    DeviceState* S = q->dState.as<DeviceState>();
+    void* args[3] = {(void*)&S, (void*)&frames, (void*)&frameLast};
+    NX_HIP(hipLaunchKernel(begin_frame_kernel_ptr(), dim3(1), dim3(kWideBlockThreads), args, 0, q->stream));
+    (void)c;
     return NXHIP_OK;
 }
 
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
-std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c)
+std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
 {
-    const DeviceState* S = c->dState.as<DeviceState>();
+    const DeviceState* S = q->dState.as<DeviceState>();
     const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
     const bool stats = c->statsEnabled;
     const int wide = c->wideBlocks;
@@ -889,12 +952,22 @@ int launch_now(nxhip_ctx* c, Launch& l)
 
 }  // namespace
 
-static int build_graph(nxhip_ctx* c)
+// The pass graph of one slot.  Timing nodes (event records around every kernel) exist only in slot 0: kernel timing runs
+// one pass at a time.
+static int build_graph(nxhip_ctx* c, PassSlot* q)
 {
-    invalidate_graph(c);
-    NX_HIP(hipGraphCreate(&c->graph, 0));
-    const bool timed = c->timingMode >= 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
-    auto levels = frame_levels(c);
+    const bool isMain = q == static_cast<PassSlot*>(c);
+    if (isMain) invalidate_graph(c);  // also drops the graphs of the other slots: they are rebuilt on their next use
+    else if (q->graphExec) {
+        (void)hipStreamSynchronize(q->stream);
+        (void)hipGraphExecDestroy(q->graphExec);
+        (void)hipGraphDestroy(q->graph);
+        q->graphExec = nullptr;
+        q->graph = nullptr;
+    }
+    NX_HIP(hipGraphCreate(&q->graph, 0));
+    const bool timed = isMain && c->timingMode >= 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
+    auto levels = frame_levels(c, q);
     std::vector<hipGraphNode_t> prev;
     for (auto& level : levels) {
         std::vector<hipGraphNode_t> cur;
@@ -917,19 +990,38 @@ static int build_graph(nxhip_ctx* c)
                 NX_HIP(hipEventCreate(&t.start));
                 NX_HIP(hipEventCreate(&t.stop));
                 hipGraphNode_t before, after;
-                NX_HIP(hipGraphAddEventRecordNode(&before, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start));
-                NX_HIP(hipGraphAddKernelNode(&node, c->graph, &before, 1, &p));
-                NX_HIP(hipGraphAddEventRecordNode(&after, c->graph, &node, 1, t.stop));
+                NX_HIP(hipGraphAddEventRecordNode(&before, q->graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start));
+                NX_HIP(hipGraphAddKernelNode(&node, q->graph, &before, 1, &p));
+                NX_HIP(hipGraphAddEventRecordNode(&after, q->graph, &node, 1, t.stop));
                 cur.push_back(after);
             } else {
-                NX_HIP(hipGraphAddKernelNode(&node, c->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
+                NX_HIP(hipGraphAddKernelNode(&node, q->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
                 cur.push_back(node);
             }
         }
         prev.swap(cur);
     }
-    NX_HIP(hipGraphInstantiate(&c->graphExec, c->graph, nullptr, nullptr, 0));
-    c->graphValid = true;
+    NX_HIP(hipGraphInstantiate(&q->graphExec, q->graph, nullptr, nullptr, 0));
+    q->graphValid = true;
+    return NXHIP_OK;
+}
+
+// Passes in flight right now: kernel timing and the counting variant measure one pass at a time, and a caller-bound
+// radiance buffer exists once.
+static uint32_t effective_slots(const nxhip_ctx* c)
+{
+    if (c->timingEnabled || c->statsEnabled || c->radianceBoundCapacity != 0) return 1u;
+    return std::min<uint32_t>(c->passesInFlight, (uint32_t)c->extra.size());
+}
+// Where pass number i of the round robin renders.  One pass at a time: the context itself, on its own stream.  R > 1: the R
+// extra slots, each on a stream of its own — the context's stream then only carries the accumulates (and whatever the caller
+// puts behind them, e.g. the multi-GPU gather), so that no pass ever queues behind the accumulate of its predecessor.
+static PassSlot* render_slot(nxhip_ctx* c, uint32_t R, uint32_t i) { return R <= 1 ? static_cast<PassSlot*>(c) : c->extra[i].get(); }
+
+static int ensure_slot_events(PassSlot* q)
+{
+    if (!q->done) NX_HIP(hipEventCreateWithFlags(&q->done, hipEventDisableTiming));
+    if (!q->accumulated) NX_HIP(hipEventCreateWithFlags(&q->accumulated, hipEventDisableTiming));
     return NXHIP_OK;
 }
 
@@ -943,11 +1035,31 @@ try {
     if (rc != NXHIP_OK) return rc;
     rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    rc = launch_begin_frame(c);
+    // the slot this pass renders in: round robin over the passes in flight (one slot: everything on the context's stream,
+    // exactly the single-pass behaviour)
+    const uint32_t R = std::max(1u, effective_slots(c));
+    if (c->nextSlot >= R) c->nextSlot = 0;
+    PassSlot* q = render_slot(c, R, c->nextSlot);
+    c->nextSlot = (c->nextSlot + 1) % R;
+    const uint32_t frames = c->framesPerPass, frameLast = c->frameNumber + frames;
+    if (R > 1) {
+        rc = ensure_slot_events(q);
+        if (rc != NXHIP_OK) return rc;
+        // the slot's previous pass must have been consumed by its accumulate before its radiance is overwritten
+        if (q->accumulateRecorded) {
+            NX_HIP(hipStreamWaitEvent(q->stream, q->accumulated, 0));
+            q->accumulateRecorded = false;
+        }
+    }
+    if (q->awaitingAccumulate) {  // rendered again without an accumulate in between: the older pass is dropped
+        c->pending.erase(std::remove(c->pending.begin(), c->pending.end(), q), c->pending.end());
+        q->awaitingAccumulate = false;
+    }
+    rc = launch_begin_frame(c, q, frames, frameLast);
     if (rc != NXHIP_OK) return rc;
     if (c->timingEnabled && c->timingMode == 1) {
         // eager path: one event pair per launch, launches strictly in level order on one stream
-        auto levels = frame_levels(c);
+        auto levels = frame_levels(c, q);
         for (auto& level : levels)
             for (auto& l : level) {
                 const size_t before = c->timerPool.size();
@@ -956,15 +1068,15 @@ try {
                 if (c->timerPool.size() > before) c->timerClass.push_back(l.klass);
             }
     } else {
-        if (!c->graphValid) {
-            rc = build_graph(c);
+        if (!q->graphValid) {
+            rc = build_graph(c, q);
             if (rc != NXHIP_OK) return rc;
         }
-        NX_HIP(hipGraphLaunch(c->graphExec, c->stream));
+        NX_HIP(hipGraphLaunch(q->graphExec, q->stream));
         if (c->timingMode == 3) c->graphTimersPending = true;  // read at nxhip_read_kernel_times: the last replay only
         if (c->timingMode == 2) {
             // the graph's events are re-recorded by the next replay: read them now (timing mode is not the fast path)
-            NX_HIP(hipStreamSynchronize(c->stream));
+            NX_SYNC_ALL(c);
             for (size_t i = 0; i < c->graphTimers.size(); i++) {
                 float ms = 0.0f;
                 NX_HIP(hipEventElapsedTime(&ms, c->graphTimers[i].start, c->graphTimers[i].stop));
@@ -973,17 +1085,24 @@ try {
             }
         }
     }
-    c->frameNumber += c->framesPerPass;
+    if (R > 1) NX_HIP(hipEventRecord(q->done, q->stream));
+    q->frames = frames;
+    q->frameLast = frameLast;
+    q->awaitingAccumulate = true;
+    c->pending.push_back(q);
+    c->lastRendered = q;
+    c->frameNumber = frameLast;
     return NXHIP_OK;
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_render_frame: ") + e.what());
     return NXHIP_ERR_INVALID;
 }
 
-static int launch_accumulate(nxhip_ctx* c, const float4* src, uint32_t count, uint32_t slices, uint32_t sliceStride, uint32_t firstFrame,
+// AccumulateKernel on the context's (main) stream, reading `stateSlot`'s device state (its radiance, pass size, frame number).
+static int launch_accumulate(nxhip_ctx* c, PassSlot* stateSlot, const float4* src, uint32_t count, uint32_t slices, uint32_t sliceStride, uint32_t firstFrame,
                              const uint32_t* dstMap)
 {
-    Launch l = make_launch(accumulate_kernel_ptr(), c->wideBlocks, kWideBlockThreads, NXHIP_K_ACCUMULATE, c->dState.as<DeviceState>());
+    Launch l = make_launch(accumulate_kernel_ptr(), c->wideBlocks, kWideBlockThreads, NXHIP_K_ACCUMULATE, stateSlot->dState.as<DeviceState>());
     l.nargs = 7;
     l.src = src;
     l.count = count;
@@ -1001,9 +1120,67 @@ int nxhip_accumulate(nxhip_ctx* c)
 {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    const int rc = upload_state(c);
+    int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, nullptr, c->localCount, 0u, 0u, 0u, nullptr);
+    if (c->pending.empty()) {
+        // nothing rendered since the last accumulate: the reference's AccumulateKernel would fold the same radiance in again
+        PassSlot* q = c->lastRendered ? c->lastRendered : static_cast<PassSlot*>(c);
+        return launch_accumulate(c, q, nullptr, c->localCount, 0u, 0u, 0u, nullptr);
+    }
+    // every rendered pass, oldest first (the running mean is order dependent); all on the context's stream, each after
+    // its pass has finished on the slot's stream
+    for (PassSlot* q : c->pending) {
+        const bool other = q->stream != c->stream;
+        if (other) NX_HIP(hipStreamWaitEvent(c->stream, q->done, 0));
+        rc = launch_accumulate(c, q, nullptr, c->localCount, 0u, 0u, 0u, nullptr);
+        if (rc != NXHIP_OK) return rc;
+        if (other) {
+            NX_HIP(hipEventRecord(q->accumulated, c->stream));
+            q->accumulateRecorded = true;
+        }
+        q->awaitingAccumulate = false;
+    }
+    c->pending.clear();
+    return NXHIP_OK;
+}
+
+// Passes in flight (default 1).  R > 1: consecutive nxhip_render_frame calls go to R slots round robin, each with its own
+// queues, stream and graph instance; nxhip_accumulate folds the finished passes into the one accumulation in order.
+int nxhip_set_passes_in_flight(nxhip_ctx* c, uint32_t passes)
+try {
+    NX_CHECK_CTX(c);
+    if (passes == 0 || passes > 8) return fail_invalid("nxhip_set_passes_in_flight: passes must be in [1, 8]");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    while (passes > 1 && c->extra.size() < passes) {
+        std::unique_ptr<PassSlot> q(new PassSlot());
+        NX_HIP(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+        q->ownsStream = true;
+        if (!q->dState.alloc(sizeof(DeviceState)) || !q->counters.alloc(sizeof(Counters)) || !q->frame.alloc(sizeof(FrameState))) {
+            (void)hipStreamDestroy(q->stream);
+            return NXHIP_ERR_HIP;
+        }
+        NX_HIP(hipMemset(q->counters.p, 0, sizeof(Counters)));
+        FrameState fs{0u, -1, -1, 0u};
+        NX_HIP(hipMemcpy(q->frame.p, &fs, sizeof fs, hipMemcpyHostToDevice));
+        const int rc = alloc_slot_queues(c, q.get(), std::max<size_t>(c->pathCapacity, 1));
+        if (rc != NXHIP_OK) {
+            (void)hipStreamDestroy(q->stream);
+            return rc;
+        }
+        c->extra.push_back(std::move(q));
+    }
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        const int rc = ensure_slot_events(slot_at(c, k));
+        if (rc != NXHIP_OK) return rc;
+    }
+    c->passesInFlight = passes;
+    c->nextSlot = 0;
+    c->stateDirty = true;
+    return NXHIP_OK;
+} catch (const std::exception& e) {
+    set_error(std::string("nxhip_set_passes_in_flight: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
@@ -1018,7 +1195,7 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
         // grow only: a later, smaller pass (e.g. the remainder of a frame budget) reuses the buffers.  The frame counter
         // and the accumulation are left alone: a pass size is a scheduling choice, not a new image.
         NX_HIP(hipSetDevice(c->device));
-        NX_HIP(hipStreamSynchronize(c->stream));
+        NX_SYNC_ALL(c);
         float4* const boundPtr = c->h.radiance;
         const size_t boundCap = c->radianceBoundCapacity;
         const int rc = alloc_queues(c, n);
@@ -1041,7 +1218,7 @@ int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
 {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     if (radianceDevice) {
         if (capacity < c->pathCount) return fail_invalid("nxhip_bind_radiance: buffer smaller than localCount * framesPerPass");
         c->h.radiance = static_cast<float4*>(radianceDevice);
@@ -1065,7 +1242,7 @@ int nxhip_read_full_rgba8(nxhip_ctx* c, uint32_t* dst)
     NX_CHECK_CTX(c);
     if (!dst) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(dst, c->rgba8.p, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
@@ -1079,7 +1256,7 @@ int nxhip_accumulate_external(nxhip_ctx* c, const void* src, uint32_t count, uin
     NX_HIP(hipSetDevice(c->device));
     const int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
-    return launch_accumulate(c, static_cast<const float4*>(src), count, slices, sliceStride, firstFrame, static_cast<const uint32_t*>(srcPixelMapDevice));
+    return launch_accumulate(c, c, static_cast<const float4*>(src), count, slices, sliceStride, firstFrame, static_cast<const uint32_t*>(srcPixelMapDevice));
 }
 
 int nxhip_compose_tiles(nxhip_ctx* c, const void* srcAccumulation, uint32_t count, const void* srcPixelMapDevice, void* dstAccumulationDevice,
@@ -1119,7 +1296,7 @@ static int read_float4_as_float3(nxhip_ctx* c, const void* dev, uint32_t count, 
 try {
     if (!dst) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     std::vector<float4> tmp(count);
     NX_HIP(hipMemcpy(tmp.data(), dev, (size_t)count * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < count; i++) {
@@ -1136,7 +1313,10 @@ try {
 int nxhip_read_radiance(nxhip_ctx* c, float* dst)
 {
     NX_CHECK_CTX(c);
-    return read_float4_as_float3(c, c->h.radiance, c->pathCount, dst);
+    // the pass rendered last (with several passes in flight: the newest one's slot)
+    const PassSlot* q = c->lastRendered ? c->lastRendered : static_cast<PassSlot*>(c);
+    const void* src = q == static_cast<PassSlot*>(c) ? (const void*)c->h.radiance : (const void*)q->radiance.p;
+    return read_float4_as_float3(c, src, c->pathCount, dst);
 }
 
 int nxhip_read_accumulation(nxhip_ctx* c, float* dst)
@@ -1150,7 +1330,7 @@ try {
     NX_CHECK_CTX(c);
     if (!src) return fail_invalid("nxhip_write_accumulation: null source");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     std::vector<float4> tmp(c->localCount);
     for (uint32_t i = 0; i < c->localCount; i++) tmp[i] = make_float4(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2], 0.0f);
     NX_HIP(hipMemcpy(c->accumulation.p, tmp.data(), (size_t)c->localCount * 16, hipMemcpyHostToDevice));
@@ -1165,7 +1345,7 @@ int nxhip_read_rgba8(nxhip_ctx* c, uint32_t* dst)
     NX_CHECK_CTX(c);
     if (!dst) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(dst, c->rgba8.p, (size_t)c->localCount * 4, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
@@ -1178,9 +1358,9 @@ int nxhip_read_queue_sizes(nxhip_ctx* c, nxhip_queue_sizes* out)
     NX_CHECK_CTX(c);
     if (!out) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     Counters h;
-    NX_HIP(hipMemcpy(&h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    NX_HIP(hipMemcpy(&h, (c->lastRendered ? c->lastRendered : static_cast<PassSlot*>(c))->counters.p, sizeof h, hipMemcpyDeviceToHost));
     std::memcpy(out->traceSize, h.traceSize, sizeof h.traceSize);
     std::memcpy(out->traceShadowSize, h.traceShadowSize, sizeof h.traceShadowSize);
     std::memcpy(out->diffuseSize, h.materialSize[NX_MAT_DIFFUSE], sizeof h.traceSize);
@@ -1196,8 +1376,8 @@ int nxhip_set_pixel_query(nxhip_ctx* c, uint32_t x, uint32_t y)
     if (x >= c->width || y >= c->height) return fail_invalid("nxhip_set_pixel_query: pixel outside the viewport");
     NX_HIP(hipSetDevice(c->device));
     const int32_t q[2] = {(int32_t)(c->width * y + x), -1};
-    NX_HIP(hipMemcpyAsync(&c->frame.as<FrameState>()->pixelQueryPixel, q, 8, hipMemcpyHostToDevice, c->stream));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
+    for (uint32_t k = 0; k < slot_count(c); k++) NX_HIP(hipMemcpy(&slot_at(c, k)->frame.as<FrameState>()->pixelQueryPixel, q, 8, hipMemcpyHostToDevice));
     return NXHIP_OK;
 }
 
@@ -1206,8 +1386,8 @@ int nxhip_get_selected_instance(nxhip_ctx* c, int32_t* instanceIdx)
     NX_CHECK_CTX(c);
     if (!instanceIdx) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
-    NX_HIP(hipMemcpy(instanceIdx, &c->frame.as<FrameState>()->pixelQueryInstance, 4, hipMemcpyDeviceToHost));
+    NX_SYNC_ALL(c);
+    NX_HIP(hipMemcpy(instanceIdx, &(c->lastRendered ? c->lastRendered : static_cast<PassSlot*>(c))->frame.as<FrameState>()->pixelQueryInstance, 4, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
 
@@ -1257,7 +1437,7 @@ try {
         if (rc != NXHIP_OK) return rc;
         NX_HIP(hipMemcpyAsync(h.data(), c->trHit.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
         NX_HIP(hipMemcpyAsync(hi.data(), c->trHitInst.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        NX_HIP(hipStreamSynchronize(c->stream));
+        NX_SYNC_ALL(c);
         for (uint32_t i = 0; i < n; i++) {
             nx_hit& out = hits[first + i];
             out.hitDistance = h[i].x;
@@ -1302,7 +1482,7 @@ try {
         rc = run_trace_chunk(c, true, n);
         if (rc != NXHIP_OK) return rc;
         NX_HIP(hipMemcpyAsync(res.data(), c->h.radiance, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-        NX_HIP(hipStreamSynchronize(c->stream));
+        NX_SYNC_ALL(c);
         for (uint32_t i = 0; i < n; i++) occluded[first + i] = res[i].x == 1.0f ? 0 : 1;
     }
     return NXHIP_OK;
@@ -1323,7 +1503,7 @@ int nxhip_read_trace_stats(nxhip_ctx* c, nxhip_trace_stats* closest, nxhip_trace
 {
     NX_CHECK_CTX(c);
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     TraceStatsDev h[2];
     NX_HIP(hipMemcpy(h, c->traceStats.p, sizeof h, hipMemcpyDeviceToHost));
     static_assert(sizeof(nxhip_trace_stats) == sizeof(TraceStatsDev), "stats layouts must match");
@@ -1351,7 +1531,7 @@ static int bsdf_hook(nxhip_ctx* c, const nx_material* material, const nx_bsdf_qu
     nx_bsdf_result* pr = dR.as<nx_bsdf_result>();
     void* args[5] = {(void*)&pm, (void*)&pq, (void*)&count, (void*)&sample, (void*)&pr};
     NX_HIP(hipLaunchKernel(bsdf_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(results, dR.p, (size_t)count * sizeof(nx_bsdf_result), hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
@@ -1387,7 +1567,7 @@ int nxhip_tex2d_batch(nxhip_ctx* c, int kind, int textureId, const float* uv, ui
     float4* po = dOut.as<float4>();
     void* args[5] = {(void*)&t, (void*)&lut, (void*)&pu, (void*)&count, (void*)&po};
     NX_HIP(hipLaunchKernel(tex2d_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(rgba, dOut.p, (size_t)count * 16, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
@@ -1408,7 +1588,7 @@ int nxhip_read_kernel_times(nxhip_ctx* c, nxhip_kernel_times* out, int reset)
     NX_CHECK_CTX(c);
     if (!out) return fail_invalid("null destination");
     NX_HIP(hipSetDevice(c->device));
-    NX_HIP(hipStreamSynchronize(c->stream));
+    NX_SYNC_ALL(c);
     for (size_t i = 0; i < c->timerPool.size(); i++) {
         float ms = 0.0f;
         NX_HIP(hipEventElapsedTime(&ms, c->timerPool[i].start, c->timerPool[i].stop));

@@ -394,3 +394,31 @@ def test_ragged_viewports_and_extreme_path_lengths(gpu_ctx_factory, W, H, path_l
         full = np.zeros_like(rad[f])
         full[pm] = rad[f]
         assert np.array_equal(full.view(np.uint32), got[f].view(np.uint32)), f
+
+
+def test_passes_in_flight_render_the_same_image(gpu_ctx_factory):
+    """nxhip_set_passes_in_flight: consecutive passes run concurrently in their own slots (queues, stream, graph instance) and
+    are folded into the one accumulation in order — accumulation, last radiance, queue sizes and pixel query are bit-identical
+    to one pass at a time, also with pass sizes that change on the way."""
+    W, H = 96, 64
+    scene = SH.material_zoo_scene(W, H, path_length=4)
+    schedule = [2, 2, 1, 3, 2, 2, 2, 1]
+    results = []
+    for R in (1, 3, 4):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+        ctx.set_frames_per_pass(3)
+        ctx.set_passes_in_flight(R)
+        ctx.set_pixel_query(40, 30)
+        for i, n in enumerate(schedule):
+            ctx.set_frames_per_pass(n)
+            ctx.render_frame()
+            ctx.accumulate()
+        results.append((ctx.read_accumulation(), ctx.read_rgba8(), ctx.read_radiance(), ctx.read_queue_sizes()["traceSize"][:5].copy(), ctx.get_selected_instance(),
+                        ctx.frame_number()))
+    for got in results[1:]:
+        assert np.array_equal(got[0].view(np.uint32), results[0][0].view(np.uint32))
+        assert np.array_equal(got[1], results[0][1])
+        assert np.array_equal(got[2].view(np.uint32), results[0][2].view(np.uint32))
+        assert np.array_equal(got[3], results[0][3]) and got[4] == results[0][4] and got[5] == results[0][5] == sum(schedule)

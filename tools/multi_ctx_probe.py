@@ -36,9 +36,9 @@ def run(ctxs, passes, S):
     return round(W * H * frames / dt / 1e6, 1), round(dt / frames * 1e3, 3)
 
 
-for S, passes in ((1, 16), (5, 8)):
+for S, passes in ((10, 6), (7, 6), (20, 4)):
     ctxs = []
-    for K in (4, 6, 8):
+    for K in (1, 2, 3):
         while len(ctxs) < K:
             ctxs.append(make(S))
         print("S", S, "contexts", K, run(ctxs, passes, S), flush=True)
