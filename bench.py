@@ -76,8 +76,8 @@ def build_workload(args):
     return sc, name, time.time() - t0
 
 
-def upload(ctx, sc):
-    sc.upload(ctx)
+def upload(ctx, sc, device_bvh=False):
+    sc.upload(ctx, device_bvh=device_bvh)
     ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
 
 
@@ -133,6 +133,8 @@ def main():
                     help="passes rendered concurrently on separate streams (nxhip_set_passes_in_flight): the drain of one pass overlaps the bulk of the next. "
                          "Default: 3 when the timed region has at least 3 passes, else 1")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
+    ap.add_argument("--device-bvh", action="store_true", help="build the BLASes on the GPU (nxhip_build_blas, LBVH) instead of uploading the host SAH builder's: "
+                                                              "a faster build, a tree of lower quality; not the metric's configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -209,7 +211,7 @@ def main():
         ctx = capi.Context(W, H, device=dev, stream=side.cuda_stream)
     else:
         ctx = capi.Context(W, H, device=0)
-    upload(ctx, sc)
+    upload(ctx, sc, device_bvh=args.device_bvh)
 
     if dist_mode:
         pm = tile_pixel_map(W, H, rank, world)
@@ -329,7 +331,7 @@ def main():
             "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order,
             "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
-            "host_scene_build_s": round(t_build, 2),
+            "host_scene_build_s": round(t_build, 2), "blas_builder": "device LBVH (nxhip_build_blas)" if args.device_bvh else "host binned-SAH + SAH-DP collapse (the reference's algorithm)",
         },
     }
 

@@ -51,6 +51,17 @@ int nxhip_sync(nxhip_ctx *ctx);
  * (symbol `bvhs`).  Returns the BLAS id == index instances refer to as bvhIdx.  ids are dense from 0. */
 int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const nx_triangle *tris,
                       uint32_t triCount, const uint32_t *triIdx, int32_t *blasId);
+/* BLAS built ON THE DEVICE from triangles alone: 63-bit Morton codes, radix sort, Karras' binary
+ * radix tree, bottom-up bounds, then a level-by-level collapse into the same 80-byte nodes (children opened by largest
+ * surface area, leaf slots of at most three triangles, the reference's octant slot assignment and quantisation).  Replaces
+ * BVH2::Build + BVH8Builder::Init / Build + BVH8::InitDeviceData (Geometry/BVH/BVH.cpp:13-210, BVH8Builder.cpp:10-393,
+ * BVH8.cpp:28-33) when build time matters more than tree quality: a valid, conservative CWBVH whose node bytes differ from
+ * the SAH builder's (another tree); hit records are the same up to equidistant ties, traversal visits more nodes.  Returns
+ * the BLAS id like nxhip_upload_blas. */
+int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount, int32_t *blasId);
+/* Read a BLAS's nodes / primitive index list back (either may be NULL; *nodeCount = nodes it has). */
+int nxhip_read_blas(nxhip_ctx *ctx, int32_t blasId, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *primIdx, uint32_t primCapacity,
+                    uint32_t *nodeCount);
 int nxhip_clear_blas(nxhip_ctx *ctx);
 /* TLAS::UpdateDeviceData — Geometry/BVH/TLAS.cpp:93-100 (symbols `tlas`, `blas`). */
 int nxhip_set_tlas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const uint32_t *instanceIdx,

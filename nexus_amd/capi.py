@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
-    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_build_blas", "nxhip_read_blas",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
 ]
@@ -473,6 +473,23 @@ class Context:
             pm = np.ascontiguousarray(pixel_map, dtype=np.uint32)
             check(self.L.nxhip_set_pixel_map(self.h, _ptr(pm), len(pm)), "nxhip_set_pixel_map")
             self.local_count = len(pm)
+
+    def build_blas(self, tris):
+        """BLAS built on the device (LBVH + wide collapse); returns the BLAS id"""
+        t = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+        bid = C.c_int32(-1)
+        self.L.nxhip_build_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+        check(self.L.nxhip_build_blas(self.h, _ptr(t), len(t), C.byref(bid)), "nxhip_build_blas")
+        return int(bid.value)
+
+    def read_blas(self, blas_id, tri_count):
+        self.L.nxhip_read_blas.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        n = C.c_uint32(0)
+        check(self.L.nxhip_read_blas(self.h, blas_id, None, 0, None, 0, C.byref(n)), "nxhip_read_blas")
+        nodes = np.zeros(n.value, dtype=pod.NODE_DT)
+        idx = np.zeros(tri_count, dtype=np.uint32)
+        check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
+        return nodes, idx
 
     def set_instance_transforms(self, instance_ids, transforms16):
         """move existing instances on the device (inverse, bounds, traversal records, TLAS refit): no scene re-upload"""

@@ -1,0 +1,450 @@
+// nx_lbvh.hip — BLAS construction on the device: triangles in HBM -> compressed wide BVH (the same 80-byte nodes and
+// primitive-index list the host builders and the reference produce, /root/reference/Nexus/src/Geometry/BVH/BVH8.h:24-49).
+//
+// SURVEY.md section 8 row f1.  The reference builds on one CPU thread (binned-SAH BVH2, BVH.cpp:65-210, then the SAH-DP
+// collapse of BVH8Builder.cpp:63-117, 273-393: ~10 s per million triangles); the host builder of this repo is the same
+// algorithm task-parallel (0.4 s per million).  This is the GPU path for scenes where even that dominates time to first
+// frame (10 M triangles replicated on 8 ranks): a linear BVH — 63-bit Morton codes of the centroids, one radix sort, the
+// binary radix tree of Karras 2012 with every internal node found independently, bounds fitted bottom-up with one arrival
+// counter per node — collapsed top-down, level by level, into 8-wide nodes: each node starts from the two children of its
+// BVH2 root and keeps opening the child with the largest surface area until it has eight; children that hold at most
+// three triangles become leaf slots.  Children are assigned to octant slots with the reference's greedy rule
+// (BVH8Builder.cpp:170-252) and quantised exactly as the host builder does (8-bit grid, floor / ceil, power-of-two scale).
+// The tree is a valid, conservative CWBVH for the unchanged traversal kernels; its node bytes differ from the SAH builder's
+// (a different tree): hits are identical, traversal visits more nodes (quality is the price of the build speed).
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "nx_context.h"
+#include "nx_math.h"
+
+namespace nxd {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Box3 {
+    float lo[3], hi[3];
+};
+
+__device__ __forceinline__ uint32_t float_ordered(float f)  // monotone float -> uint map for atomicMin / atomicMax
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_float(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// ---- 1. per-triangle boxes, centroid bounds ---------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) tri_bounds_kernel(const nx_triangle* __restrict__ tris, const uint32_t n, Box3* __restrict__ triBox, uint32_t* __restrict__ sceneBounds)
+{
+    float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const nx_triangle t = tris[i];
+        Box3 b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = fminf(fminf(t.pos0[a], t.pos1[a]), t.pos2[a]);
+            b.hi[a] = fmaxf(fmaxf(t.pos0[a], t.pos1[a]), t.pos2[a]);
+            const float c = 0.5f * (b.lo[a] + b.hi[a]);
+            cl[a] = fminf(cl[a], c);
+            ch[a] = fmaxf(ch[a], c);
+        }
+        triBox[i] = b;
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            cl[a] = fminf(cl[a], __shfl_down(cl[a], o));
+            ch[a] = fmaxf(ch[a], __shfl_down(ch[a], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&sceneBounds[a], float_ordered(cl[a]));
+            atomicMax(&sceneBounds[3 + a], float_ordered(ch[a]));
+        }
+    }
+}
+
+// ---- 2. 63-bit Morton codes of the box centres --------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long spread21(uint32_t v)  // 21 bits -> every third bit
+{
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(kBlock) morton_kernel(const Box3* __restrict__ triBox, const uint32_t n, const uint32_t* __restrict__ sceneBounds,
+                                                        unsigned long long* __restrict__ codes, uint32_t* __restrict__ order)
+{
+    float lo[3], inv[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = ordered_float(sceneBounds[a]);
+        const float ext = ordered_float(sceneBounds[3 + a]) - lo[a];
+        inv[a] = ext > 0.0f ? 2097151.0f / ext : 0.0f;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Box3 b = triBox[i];
+        uint32_t q[3];
+        for (int a = 0; a < 3; a++) q[a] = (uint32_t)fminf(fmaxf((0.5f * (b.lo[a] + b.hi[a]) - lo[a]) * inv[a], 0.0f), 2097151.0f);
+        codes[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+        order[i] = i;
+    }
+}
+
+// ---- 3. binary radix tree (Karras 2012): internal nodes 0 .. n-2, leaf k = node n-1+k (k = position in the sorted order)
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ codes, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = codes[i], b = codes[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);  // equal codes: the index breaks the tie
+    return __clzll((long long)(a ^ b));
+}
+
+struct Bvh2 {
+    int* left;     // [n-1] child node ids (>= n-1: leaf)
+    int* right;
+    int* parent;   // [2n-1]
+    int* first;    // [n-1] range of sorted positions covered by the internal node
+    int* last;
+    Box3* box;     // [2n-1]
+    int* arrived;  // [n-1]
+};
+
+__global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long long* __restrict__ codes, const int n, Bvh2 t)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+        const int d = delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1) >= 0 ? 1 : -1;
+        const int dmin = delta(codes, n, i, i - d);
+        int lmax = 2;
+        while (delta(codes, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int s = lmax / 2; s >= 1; s /= 2)
+            if (delta(codes, n, i, i + (l + s) * d) > dmin) l += s;
+        const int j = i + l * d;
+        const int dnode = delta(codes, n, i, j);
+        int s = 0, step = l;
+        do {  // binary search for the split: step = ceil(l / 2), ceil(l / 4), ... 1
+            step = (step + 1) >> 1;
+            if (delta(codes, n, i, i + (s + step) * d) > dnode) s += step;
+        } while (step > 1);
+        const int gamma = i + s * d + (d < 0 ? -1 : 0);
+        const int lo = d > 0 ? i : j, hi = d > 0 ? j : i;
+        const int leftNode = lo == gamma ? (n - 1) + gamma : gamma;
+        const int rightNode = hi == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
+        t.left[i] = leftNode;
+        t.right[i] = rightNode;
+        t.first[i] = lo;
+        t.last[i] = hi;
+        t.parent[leftNode] = i;
+        t.parent[rightNode] = i;
+        if (i == 0) t.parent[0] = -1;
+    }
+}
+
+__device__ __forceinline__ Box3 load_fresh(const Box3* p)  // written by another thread of this launch: no register / L1 reuse
+{
+    const volatile float* v = reinterpret_cast<const volatile float*>(p);
+    Box3 b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = v[a]; b.hi[a] = v[3 + a]; }
+    return b;
+}
+
+// ---- 4. bounds, bottom-up: the second child to arrive at a node computes it and carries on
+__global__ void __launch_bounds__(kBlock) fit_kernel(const Box3* __restrict__ triBox, const uint32_t* __restrict__ order, const int n, Bvh2 t)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int leaf = (n - 1) + k;
+        t.box[leaf] = triBox[order[k]];
+        int node = n > 1 ? t.parent[leaf] : -1;
+        while (node >= 0) {
+            __threadfence();  // this thread's child box is visible before its arrival is
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back must have completed: MI355X_MICROARCH.md, compiler hazard)
+            if (atomicAdd(&t.arrived[node], 1) == 0) break;  // the sibling subtree is not done yet: its thread will do this node
+            __threadfence();
+            const Box3 a = load_fresh(&t.box[t.left[node]]), b = load_fresh(&t.box[t.right[node]]);
+            Box3 m;
+            for (int x = 0; x < 3; x++) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+            t.box[node] = m;
+            node = t.parent[node];
+        }
+    }
+}
+
+// ---- 5. collapse into 8-wide nodes, one level per launch
+struct WorkItem {
+    int bvh2Node;   // root of the BVH2 subtree this BVH8 node covers (internal node id)
+    uint32_t outNode;
+};
+
+__device__ __forceinline__ float half_area(const Box3& b)
+{
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ex * ez;
+}
+__device__ __forceinline__ uint32_t quantize(float v)  // nexus::collapse Quantize
+{
+    if (!(v == v)) return 0u;
+    if (v <= 0.0f) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)v;
+}
+
+__global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, const int n, const uint32_t* __restrict__ order, const WorkItem* __restrict__ work,
+                                                                const uint32_t workCount, WorkItem* __restrict__ nextWork, uint32_t* __restrict__ counters /* [0] nodes used, [1] prims used, [2] next work count */,
+                                                                nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx, const uint32_t nodeCapacity)
+{
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < workCount; w += gridDim.x * blockDim.x) {
+        const WorkItem item = work[w];
+        // open children by largest area until eight (a BVH2 leaf, one triangle, cannot be opened)
+        int child[8];
+        int count = 2;
+        child[0] = t.left[item.bvh2Node];
+        child[1] = t.right[item.bvh2Node];
+        while (count < 8) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int k = 0; k < count; k++) {
+                if (child[k] >= n - 1) continue;
+                const float a = half_area(t.box[child[k]]);
+                if (a > bestArea) { bestArea = a; best = k; }
+            }
+            if (best < 0) break;
+            const int open = child[best];
+            child[best] = t.left[open];
+            child[count++] = t.right[open];
+        }
+        const Box3 nb = t.box[item.bvh2Node];
+        // octant slots: the reference's greedy assignment (BVH8Builder.cpp:170-252) — repeatedly the (child, slot) pair with the
+        // smallest dot(child centre - node centre, slot direction), slot bit 2 / 1 / 0 set = -x / -y / -z
+        float cx[8], cy[8], cz[8];
+        const float ncx = 0.5f * (nb.lo[0] + nb.hi[0]), ncy = 0.5f * (nb.lo[1] + nb.hi[1]), ncz = 0.5f * (nb.lo[2] + nb.hi[2]);
+        for (int k = 0; k < count; k++) {
+            const Box3 b = t.box[child[k]];
+            cx[k] = 0.5f * (b.lo[0] + b.hi[0]) - ncx; cy[k] = 0.5f * (b.lo[1] + b.hi[1]) - ncy; cz[k] = 0.5f * (b.lo[2] + b.hi[2]) - ncz;
+        }
+        int slotOf[8], childAt[8];
+        for (int s = 0; s < 8; s++) childAt[s] = -1;
+        for (int k = 0; k < 8; k++) slotOf[k] = -1;
+        for (int round = 0; round < count; round++) {
+            float best = 1e30f;
+            int bk = -1, bs = -1;
+            for (int k = 0; k < count; k++) {
+                if (slotOf[k] >= 0) continue;
+                for (int s = 0; s < 8; s++) {
+                    if (childAt[s] >= 0) continue;
+                    const float dx = (s & 4) ? -1.0f : 1.0f, dy = (s & 2) ? -1.0f : 1.0f, dz = (s & 1) ? -1.0f : 1.0f;
+                    const float cost = cx[k] * dx + cy[k] * dy + cz[k] * dz;
+                    if (cost < best) { best = cost; bk = k; bs = s; }
+                }
+            }
+            if (bk < 0) {  // no finite cost (a box with NaNs): any free pair keeps the node well formed
+                for (int k = 0; k < count && bk < 0; k++)
+                    if (slotOf[k] < 0) bk = k;
+                for (int s = 0; s < 8 && bs < 0; s++)
+                    if (childAt[s] < 0) bs = s;
+            }
+            slotOf[bk] = bs;
+            childAt[bs] = bk;
+        }
+        // inner children (more than three triangles) get consecutive node ids in slot order, leaf children consecutive
+        // entries of the primitive list in slot order
+        uint32_t innerCount = 0, primCount = 0;
+        for (int s = 0; s < 8; s++) {
+            if (childAt[s] < 0) continue;
+            const int c = child[childAt[s]];
+            const int tris = c >= n - 1 ? 1 : t.last[c] - t.first[c] + 1;
+            if (tris > 3) innerCount++;
+            else primCount += (uint32_t)tris;
+        }
+        const uint32_t childBase = innerCount ? atomicAdd(&counters[0], innerCount) : 0u;
+        const uint32_t primBase = primCount ? atomicAdd(&counters[1], primCount) : 0u;
+        if (innerCount && childBase + innerCount > nodeCapacity) continue;  // cannot happen: capacity covers the worst case
+        const uint32_t workBase = innerCount ? atomicAdd(&counters[2], innerCount) : 0u;
+
+        nx_bvh8_node node;
+        node = nx_bvh8_node{};
+        // quantisation frame, as nexus::collapse: e = ceil(log2(extent / 255)) per axis
+        float invScale[3];
+        for (int a = 0; a < 3; a++) {
+            const float ex = ceilf((float)log2((double)((nb.hi[a] - nb.lo[a]) * (1.0f / 255.0f))));
+            uint32_t e = 0;
+            if (ex == ex && ex > -127.0f) e = ex >= 128.0f ? 255u : (uint32_t)((int)ex + 127);
+            const float pw = ex == ex ? (ex < -200.0f ? 0.0f : (ex > 200.0f ? __uint_as_float(0x7f800000u) : ldexpf(1.0f, (int)ex))) : ex;
+            invScale[a] = 1.0f / pw;
+            node.p[a] = nb.lo[a];
+            node.e[a] = (uint8_t)e;
+        }
+        node.childBaseIdx = childBase;
+        node.triangleBaseIdx = primBase;
+        uint32_t innerSeen = 0, primSeen = 0;
+        for (int s = 0; s < 8; s++) {
+            if (childAt[s] < 0) continue;
+            const int c = child[childAt[s]];
+            const Box3 b = t.box[c];
+            node.qlox[s] = (uint8_t)quantize(floorf((b.lo[0] - nb.lo[0]) * invScale[0]));
+            node.qloy[s] = (uint8_t)quantize(floorf((b.lo[1] - nb.lo[1]) * invScale[1]));
+            node.qloz[s] = (uint8_t)quantize(floorf((b.lo[2] - nb.lo[2]) * invScale[2]));
+            node.qhix[s] = (uint8_t)quantize(ceilf((b.hi[0] - nb.lo[0]) * invScale[0]));
+            node.qhiy[s] = (uint8_t)quantize(ceilf((b.hi[1] - nb.lo[1]) * invScale[1]));
+            node.qhiz[s] = (uint8_t)quantize(ceilf((b.hi[2] - nb.lo[2]) * invScale[2]));
+            const int firstPos = c >= n - 1 ? c - (n - 1) : t.first[c];
+            const int tris = c >= n - 1 ? 1 : t.last[c] - t.first[c] + 1;
+            if (tris > 3) {
+                node.meta[s] = (uint8_t)(0x20 | (24 + s));
+                node.imask |= (uint8_t)(1u << s);
+                nextWork[workBase + innerSeen] = WorkItem{c, childBase + innerSeen};
+                innerSeen++;
+            } else {
+                uint32_t unary = 0;
+                for (int j = 0; j < tris; j++) {
+                    unary |= 1u << (j + 5);
+                    primIdx[primBase + primSeen + (uint32_t)j] = order[firstPos + j];
+                }
+                node.meta[s] = (uint8_t)(unary | primSeen);
+                primSeen += (uint32_t)tris;
+            }
+        }
+        nodes[item.outNode] = node;
+    }
+}
+
+// tiny inputs: a root whose children are the triangles themselves (fewer than 2 internal BVH2 nodes to speak of)
+__global__ void small_mesh_kernel(const Box3* __restrict__ triBox, const int n, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Box3 nb;
+    for (int a = 0; a < 3; a++) { nb.lo[a] = 1e30f; nb.hi[a] = -1e30f; }
+    for (int k = 0; k < n; k++)
+        for (int a = 0; a < 3; a++) { nb.lo[a] = fminf(nb.lo[a], triBox[k].lo[a]); nb.hi[a] = fmaxf(nb.hi[a], triBox[k].hi[a]); }
+    nx_bvh8_node node;
+    node = nx_bvh8_node{};
+    float invScale[3];
+    for (int a = 0; a < 3; a++) {
+        const float ex = ceilf((float)log2((double)((nb.hi[a] - nb.lo[a]) * (1.0f / 255.0f))));
+        uint32_t e = 0;
+        if (ex == ex && ex > -127.0f) e = ex >= 128.0f ? 255u : (uint32_t)((int)ex + 127);
+        const float pw = ex == ex ? (ex < -200.0f ? 0.0f : (ex > 200.0f ? __uint_as_float(0x7f800000u) : ldexpf(1.0f, (int)ex))) : ex;
+        invScale[a] = 1.0f / pw;
+        node.p[a] = nb.lo[a];
+        node.e[a] = (uint8_t)e;
+    }
+    for (int k = 0; k < n; k++) {  // n <= 8: one triangle per slot
+        const Box3 b = triBox[k];
+        node.qlox[k] = (uint8_t)quantize(floorf((b.lo[0] - nb.lo[0]) * invScale[0]));
+        node.qloy[k] = (uint8_t)quantize(floorf((b.lo[1] - nb.lo[1]) * invScale[1]));
+        node.qloz[k] = (uint8_t)quantize(floorf((b.lo[2] - nb.lo[2]) * invScale[2]));
+        node.qhix[k] = (uint8_t)quantize(ceilf((b.hi[0] - nb.lo[0]) * invScale[0]));
+        node.qhiy[k] = (uint8_t)quantize(ceilf((b.hi[1] - nb.lo[1]) * invScale[1]));
+        node.qhiz[k] = (uint8_t)quantize(ceilf((b.hi[2] - nb.lo[2]) * invScale[2]));
+        node.meta[k] = (uint8_t)(0x20u | (uint32_t)k);
+        primIdx[k] = (uint32_t)k;
+    }
+    nodes[0] = node;
+}
+
+// ---- 6. the traversal kernels' leaf-ordered intersection stream {p0 | id}, {e0}, {e1} (nxhip_upload_blas builds it on the host)
+__global__ void __launch_bounds__(kBlock) isect_kernel(const nx_triangle* __restrict__ tris, const uint32_t* __restrict__ primIdx, const uint32_t n, float4* __restrict__ isect)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t id = primIdx[k];
+        const nx_triangle t = tris[id];
+        isect[(size_t)kTriStride * k + 0] = make_float4(t.pos0[0], t.pos0[1], t.pos0[2], __uint_as_float(id));
+        isect[(size_t)kTriStride * k + 1] = make_float4(t.pos1[0] - t.pos0[0], t.pos1[1] - t.pos0[1], t.pos1[2] - t.pos0[2], 0.0f);
+        isect[(size_t)kTriStride * k + 2] = make_float4(t.pos2[0] - t.pos0[0], t.pos2[1] - t.pos0[1], t.pos2[2] - t.pos0[2], 0.0f);
+    }
+}
+
+int grid_for(uint32_t n, int cus) { return (int)std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)(8 * cus)); }
+
+}  // namespace
+
+// Builds nodes / primIdx / isect for the `n` triangles at dTris (device).  All device buffers come back through the
+// arguments; *nodeCount = nodes used.
+int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    DevBuf triBox, bounds;
+    if (!triBox.alloc((size_t)n * sizeof(Box3)) || !bounds.alloc(6 * 4) || !primIdx.alloc((size_t)n * 4) || !isect.alloc((size_t)n * kTriStride * sizeof(float4))) return NXHIP_ERR_HIP;
+    {
+        const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
+        tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
+    }
+    if (n <= 8) {
+        if (!nodes.alloc(sizeof(nx_bvh8_node))) return NXHIP_ERR_HIP;
+        small_mesh_kernel<<<1, 64, 0, st>>>(triBox.as<Box3>(), (int)n, nodes.as<nx_bvh8_node>(), primIdx.as<uint32_t>());
+        isect_kernel<<<1, kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
+        NX_HIP(hipStreamSynchronize(st));
+        *nodeCount = 1;
+        return NXHIP_OK;
+    }
+    DevBuf codes, codesSorted, order, orderSorted, sortTemp;
+    if (!codes.alloc((size_t)n * 8) || !codesSorted.alloc((size_t)n * 8) || !order.alloc((size_t)n * 4) || !orderSorted.alloc((size_t)n * 4)) return NXHIP_ERR_HIP;
+    morton_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), n, bounds.as<uint32_t>(), codes.as<unsigned long long>(), order.as<uint32_t>());
+    size_t tempBytes = 0;
+    NX_HIP(rocprim::radix_sort_pairs(nullptr, tempBytes, codes.as<unsigned long long>(), codesSorted.as<unsigned long long>(), order.as<uint32_t>(), orderSorted.as<uint32_t>(), n, 0, 63, st));
+    if (!sortTemp.alloc(std::max<size_t>(tempBytes, 16))) return NXHIP_ERR_HIP;
+    NX_HIP(rocprim::radix_sort_pairs(sortTemp.p, tempBytes, codes.as<unsigned long long>(), codesSorted.as<unsigned long long>(), order.as<uint32_t>(), orderSorted.as<uint32_t>(), n, 0, 63, st));
+
+    // binary radix tree + bounds
+    const size_t inner = (size_t)n - 1, all = 2 * (size_t)n - 1;
+    DevBuf left, right, parent, first, last, box, arrived;
+    if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !box.alloc(all * sizeof(Box3)) ||
+        !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
+    NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
+    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), box.as<Box3>(), arrived.as<int>()};
+    radix_tree_kernel<<<grid_for(n - 1, cus), kBlock, 0, st>>>(codesSorted.as<unsigned long long>(), (int)n, t);
+    fit_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), orderSorted.as<uint32_t>(), (int)n, t);
+
+    // collapse.  Every BVH8 node but the root stands for a distinct internal BVH2 node, so n - 1 nodes cannot be exceeded
+    // (typical use: 0.1 - 0.2 n); the caller shrinks the array to the used size.
+    const uint32_t nodeCapacity = (uint32_t)inner;
+    DevBuf workA, workB, counters;
+    if (!nodes.alloc((size_t)nodeCapacity * sizeof(nx_bvh8_node)) || !workA.alloc((size_t)nodeCapacity * sizeof(WorkItem)) || !workB.alloc((size_t)nodeCapacity * sizeof(WorkItem)) ||
+        !counters.alloc(3 * 4)) return NXHIP_ERR_HIP;
+    {
+        const uint32_t init[3] = {1u, 0u, 0u};  // node 0 is the root
+        const WorkItem root{0, 0u};
+        NX_HIP(hipMemcpyAsync(counters.p, init, sizeof init, hipMemcpyHostToDevice, st));
+        NX_HIP(hipMemcpyAsync(workA.p, &root, sizeof root, hipMemcpyHostToDevice, st));
+    }
+    uint32_t workCount = 1;
+    WorkItem* cur = workA.as<WorkItem>();
+    WorkItem* nxt = workB.as<WorkItem>();
+    for (int level = 0; workCount > 0; level++) {
+        if (level > 128) {
+            set_error("lbvh_build: the collapse does not terminate");
+            return NXHIP_ERR_INVALID;
+        }
+        collapse_level_kernel<<<grid_for(workCount, cus), kBlock, 0, st>>>(t, (int)n, orderSorted.as<uint32_t>(), cur, workCount, nxt, counters.as<uint32_t>(), nodes.as<nx_bvh8_node>(),
+                                                                           primIdx.as<uint32_t>(), nodeCapacity);
+        uint32_t h[3];
+        NX_HIP(hipMemcpyAsync(h, counters.p, sizeof h, hipMemcpyDeviceToHost, st));
+        NX_HIP(hipStreamSynchronize(st));
+        if (h[0] > nodeCapacity) {
+            set_error("lbvh_build: node capacity exceeded");
+            return NXHIP_ERR_INVALID;
+        }
+        workCount = h[2];
+        *nodeCount = h[0];
+        const uint32_t zero = 0;
+        NX_HIP(hipMemcpyAsync(counters.as<uint32_t>() + 2, &zero, 4, hipMemcpyHostToDevice, st));
+        std::swap(cur, nxt);
+    }
+    isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
+    NX_HIP(hipStreamSynchronize(st));
+    NX_HIP(hipGetLastError());
+    return NXHIP_OK;
+}
+
+}  // namespace nxd

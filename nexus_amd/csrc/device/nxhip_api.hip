@@ -25,6 +25,7 @@ const void* bsdf_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
+int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
 
 static thread_local std::string g_lastError;
 
@@ -506,6 +507,47 @@ try {
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_upload_blas: ") + e.what());
     return NXHIP_ERR_INVALID;
+}
+
+int nxhip_build_blas(nxhip_ctx* c, const nx_triangle* tris, uint32_t triCount, int32_t* blasId)
+try {
+    NX_CHECK_CTX(c);
+    if (!tris || triCount == 0) return fail_invalid("nxhip_build_blas: empty input");
+    if (kNodeStride != 5) return fail_invalid("nxhip_build_blas: built with padded node records");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    BlasHost b;
+    b.triCount = triCount;
+    NX_ALLOC(b.tris, (size_t)triCount * sizeof(nx_triangle));
+    NX_HIP(hipMemcpy(b.tris.p, tris, (size_t)triCount * sizeof(nx_triangle), hipMemcpyHostToDevice));
+    DevBuf wide;
+    uint32_t nodeCount = 0;
+    const int rc = lbvh_build(c, b.tris.as<nx_triangle>(), triCount, wide, b.triIdx, b.isect, &nodeCount);
+    if (rc != NXHIP_OK) return rc;
+    NX_ALLOC(b.nodes, (size_t)nodeCount * sizeof(nx_bvh8_node));  // the builder's array is sized for the worst case
+    NX_HIP(hipMemcpy(b.nodes.p, wide.p, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToDevice));
+    b.nodeCount = nodeCount;
+    c->blas.push_back(std::move(b));
+    if (blasId) *blasId = (int32_t)c->blas.size() - 1;
+    return refresh_blas_table(c);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_build_blas: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
+int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t nodeCapacity, uint32_t* primIdx, uint32_t primCapacity, uint32_t* nodeCount)
+{
+    NX_CHECK_CTX(c);
+    if (blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_read_blas: no such BLAS");
+    const BlasHost& b = c->blas[(size_t)blasId];
+    if (nodeCount) *nodeCount = b.nodeCount;
+    if ((nodes && nodeCapacity < b.nodeCount) || (primIdx && primCapacity < b.triCount)) return fail_invalid("nxhip_read_blas: destination too small");
+    if (kNodeStride != 5) return fail_invalid("nxhip_read_blas: built with padded node records");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    if (nodes) NX_HIP(hipMemcpy(nodes, b.nodes.p, (size_t)b.nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+    if (primIdx) NX_HIP(hipMemcpy(primIdx, b.triIdx.p, (size_t)b.triCount * 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
 }
 
 int nxhip_clear_blas(nxhip_ctx* c)

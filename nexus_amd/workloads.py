@@ -81,12 +81,24 @@ class Workload:
         """device bytes the trace kernels read from: 80-byte nodes + 48-byte intersection records + instance records"""
         return int(sum(80 * len(b[0]) + 48 * len(b[1]) for b in self.blas) + 80 * len(self.tlas_nodes) + 80 * len(self.instances))
 
-    def upload(self, ctx):
+    def upload(self, ctx, device_bvh=False):
+        """device_bvh: build every BLAS on the GPU (nxhip_build_blas: LBVH + wide collapse) instead of uploading the host
+        builder's; the instances' world bounds follow the BLAS root frame, so instances and TLAS are rebuilt for those roots."""
         ctx.clear_blas()
         ctx.clear_textures()
-        for nodes, tris, idx in self.blas:
-            ctx.upload_blas(nodes, tris, idx)
-        ctx.set_tlas(self.tlas_nodes, self.tlas_idx, self.instances)
+        if device_bvh:
+            roots = []
+            for _nodes, tris, _idx in self.blas:
+                bid = ctx.build_blas(tris)
+                roots.append(ctx.read_blas(bid, len(tris))[0][0])
+            insts = np.array([capi.instance_init(int(i["bvhIdx"]), int(i["materialId"]), i["transform"], roots[int(i["bvhIdx"])]) for i in self.instances],
+                             dtype=pod.INST_DT)
+            tlas_nodes, tlas_idx = capi.tlas_build(insts)
+            ctx.set_tlas(tlas_nodes, tlas_idx, insts)
+        else:
+            for nodes, tris, idx in self.blas:
+                ctx.upload_blas(nodes, tris, idx)
+            ctx.set_tlas(self.tlas_nodes, self.tlas_idx, self.instances)
         ctx.set_materials(self.materials)
         ctx.set_lights(self.lights)
         for img in self.diffuse_maps:

@@ -1,0 +1,117 @@
+"""BLAS built on the device (nxhip_build_blas: LBVH + wide collapse, nx_lbvh.hip): structural validity and conservative
+bounds of the 80-byte nodes, and the same hits as the SAH-built BLAS / brute force through the unchanged traversal kernels."""
+import numpy as np
+import pytest
+
+from nexus_amd import capi, pod, scenegen
+from tests import scene_helpers as SH
+from tests.test_builder_parity import _decode_children
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_structure(nodes, idx, tris):
+    assert sorted(idx.tolist()) == list(range(len(tris))), "every triangle exactly once"
+    tmin = np.minimum(np.minimum(tris["pos0"], tris["pos1"]), tris["pos2"]).astype(np.float64)
+    tmax = np.maximum(np.maximum(tris["pos0"], tris["pos1"]), tris["pos2"]).astype(np.float64)
+    seen_nodes, seen_prims = set(), set()
+    stack = [0]
+    while stack:
+        ni = stack.pop()
+        assert ni not in seen_nodes and ni < len(nodes)
+        seen_nodes.add(ni)
+        total, inner = 0, []
+        for s, kind, lo, hi, first, count in _decode_children(nodes[ni]):
+            eps = 1e-6 * np.maximum(1.0, np.abs(hi))
+            if kind == "inner":
+                inner.append(first)
+                stack.append(first)
+            else:
+                assert 1 <= count <= 3
+                total += count
+                for k in range(first, first + count):
+                    assert k not in seen_prims
+                    seen_prims.add(k)
+                    t = idx[k]
+                    assert np.all(lo <= tmin[t] + eps) and np.all(hi >= tmax[t] - eps), (ni, s, k)
+        assert total <= 24
+        assert inner == list(range(inner[0], inner[0] + len(inner))) if inner else True, "inner children are consecutive in slot order"
+    assert len(seen_nodes) == len(nodes) and len(seen_prims) == len(tris)
+
+
+MESHES = {
+    "soup": lambda: scenegen.random_soup(5000, seed=3),
+    "torus": lambda: scenegen.displaced_torus(96, 48, seed=2),
+    "tiny": lambda: scenegen.random_soup(5, seed=1),
+    "nine": lambda: scenegen.random_soup(9, seed=4),
+    "one": lambda: scenegen.random_soup(1, seed=5),
+    "same_centroids": lambda: np.repeat(scenegen.random_soup(1, seed=6), 300),
+    "planar": lambda: scenegen.height_field(40, seed=7, amp=0.0),
+}
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name):
+    tris = np.ascontiguousarray(MESHES[name](), dtype=pod.TRI_DT)
+    ctx = gpu_ctx_factory(32, 32)
+    bid = ctx.build_blas(tris)
+    nodes, idx = ctx.read_blas(bid, len(tris))
+    _check_structure(nodes, idx, tris)
+
+
+def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_factory):
+    """Same scene twice: BLASes from the host SAH builder vs. built on the device; the oracle traverses the SAH version.
+    Hit distances are identical (the closest hit does not depend on the tree); ids may differ only on equidistant ties."""
+    meshes = [scenegen.displaced_torus(128, 64, seed=3, major=0.6, minor=0.25, amp=0.05), scenegen.random_soup(3000, seed=9, extent=0.6, size=0.05)]
+    rng = np.random.RandomState(5)
+    placements = [(i % 2, 0, capi.mat4_from_trs(rng.uniform(-2, 2, 3), rng.uniform(0, 360, 3), rng.uniform(0.6, 1.4, 3))) for i in range(12)]
+    scene = SH.BuiltScene(meshes, placements)
+    rays = np.concatenate([scenegen.random_rays(20000, seed=7, radius=6.0, target_extent=2.5), scenegen.interior_rays(20000, seed=8, extent=2.5)])
+    want = scene.oracle().trace_closest(rays)
+    ref = gpu_ctx_factory(32, 32)
+    scene.upload(ref)
+    assert SH.hit_records_equal(ref.trace_batch(rays), want)
+    ctx = gpu_ctx_factory(32, 32)
+    ids = [ctx.build_blas(m) for m in scene.meshes]
+    assert ids == [0, 1]
+    # the instances' world bounds come from the BLAS root frame (BVHInstance.cpp:8-21): recompute them for the device-built roots
+    roots = [ctx.read_blas(i, len(m))[0][0] for i, m in zip(ids, scene.meshes)]
+    insts = np.array([capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), old["transform"], roots[int(old["bvhIdx"])]) for old in scene.instances], dtype=pod.INST_DT)
+    tlas_nodes, tlas_idx = capi.tlas_build(insts)
+    ctx.set_tlas(tlas_nodes, tlas_idx, insts)
+    got = ctx.trace_batch(rays)
+    assert (want["hitDistance"] < 1e29).mean() > 0.1
+    assert np.array_equal(got["hitDistance"].view(np.uint32), want["hitDistance"].view(np.uint32))
+    same = (got["triIdx"] == want["triIdx"]) & (got["instanceIdx"] == want["instanceIdx"])
+    assert same.mean() > 0.999
+    occl = ctx.trace_shadow_batch(rays[:5000], np.full(5000, 3.0, np.float32))
+    assert np.array_equal(occl, ref.trace_shadow_batch(rays[:5000], np.full(5000, 3.0, np.float32)))
+
+
+def test_device_build_of_a_million_triangles_is_fast_and_valid(gpu_ctx_factory):
+    import time
+
+    tris = scenegen.displaced_torus(1024, 512, seed=1, major=1.0, minor=0.45, amp=0.06)
+    ctx = gpu_ctx_factory(32, 32)
+    ctx.build_blas(scenegen.random_soup(100, seed=1))  # first use: code objects, sort temporaries
+    t0 = time.time()
+    bid = ctx.build_blas(tris)
+    dt = time.time() - t0
+    nodes, idx = ctx.read_blas(bid, len(tris))
+    print("device build of %d triangles: %.3f s including the upload, %d nodes" % (len(tris), dt, len(nodes)))
+    assert dt < 2.0
+    assert sorted(idx.tolist()) == list(range(len(tris)))
+    assert len(nodes) < len(tris) // 3
+    rays = scenegen.random_rays(20000, seed=2, radius=4.0, target_extent=1.5)
+    got = ctx.trace_batch if False else None
+    host_nodes, host_idx = capi.bvh8_build(tris, threads=0)
+    a = gpu_ctx_factory(32, 32)
+    a.upload_blas(host_nodes, tris, host_idx)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    for c, root in ((a, host_nodes[0]), (ctx, nodes[0])):
+        inst = np.array([capi.instance_init(0 if c is a else bid, 0, ident, root)], dtype=pod.INST_DT)
+        tn, ti = capi.tlas_build(inst)
+        c.set_tlas(tn, ti, inst)
+    ha, hb = a.trace_batch(rays), ctx.trace_batch(rays)
+    assert (ha["hitDistance"] < 1e29).mean() > 0.2
+    assert np.array_equal(ha["hitDistance"].view(np.uint32), hb["hitDistance"].view(np.uint32))
