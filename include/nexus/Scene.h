@@ -29,6 +29,7 @@ public:
     MeshInstance& CreateMeshInstance(uint32_t meshId);
     void AddMaterial(Material& material) { m_AssetManager.AddMaterial(material); }
     void AddHDRMap(const Texture& texture);
+    void AddHDRMap(const std::string& filePath, const std::string& fileName);  // Scene.cpp:93-97: IMGLoader::LoadIMG (.hdr or .png)
     size_t AddLight(const Light& light);
     void RemoveLight(size_t index);
 

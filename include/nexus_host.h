@@ -119,6 +119,29 @@ uint32_t nxs_pathtracer_frame_number(const nxs_pathtracer *p);
 int nxs_pathtracer_read_pixels(nxs_pathtracer *p, uint32_t *rgba8);
 struct nxhip_ctx *nxs_pathtracer_device_context(nxs_pathtracer *p);
 
+/* Scene::AddHDRMap(filePath, fileName) — Scene/Scene.cpp:93-97: environment map from a Radiance .hdr (or .png) file. */
+int nxs_scene_add_hdr_map_file(nxs_scene *s, const char *path, const char *fileName);
+
+/* ---- nexus::Renderer (include/nexus/Renderer.h): the reference's frame driver without its window ---------------------
+ * Renderer::Render (Renderer/Renderer.cpp:41-77): scene.Update() + ResetFrameNumber when the scene is invalid, then
+ * UpdateDeviceScene + PathTracer::Render; SaveScreenshot (Renderer.cpp:183-215): PNG with rows flipped. */
+typedef struct nxs_renderer nxs_renderer;
+int nxs_renderer_create(uint32_t width, uint32_t height, nxs_scene *scene, int device, nxs_renderer **out);
+void nxs_renderer_destroy(nxs_renderer *r);
+int nxs_renderer_render(nxs_renderer *r, nxs_scene *scene, float deltaTime);
+int nxs_renderer_reset(nxs_renderer *r);
+int nxs_renderer_on_resize(nxs_renderer *r, uint32_t width, uint32_t height);
+int nxs_renderer_save_screenshot(nxs_renderer *r, const char *path);
+int nxs_renderer_save_exr(nxs_renderer *r, const char *path); /* extension: float accumulation as OpenEXR */
+uint32_t nxs_renderer_frame_number(const nxs_renderer *r);
+double nxs_renderer_megasamples_per_second(const nxs_renderer *r); /* MetricsPanel.cpp:28-56 */
+struct nxhip_ctx *nxs_renderer_device_context(nxs_renderer *r);
+int nxs_renderer_set_modes(nxs_renderer *r, int rngMode, int compactMode, int conductorMode);
+/* Image writers without stb: PNG (RGBA8; the reference's stbi_write_png) and OpenEXR (scanline, uncompressed, float32 B G R).
+ * flipVertically != 0 writes the last row first (the render buffer's row 0 is the bottom of the viewport). */
+int nxh_write_png(const char *path, const uint32_t *rgba8, uint32_t width, uint32_t height, int flipVertically);
+int nxh_write_exr(const char *path, const float *rgb, uint32_t width, uint32_t height, int flipVertically);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,10 @@ HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
     "nxh_bvh8_prim_indices", "nxh_bvh8_free", "nxh_bvh2_build", "nxh_mat4_from_trs", "nxh_mat4_invert",
     "nxh_instance_init", "nxh_camera_init", "nxh_loaded_texture_count", "nxh_loaded_texture_info", "nxh_loaded_texture_pixels",
-    "nxh_loaded_material_textures", "nxh_loaded_warning_count", "nxh_loaded_warning", "nxh_decode_png",
+    "nxh_loaded_material_textures", "nxh_loaded_warning_count", "nxh_loaded_warning", "nxh_decode_png", "nxh_write_png", "nxh_write_exr",
+    "nxs_scene_add_hdr_map_file", "nxs_renderer_create", "nxs_renderer_destroy", "nxs_renderer_render", "nxs_renderer_reset", "nxs_renderer_on_resize",
+    "nxs_renderer_save_screenshot", "nxs_renderer_save_exr", "nxs_renderer_frame_number", "nxs_renderer_megasamples_per_second", "nxs_renderer_device_context",
+    "nxs_renderer_set_modes",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
     "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
@@ -780,6 +783,89 @@ class Scene:
 
     def instance_count(self):
         return int(self.L.nxs_scene_instance_count(self.h))
+
+
+def write_png(path, rgba8, width, height, flip=True):
+    px = np.ascontiguousarray(rgba8, dtype=np.uint32)
+    L = lib()
+    L.nxh_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    _scheck(L.nxh_write_png(str(path).encode(), _ptr(px), width, height, 1 if flip else 0), "nxh_write_png")
+
+
+def write_exr(path, rgb, width, height, flip=True):
+    px = np.ascontiguousarray(rgb, dtype=np.float32)
+    L = lib()
+    L.nxh_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    _scheck(L.nxh_write_exr(str(path).encode(), _ptr(px), width, height, 1 if flip else 0), "nxh_write_exr")
+
+
+class Renderer:
+    """nexus::Renderer: the reference's frame driver (Renderer::Render / SaveScreenshot) without its window."""
+
+    def __init__(self, width, height, scene, device=0):
+        self.L = lib()
+        L = self.L
+        L.nxs_renderer_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.nxs_renderer_destroy.argtypes = [C.c_void_p]
+        L.nxs_renderer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.nxs_renderer_reset.argtypes = [C.c_void_p]
+        L.nxs_renderer_on_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.nxs_renderer_save_screenshot.argtypes = [C.c_void_p, C.c_char_p]
+        L.nxs_renderer_save_exr.argtypes = [C.c_void_p, C.c_char_p]
+        L.nxs_renderer_frame_number.argtypes = [C.c_void_p]
+        L.nxs_renderer_frame_number.restype = C.c_uint32
+        L.nxs_renderer_megasamples_per_second.argtypes = [C.c_void_p]
+        L.nxs_renderer_megasamples_per_second.restype = C.c_double
+        L.nxs_renderer_device_context.argtypes = [C.c_void_p]
+        L.nxs_renderer_device_context.restype = C.c_void_p
+        L.nxs_renderer_set_modes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        h = C.c_void_p()
+        _scheck(L.nxs_renderer_create(width, height, scene.h, device, C.byref(h)), "nxs_renderer_create")
+        self.h = h
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nxs_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_modes(self, rng_mode, compact_mode, conductor_mode):
+        _scheck(self.L.nxs_renderer_set_modes(self.h, rng_mode, compact_mode, conductor_mode), "nxs_renderer_set_modes")
+
+    def render(self, scene, delta_time=0.0):
+        _scheck(self.L.nxs_renderer_render(self.h, scene.h, delta_time), "nxs_renderer_render")
+
+    def reset(self):
+        _scheck(self.L.nxs_renderer_reset(self.h), "nxs_renderer_reset")
+
+    def save_screenshot(self, path):
+        _scheck(self.L.nxs_renderer_save_screenshot(self.h, str(path).encode()), "nxs_renderer_save_screenshot")
+
+    def save_exr(self, path):
+        _scheck(self.L.nxs_renderer_save_exr(self.h, str(path).encode()), "nxs_renderer_save_exr")
+
+    def frame_number(self):
+        return int(self.L.nxs_renderer_frame_number(self.h))
+
+    def megasamples_per_second(self):
+        return float(self.L.nxs_renderer_megasamples_per_second(self.h))
+
+    def read_accumulation(self):
+        out = np.zeros((self.width * self.height, 3), dtype=np.float32)
+        lib().nxhip_read_accumulation.argtypes = [C.c_void_p, C.c_void_p]
+        check(lib().nxhip_read_accumulation(C.c_void_p(self.L.nxs_renderer_device_context(self.h)), _ptr(out)), "nxhip_read_accumulation")
+        return out
+
+    def read_pixels(self):
+        out = np.zeros(self.width * self.height, dtype=np.uint32)
+        check(lib().nxhip_read_rgba8(C.c_void_p(self.L.nxs_renderer_device_context(self.h)), _ptr(out)), "nxhip_read_rgba8")
+        return out
 
 
 class PathTracer:

@@ -7,6 +7,7 @@
 
 #include "nexus/IMGLoader.h"
 #include "nexus/OBJLoader.h"
+#include "nexus/Renderer.h"
 #include "nexus/PathTracer.h"
 #include "nexus/Scene.h"
 #include "nexus_host.h"
@@ -23,6 +24,10 @@ struct nxh_loaded_scene {
 struct nxs_pathtracer {
     PathTracer pt;
     nxs_pathtracer(uint32_t w, uint32_t h, int dev) : pt(w, h, dev) {}
+};
+struct nxs_renderer {
+    Renderer r;
+    nxs_renderer(uint32_t w, uint32_t h, Scene* s, int dev) : r(w, h, s, dev) {}
 };
 
 namespace {
@@ -270,5 +275,60 @@ int nxs_pathtracer_read_pixels(nxs_pathtracer* p, uint32_t* rgba8)
     });
 }
 struct nxhip_ctx* nxs_pathtracer_device_context(nxs_pathtracer* p) { return p->pt.GetDeviceContext(); }
+
+int nxs_scene_add_hdr_map_file(nxs_scene* s, const char* path, const char* fileName)
+{
+    return guarded([&] {
+        if (!path || !fileName) throw std::runtime_error("nxs_scene_add_hdr_map_file: null argument");
+        s->scene.AddHDRMap(path, fileName);
+    });
+}
+
+int nxs_renderer_create(uint32_t width, uint32_t height, nxs_scene* scene, int device, nxs_renderer** out)
+{
+    return guarded([&] {
+        if (!scene || !out) throw std::runtime_error("nxs_renderer_create: null argument");
+        *out = new nxs_renderer(width, height, &scene->scene, device);
+    });
+}
+void nxs_renderer_destroy(nxs_renderer* r) { delete r; }
+int nxs_renderer_render(nxs_renderer* r, nxs_scene* scene, float deltaTime)
+{
+    return guarded([&] { r->r.Render(scene->scene, deltaTime); });
+}
+int nxs_renderer_reset(nxs_renderer* r) { return guarded([&] { r->r.Reset(); }); }
+int nxs_renderer_on_resize(nxs_renderer* r, uint32_t width, uint32_t height) { return guarded([&] { r->r.OnResize(width, height); }); }
+int nxs_renderer_save_screenshot(nxs_renderer* r, const char* path)
+{
+    return guarded([&] {
+        if (!path || !r->r.SaveScreenshot(path)) throw std::runtime_error(std::string("cannot write ") + (path ? path : "(null)"));
+    });
+}
+int nxs_renderer_save_exr(nxs_renderer* r, const char* path)
+{
+    return guarded([&] {
+        if (!path || !r->r.SaveAccumulationEXR(path)) throw std::runtime_error(std::string("cannot write ") + (path ? path : "(null)"));
+    });
+}
+uint32_t nxs_renderer_frame_number(const nxs_renderer* r) { return r->r.GetFrameNumber(); }
+double nxs_renderer_megasamples_per_second(const nxs_renderer* r) { return r->r.GetMegaSamplesPerSecond(); }
+struct nxhip_ctx* nxs_renderer_device_context(nxs_renderer* r) { return r->r.GetPathTracer().GetDeviceContext(); }
+int nxs_renderer_set_modes(nxs_renderer* r, int rngMode, int compactMode, int conductorMode)
+{
+    return guarded([&] { r->r.GetPathTracer().SetModes(rngMode, compactMode, conductorMode); });
+}
+
+int nxh_write_png(const char* path, const uint32_t* rgba8, uint32_t width, uint32_t height, int flipVertically)
+{
+    return guarded([&] {
+        if (!path || !WritePNG(path, rgba8, width, height, flipVertically != 0)) throw std::runtime_error("nxh_write_png: cannot write the file");
+    });
+}
+int nxh_write_exr(const char* path, const float* rgb, uint32_t width, uint32_t height, int flipVertically)
+{
+    return guarded([&] {
+        if (!path || !WriteEXR(path, rgb, width, height, flipVertically != 0)) throw std::runtime_error("nxh_write_exr: cannot write the file");
+    });
+}
 
 }  // extern "C"

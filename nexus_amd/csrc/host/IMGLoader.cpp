@@ -3,9 +3,12 @@
 
 #include <zlib.h>
 
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <string>
 #include <stdexcept>
 #include <vector>
 
@@ -26,8 +29,84 @@ int paeth(int a, int b, int c)
 
 }  // namespace
 
+namespace {
+
+// Radiance .hdr (RGBE, flat or run-length encoded scanlines) reduced to 8 bits the way stbi_load does for an HDR file
+// (stb_image: stbi__hdr_load then stbi__hdr_to_ldr with gamma 2.2, scale 1): c8 = clamp(pow(c, 1 / 2.2) * 255 + 0.5), alpha 255.
+Texture load_radiance_hdr(const unsigned char* data, size_t size)
+{
+    size_t pos = 0;
+    auto line = [&]() {
+        std::string l;
+        while (pos < size && data[pos] != '\n') l.push_back(static_cast<char>(data[pos++]));
+        if (pos < size) pos++;
+        return l;
+    };
+    const std::string magic = line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") fail("not a Radiance HDR file");
+    bool format = false;
+    for (;;) {
+        if (pos >= size) fail("HDR header is not terminated");
+        const std::string l = line();
+        if (l.empty()) break;
+        if (l == "FORMAT=32-bit_rle_rgbe") format = true;
+    }
+    if (!format) fail("unsupported HDR format (need 32-bit_rle_rgbe)");
+    const std::string res = line();
+    int h = 0, w = 0;
+    if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0 || w > 32768 || h > 32768) fail("unsupported HDR orientation / size");
+    std::vector<unsigned char> rgbe(static_cast<size_t>(w) * h * 4);
+    for (int y = 0; y < h; y++) {
+        unsigned char* row = rgbe.data() + static_cast<size_t>(y) * w * 4;
+        if (w >= 8 && w < 32768 && pos + 4 <= size && data[pos] == 2 && data[pos + 1] == 2 && !(data[pos + 2] & 0x80) && ((data[pos + 2] << 8) | data[pos + 3]) == w) {
+            pos += 4;  // new-style RLE: the four components of the line one after the other
+            for (int c = 0; c < 4; c++) {
+                int x = 0;
+                while (x < w) {
+                    if (pos >= size) fail("HDR data ends early");
+                    int count = data[pos++];
+                    if (count > 128) {  // run
+                        count -= 128;
+                        if (count == 0 || x + count > w || pos >= size) fail("corrupt HDR run");
+                        const unsigned char v = data[pos++];
+                        for (int k = 0; k < count; k++) row[4 * (x++) + c] = v;
+                    } else {  // literal
+                        if (count == 0 || x + count > w || pos + static_cast<size_t>(count) > size) fail("corrupt HDR literal");
+                        for (int k = 0; k < count; k++) row[4 * (x++) + c] = data[pos++];
+                    }
+                }
+            }
+        } else {  // flat
+            if (pos + static_cast<size_t>(w) * 4 > size) fail("HDR data ends early");
+            std::memcpy(row, data + pos, static_cast<size_t>(w) * 4);
+            pos += static_cast<size_t>(w) * 4;
+        }
+    }
+    Texture tex;
+    tex.width = static_cast<uint32_t>(w);
+    tex.height = static_cast<uint32_t>(h);
+    tex.channels = 3;
+    tex.pixels.resize(static_cast<size_t>(w) * h * 4);
+    for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) {
+        const unsigned char* p = &rgbe[4 * i];
+        for (int c = 0; c < 3; c++) {
+            float f = 0.0f;
+            if (p[3] != 0) f = static_cast<float>(p[c]) * std::ldexp(1.0f, static_cast<int>(p[3]) - (128 + 8));
+            float z = static_cast<float>(std::pow(static_cast<double>(f), static_cast<double>(1.0f / 2.2f))) * 255.0f + 0.5f;  // stb: (float)pow(x, gamma)
+            if (z < 0.0f) z = 0.0f;
+            if (z > 255.0f) z = 255.0f;
+            tex.pixels[4 * i + static_cast<size_t>(c)] = static_cast<unsigned char>(static_cast<int>(z));
+        }
+        tex.pixels[4 * i + 3] = 255;
+    }
+    return tex;
+}
+
+}  // namespace
+
 Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
 {
+    if (size >= 2 && data[0] == '#' && data[1] == '?') return load_radiance_hdr(data, size);
     static const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (size >= 3 && data[0] == 0xff && data[1] == 0xd8) fail("JPEG images are not supported (PNG only)");
     if (size < 8 || std::memcmp(data, kSig, 8) != 0) fail("not a PNG file");

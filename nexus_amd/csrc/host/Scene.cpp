@@ -3,6 +3,7 @@
 // emissive map or intensity * max(emissive) > 0; the TLAS is rebuilt whenever an instance changed.
 #include "nexus/Scene.h"
 
+#include "nexus/IMGLoader.h"
 #include "nexus/OBJLoader.h"
 
 namespace nexus {
@@ -104,6 +105,8 @@ void Scene::AddHDRMap(const Texture& texture)
     m_HdrMap = texture;
     hdrDirty = true;
 }
+
+void Scene::AddHDRMap(const std::string& filePath, const std::string& fileName) { AddHDRMap(IMGLoader::LoadIMG(filePath + fileName)); }
 
 size_t Scene::AddLight(const Light& light)
 {

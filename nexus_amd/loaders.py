@@ -78,6 +78,62 @@ class LoadedScene:
         self.warnings = []
 
 
+def decode_hdr(data):
+    """Radiance .hdr (RGBE, flat or run-length encoded) -> HxWx4 uint8 the way stbi_load reduces an HDR file to 8 bits
+    (stb_image stbi__hdr_to_ldr: gamma 2.2, scale 1, alpha 255) — what Scene::AddHDRMap gets from IMGLoader (Scene.cpp:93-97)."""
+    data = bytes(data)
+    pos = 0
+
+    def line():
+        nonlocal pos
+        end = data.index(b"\n", pos)
+        l = data[pos:end]
+        pos = end + 1
+        return l
+
+    if line() not in (b"#?RADIANCE", b"#?RGBE"):
+        raise ValueError("not a Radiance HDR file")
+    fmt = False
+    while True:
+        l = line()
+        if not l:
+            break
+        fmt = fmt or l == b"FORMAT=32-bit_rle_rgbe"
+    if not fmt:
+        raise ValueError("unsupported HDR format")
+    parts = line().split()
+    if len(parts) != 4 or parts[0] != b"-Y" or parts[2] != b"+X":
+        raise ValueError("unsupported HDR orientation")
+    h, w = int(parts[1]), int(parts[3])
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    for y in range(h):
+        if 8 <= w < 32768 and data[pos] == 2 and data[pos + 1] == 2 and not (data[pos + 2] & 0x80) and ((data[pos + 2] << 8) | data[pos + 3]) == w:
+            pos += 4
+            for c in range(4):
+                x = 0
+                while x < w:
+                    count = data[pos]
+                    pos += 1
+                    if count > 128:
+                        count -= 128
+                        rgbe[y, x: x + count, c] = data[pos]
+                        pos += 1
+                    else:
+                        rgbe[y, x: x + count, c] = np.frombuffer(data, dtype=np.uint8, count=count, offset=pos)
+                        pos += count
+                    x += count
+        else:
+            rgbe[y] = np.frombuffer(data, dtype=np.uint8, count=4 * w, offset=pos).reshape(w, 4)
+            pos += 4 * w
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e != 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0.0)).astype(np.float32)
+    f = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    z = np.power(f.astype(np.float64), np.float64(np.float32(1.0) / np.float32(2.2))).astype(np.float32) * np.float32(255.0) + np.float32(0.5)
+    out = np.full((h, w, 4), 255, dtype=np.uint8)
+    out[..., :3] = np.clip(z, 0.0, 255.0).astype(np.int32).astype(np.uint8)
+    return out, 3
+
+
 def decode_png(data):
     """PNG (ISO/IEC 15948) -> (HxWx4 uint8, channels of the file), what stbi_load(..., 4) returns and the reference's
     IMGLoader hands to Texture (Assets/IMGLoader.cpp:17-41): all colour types, 1-16 bits, palette / colour-key
