@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
-    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_build_blas", "nxhip_read_blas",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
 ]
@@ -559,6 +559,10 @@ class Context:
     def compose_tiles(self, src_accum_dev_ptr, count, pixel_map_dev_ptr, dst_accum_dev_ptr, dst_rgba8_dev_ptr=None):
         check(self.L.nxhip_compose_tiles(self.h, C.c_void_p(src_accum_dev_ptr), count, C.c_void_p(pixel_map_dev_ptr) if pixel_map_dev_ptr else None,
                                          C.c_void_p(dst_accum_dev_ptr), C.c_void_p(dst_rgba8_dev_ptr) if dst_rgba8_dev_ptr else None), "nxhip_compose_tiles")
+
+    def set_env_sampling(self, on=True):
+        self.L.nxhip_set_env_sampling.argtypes = [C.c_void_p, C.c_int]
+        check(self.L.nxhip_set_env_sampling(self.h, 1 if on else 0), "nxhip_set_env_sampling")
 
     def set_passes_in_flight(self, passes):
         self.L.nxhip_set_passes_in_flight.argtypes = [C.c_void_p, C.c_uint32]

@@ -123,6 +123,10 @@ struct nxhip_ctx : nxd::PassSlot {
     std::vector<nxd::TextureHost> diffuseMaps, emissiveMaps;
     nxd::TextureHost hdrMap;
     nxd::DevBuf diffuseTable, emissiveTable, srgbLut;
+    // environment importance sampling (extension): host copy of the hdr map and the tables built from it
+    std::vector<uint8_t> hostHdr;
+    bool envSampling = false;
+    nxd::DevBuf envMarginalCdf, envRowCdf, envDensity;
     // paths / queues
     nxd::DevBuf pixelMap, accumulation, rgba8;
     nxd::DevBuf traceStats;

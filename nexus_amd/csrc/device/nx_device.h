@@ -143,6 +143,12 @@ struct DeviceState {
     nx_camera camera;
     nx_render_settings settings;
     int32_t rngMode, compactMode, conductorMode;
+    // environment importance sampling (extension, nxhip_set_env_sampling): piecewise-constant distribution over the texels of
+    // hdrMap — marginal cdf over rows [height], conditional cdf per row [height][width], pdf per solid angle x cos(latitude)
+    int32_t envSampling;
+    const NX_G float* envMarginalCdf;
+    const NX_G float* envRowCdf;
+    const NX_G float* envDensity;
     // paths: a pass renders framesPerPass consecutive frames at once; path p belongs to frame slice p / localCount
     // and to local pixel p % localCount.  Batching frames keeps every kernel large (the tail of a trace launch is
     // set by its slowest ray) and uses HBM capacity instead of launches.

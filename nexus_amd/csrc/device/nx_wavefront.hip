@@ -195,6 +195,60 @@ NXD f3 sample_background(const DeviceState* S, f3 d)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Environment importance sampling — an extension (the reference adds the environment on a miss only, PathTracer.cu:152-164,
+// so an HDR map with a small bright sun converges very slowly): the NEE may pick the environment as one more light and
+// draws its direction from the map's luminance distribution; a BSDF-sampled ray that misses is MIS-weighted against it.
+
+// the texel a direction falls in, with (u, v) exactly as sample_background computes them
+NXD uint32_t env_texel(const DeviceState* S, f3 d)
+{
+    const float theta = atan2f(d.z, d.x);
+    const float phi = asinf(d.y);
+    const float u = (float)((theta + kPiD) * kInvPi * 0.5);
+    const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
+    const int W = (int)S->hdrMap.width, H = (int)S->hdrMap.height;
+    const int x = min(max((int)(u * (float)W), 0), W - 1), y = min(max((int)(v * (float)H), 0), H - 1);
+    return (uint32_t)y * (uint32_t)W + (uint32_t)x;
+}
+
+// pdf per solid angle of the environment sampler for the unit direction d (light-selection probability excluded)
+NXD float env_pdf(const DeviceState* S, f3 d)
+{
+    const float cosLat = sqrtf(fmaxf(1.0f - d.y * d.y, 1.0e-12f));
+    return S->envDensity[env_texel(S, d)] / cosLat;
+}
+
+NXD int cdf_find(const NX_G float* cdf, int n, float r)  // first index whose cdf exceeds r
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > r) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+NXD f3 env_sample(const DeviceState* S, float r1, float r2)
+{
+    const int W = (int)S->hdrMap.width, H = (int)S->hdrMap.height;
+    const int y = cdf_find(S->envMarginalCdf, H, r1);
+    const float ylo = y ? S->envMarginalCdf[y - 1] : 0.0f;
+    const float fy = (r1 - ylo) / (S->envMarginalCdf[y] - ylo);
+    const NX_G float* row = S->envRowCdf + (size_t)y * (size_t)W;
+    const int x = cdf_find(row, W, r2);
+    const float xlo = x ? row[x - 1] : 0.0f;
+    const float fx = (r2 - xlo) / (row[x] - xlo);
+    const float u = ((float)x + fx) / (float)W, v = ((float)y + fy) / (float)H;
+    const float phi = (1.0f - v) * 3.14159265f - 1.57079633f, theta = u * 6.28318531f - 3.14159265f;
+    const float c = cosf(phi);
+    return mk3(c * cosf(theta), sinf(phi), c * sinf(theta));
+}
+
+// lights the NEE chooses among: the mesh lights, plus the environment when it is importance sampled
+NXD uint32_t nee_light_count(const DeviceState* S) { return S->lightCount + ((S->envSampling && S->hdrMap.texels) ? 1u : 0u); }
+
+// ------------------------------------------------------------------------------------------------------
 // LogicKernel — PathTracer.cu:136-210
 
 template <bool ORDERED>
@@ -223,7 +277,12 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
             const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
             const f3 throughput = mk3(tp.x, tp.y, tp.z);
             if (hit.x == 1e30f) {
-                const f3 bg = throughput * sample_background(S, dir);
+                f3 bg = throughput * sample_background(S, dir);
+                if (S->envSampling && S->hdrMap.texels && bounce > 1 && S->settings.useMIS) {
+                    // the NEE samples the environment too: weight the BSDF-sampled miss against it (extension)
+                    const float envPdf = env_pdf(S, dir) / (float)nee_light_count(S);
+                    if (pdf_valid(envPdf)) bg = bg * power_heuristic(tp.w, envPdf);
+                }
                 float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
                 r.x += bg.x; r.y += bg.y; r.z += bg.z;
                 if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
@@ -283,8 +342,28 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
 {
     // no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
     // drawn", identically in the CPU restatement used by the tests
-    if (S->lightCount == 0u) return false;
-    const nx_light light = S->lights[uniform_index(S->lightCount, rng)];
+    const uint32_t nLights = nee_light_count(S);
+    if (nLights == 0u) return false;
+    const uint32_t pick = uniform_index(nLights, rng);
+    if (pick >= S->lightCount) {
+        // the environment (extension): direction from the map's luminance distribution, shadow ray to infinity
+        const float r1 = rng_next(rng), r2 = rng_next(rng);
+        const f3 shDir = env_sample(S, r1, r2);
+        const float lightPdf = env_pdf(S, shDir) / (float)nLights;
+        if (!pdf_valid(lightPdf)) return false;
+        const float4 q = rotation_to_z(normal);
+        const f3 wo = rotate_point(q, shDir);
+        f3 sampleThroughput;
+        float bsdfPdf;
+        if (!Bsdf<TYPE>::eval(mp, wi, wo, sampleThroughput, bsdfPdf)) return false;
+        const float weight = power_heuristic(lightPdf, bsdfPdf);
+        out.radiance = (((throughput * weight) * sampleThroughput) * sample_background(S, shDir)) / lightPdf;
+        out.origin = offset_ray(hitPoint, hitGNormal * sgnE(dot3(shDir, normal)));
+        out.direction = shDir;
+        out.distance = 1e30f;
+        return true;
+    }
+    const nx_light light = S->lights[pick];
     if (light.type != NX_LIGHT_MESH) return false;
     const nx_bvh_instance* inst = &S->instances[light.mesh.meshId];
     const BlasDev* bvh = &S->blas[inst->bvhIdx];
@@ -314,7 +393,7 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
     const float cosThetaO = fabsf(dot3(lightNormal, out.direction));
     const float dSquared = dot3(toLight, toLight);
     const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
-    float lightPdf = 1.0f / ((float)(S->lightCount * bvh->triCount) * area);
+    float lightPdf = 1.0f / ((float)(nLights * bvh->triCount) * area);
     lightPdf *= dSquared / cosThetaO;
     if (!pdf_valid(lightPdf)) return false;
 
@@ -402,7 +481,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
                     const float4 ro = S->rayOrigin[pixelIdx];
                     const float dSquared = squaref(length3(p - mk3(ro.x, ro.y, ro.z)));
                     const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
-                    float lightPdf = 1.0f / ((float)(S->lightCount * bvh->triCount) * area);
+                    float lightPdf = 1.0f / ((float)(nee_light_count(S) * bvh->triCount) * area);
                     lightPdf *= dSquared / cosThetaO;
                     if (!pdf_valid(lightPdf)) weight = 0.0f;
                     else weight = power_heuristic(lastPdf, lightPdf);

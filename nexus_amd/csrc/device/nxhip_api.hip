@@ -756,6 +756,78 @@ static int refresh_texture_tables(nxhip_ctx* c)
     return NXHIP_OK;
 }
 
+// Sampling distribution of the environment map (see nx_wavefront.hip, "Environment importance sampling"): texel weight =
+// luminance of the sRGB-decoded texel x sin(polar angle of its row) + 1e-6, accumulated in double; cdfs as float ending in
+// exactly 1; density = weight / total x width x height / (2 pi^2) = pdf per solid angle x cos(latitude).
+static int build_env_tables(nxhip_ctx* c)
+{
+    const uint32_t W = c->hdrMap.width, H = c->hdrMap.height;
+    if (!c->envSampling || W == 0 || H == 0 || c->hostHdr.size() != (size_t)W * H * 4) {
+        c->h.envSampling = 0;
+        c->h.envMarginalCdf = c->h.envRowCdf = c->h.envDensity = nullptr;
+        c->stateDirty = true;
+        return NXHIP_OK;
+    }
+    float lut[256];
+    for (int i = 0; i < 256; i++) {
+        const float x = (float)i / 255.0f;
+        lut[i] = x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
+    }
+    const double pi = 3.14159265358979323846;
+    std::vector<float> marginal(H), row((size_t)W * H), density((size_t)W * H);
+    std::vector<double> rowSum(H);
+    double total = 0.0;
+    for (uint32_t y = 0; y < H; y++) {
+        const double sinTheta = std::sin(pi * ((double)y + 0.5) / (double)H);
+        double run = 0.0;
+        for (uint32_t x = 0; x < W; x++) {
+            const uint8_t* t = &c->hostHdr[4 * ((size_t)y * W + x)];
+            const double lum = 0.2126 * (double)lut[t[0]] + 0.7152 * (double)lut[t[1]] + 0.0722 * (double)lut[t[2]];
+            const double wgt = lum * sinTheta + 1e-6;
+            density[(size_t)y * W + x] = (float)wgt;
+            run += wgt;
+            row[(size_t)y * W + x] = (float)run;
+        }
+        rowSum[y] = run;
+        total += run;
+    }
+    double run = 0.0;
+    for (uint32_t y = 0; y < H; y++) {
+        for (uint32_t x = 0; x < W; x++) {
+            const size_t i = (size_t)y * W + x;
+            row[i] = x == W - 1 ? 1.0f : (float)((double)row[i] / rowSum[y]);
+            density[i] = (float)((double)density[i] / total * (double)W * (double)H / (2.0 * pi * pi));
+        }
+        run += rowSum[y];
+        marginal[y] = y == H - 1 ? 1.0f : (float)(run / total);
+    }
+    NX_SYNC_ALL(c);
+    NX_ALLOC(c->envMarginalCdf, marginal.size() * 4);
+    NX_ALLOC(c->envRowCdf, row.size() * 4);
+    NX_ALLOC(c->envDensity, density.size() * 4);
+    NX_HIP(hipMemcpy(c->envMarginalCdf.p, marginal.data(), marginal.size() * 4, hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->envRowCdf.p, row.data(), row.size() * 4, hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->envDensity.p, density.data(), density.size() * 4, hipMemcpyHostToDevice));
+    c->h.envSampling = 1;
+    c->h.envMarginalCdf = c->envMarginalCdf.as<float>();
+    c->h.envRowCdf = c->envRowCdf.as<float>();
+    c->h.envDensity = c->envDensity.as<float>();
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_set_env_sampling(nxhip_ctx* c, int enable)
+try {
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    if (enable && !c->hdrMap.texels.p) return fail_invalid("nxhip_set_env_sampling: upload the environment map first (nxhip_upload_texture kind 2)");
+    c->envSampling = enable != 0;
+    return build_env_tables(c);
+} catch (const std::exception& e) {
+    set_error(std::string("nxhip_set_env_sampling: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
 int nxhip_upload_texture(nxhip_ctx* c, int kind, const uint8_t* rgba8, uint32_t width, uint32_t height, int32_t* texId)
 try {
     NX_CHECK_CTX(c);
@@ -769,9 +841,15 @@ try {
     int32_t id = 0;
     if (kind == 0) { c->diffuseMaps.push_back(std::move(t)); id = (int32_t)c->diffuseMaps.size() - 1; }
     else if (kind == 1) { c->emissiveMaps.push_back(std::move(t)); id = (int32_t)c->emissiveMaps.size() - 1; }
-    else { NX_SYNC_ALL(c); c->hdrMap = std::move(t); }
+    else {
+        NX_SYNC_ALL(c);
+        c->hdrMap = std::move(t);
+        c->hostHdr.assign(rgba8, rgba8 + (size_t)width * height * 4);
+    }
     if (texId) *texId = id;
-    return refresh_texture_tables(c);
+    const int rc = refresh_texture_tables(c);
+    if (rc != NXHIP_OK || kind != 2) return rc;
+    return build_env_tables(c);  // a new map under an enabled sampler gets new tables
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_upload_texture: ") + e.what());
     return NXHIP_ERR_INVALID;
@@ -785,6 +863,10 @@ try {
     c->diffuseMaps.clear();
     c->emissiveMaps.clear();
     c->hdrMap = TextureHost();
+    c->hostHdr.clear();
+    c->envSampling = false;
+    const int rc = build_env_tables(c);
+    if (rc != NXHIP_OK) return rc;
     return refresh_texture_tables(c);
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_clear_textures: ") + e.what());

@@ -63,6 +63,7 @@ class Workload:
         self.camera = camera
         self.settings = settings if settings is not None else make_settings()
         self.diffuse_maps, self.emissive_maps, self.hdr_map = list(diffuse_maps), list(emissive_maps), hdr_map
+        self.env_sampling = False  # extension: importance-sample the environment map in the NEE (nxhip_set_env_sampling)
 
     @property
     def triangles(self):
@@ -107,6 +108,7 @@ class Workload:
             ctx.upload_texture("emissive", img)
         if self.hdr_map is not None:
             ctx.upload_texture("hdr", self.hdr_map)
+            ctx.set_env_sampling(self.env_sampling)
         if self.camera is not None:
             ctx.set_camera(self.camera)
         ctx.set_render_settings(self.settings)

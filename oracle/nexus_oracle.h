@@ -100,7 +100,19 @@ typedef struct orc_scene {
     const nx_texture_desc *hdrMap; /* NULL: flat background */
     nx_camera camera;
     nx_render_settings settings;
+    /* Extension (no counterpart in the reference, which adds the environment on a miss only, PathTracer.cu:152-164):
+     * importance sampling of the environment map in NEE + MIS on a miss — include/nexus_hip.h nxhip_set_env_sampling.
+     * The three tables are filled by orc_env_distribution. */
+    int32_t envSampling;
+    const float *envMarginalCdf; /* [height] */
+    const float *envRowCdf;      /* [height][width] */
+    const float *envDensity;     /* [height][width]: pdf per solid angle x cos(latitude) */
 } orc_scene;
+
+/* Piecewise-constant sampling distribution of an equirectangular map: texel weight = luminance of the sRGB-decoded texel
+ * x sin(polar angle of the row) + 1e-6, accumulated in double; cdfs as float with a final 1; density = weight / total
+ * x width x height / (2 pi^2). */
+void orc_env_distribution(const nx_texture_desc *hdr, float *marginalCdf, float *rowCdf, float *density);
 
 /* Visit counters for the roofline's algorithmic bytes. */
 typedef struct orc_trace_stats {

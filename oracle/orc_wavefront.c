@@ -112,6 +112,92 @@ static f3 sample_background(const orc_scene *s, f3 d)
     return scale3(ld3(s->settings.backgroundColor), s->settings.backgroundIntensity);
 }
 
+/* ---- environment importance sampling (extension; see nexus_oracle.h) -------------------------------------------- */
+
+void orc_env_distribution(const nx_texture_desc *hdr, float *marginalCdf, float *rowCdf, float *density)
+{
+    const int W = (int)hdr->width, H = (int)hdr->height;
+    double *rowSum = (double *)malloc(sizeof(double) * (size_t)H);
+    double total = 0.0;
+    for (int y = 0; y < H; y++) {
+        const double sinTheta = sin(3.14159265358979323846 * ((double)y + 0.5) / (double)H);
+        double run = 0.0;
+        for (int x = 0; x < W; x++) {
+            const uint8_t *t = hdr->rgba8 + 4 * ((size_t)y * (size_t)W + (size_t)x);
+            const double lum = 0.2126 * (double)orc_srgb_to_linear(t[0]) + 0.7152 * (double)orc_srgb_to_linear(t[1]) + 0.0722 * (double)orc_srgb_to_linear(t[2]);
+            const double wgt = lum * sinTheta + 1e-6;
+            density[(size_t)y * (size_t)W + (size_t)x] = (float)wgt; /* scaled below */
+            run += wgt;
+            rowCdf[(size_t)y * (size_t)W + (size_t)x] = (float)run; /* normalised below */
+        }
+        rowSum[y] = run;
+        total += run;
+    }
+    double run = 0.0;
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            const size_t i = (size_t)y * (size_t)W + (size_t)x;
+            rowCdf[i] = x == W - 1 ? 1.0f : (float)((double)rowCdf[i] / rowSum[y]);
+            density[i] = (float)((double)density[i] / total * (double)W * (double)H / (2.0 * 3.14159265358979323846 * 3.14159265358979323846));
+        }
+        run += rowSum[y];
+        marginalCdf[y] = y == H - 1 ? 1.0f : (float)(run / total);
+    }
+    free(rowSum);
+}
+
+/* (u, v) of a direction exactly as SampleBackground computes them, and the texel they fall in */
+static void env_texel(const orc_scene *s, f3 d, int *x, int *y)
+{
+    const float theta = atan2f(d.z, d.x);
+    const float phi = asinf(d.y);
+    const float u = (float)((theta + ORC_PI) * ORC_INV_PI * 0.5);
+    const float v = (float)(1.0f - (phi + ORC_PI * 0.5f) * ORC_INV_PI);
+    const int W = (int)s->hdrMap->width, H = (int)s->hdrMap->height;
+    int xi = (int)(u * (float)W), yi = (int)(v * (float)H);
+    *x = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi);
+    *y = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
+}
+
+/* pdf per solid angle of the environment sampler for direction d (unit length), light-selection probability excluded */
+static float env_pdf(const orc_scene *s, f3 d)
+{
+    int x, y;
+    env_texel(s, d, &x, &y);
+    const float cosLat = sqrtf(fmaxf(1.0f - d.y * d.y, 1.0e-12f));
+    return s->envDensity[(size_t)y * s->hdrMap->width + (size_t)x] / cosLat;
+}
+
+static int cdf_find(const float *cdf, int n, float r)  /* first index whose cdf exceeds r */
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > r) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+static f3 env_sample(const orc_scene *s, float r1, float r2)
+{
+    const int W = (int)s->hdrMap->width, H = (int)s->hdrMap->height;
+    const int y = cdf_find(s->envMarginalCdf, H, r1);
+    const float ylo = y ? s->envMarginalCdf[y - 1] : 0.0f;
+    const float fy = (r1 - ylo) / (s->envMarginalCdf[y] - ylo);
+    const float *row = s->envRowCdf + (size_t)y * (size_t)W;
+    const int x = cdf_find(row, W, r2);
+    const float xlo = x ? row[x - 1] : 0.0f;
+    const float fx = (r2 - xlo) / (row[x] - xlo);
+    const float u = ((float)x + fx) / (float)W, v = ((float)y + fy) / (float)H;
+    const float phi = (1.0f - v) * 3.14159265f - 1.57079633f, theta = u * 6.28318531f - 3.14159265f;
+    const float c = cosf(phi);
+    return mk3(c * cosf(theta), sinf(phi), c * sinf(theta));
+}
+
+/* lights the NEE chooses among: the mesh lights, plus the environment when it is importance sampled */
+static uint32_t nee_light_count(const orc_scene *s) { return s->lightCount + (s->envSampling && s->hdrMap ? 1u : 0u); }
+
 /* GenerateKernel — PathTracer.cu:85-122 */
 static void generate(orc_wavefront *w)
 {
@@ -211,7 +297,12 @@ static void logic(orc_wavefront *w, uint32_t bounce)
         const f3 throughput = bounce == 1 ? mk3s(1.0f) : w->throughput[pixelIdx];
 
         if (hit.hitDistance == 1e30f) {
-            const f3 bg = mul3(throughput, sample_background(s, dir));
+            f3 bg = mul3(throughput, sample_background(s, dir));
+            if (s->envSampling && s->hdrMap && bounce > 1 && s->settings.useMIS) {
+                /* the NEE samples the environment too: weight the BSDF-sampled miss against it (extension) */
+                const float envPdf = env_pdf(s, dir) / (float)nee_light_count(s);
+                if (orc_pdf_valid(envPdf)) bg = scale3(bg, orc_power_heuristic(w->lastPdf[pixelIdx], envPdf));
+            }
             if (bounce == 1) w->radiance[pixelIdx] = bg;
             else w->radiance[pixelIdx] = add3(w->radiance[pixelIdx], bg);
             continue;
@@ -242,8 +333,31 @@ static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *mat
     const orc_scene *s = w->scene;
     /* no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
      * drawn", identically in the device code */
-    if (s->lightCount == 0u) return;
-    const nx_light light = s->lights[orc_uniform(s->lightCount, rng)];
+    const uint32_t nLights = nee_light_count(s);
+    if (nLights == 0u) return;
+    const uint32_t pick = orc_uniform(nLights, rng);
+    if (pick >= s->lightCount) {
+        /* the environment (extension): direction from the map's luminance distribution, shadow ray to infinity */
+        const float r1 = orc_rand(rng), r2 = orc_rand(rng);
+        const f3 shDir = env_sample(s, r1, r2);
+        const float lightPdf = env_pdf(s, shDir) / (float)nLights;
+        if (!orc_pdf_valid(lightPdf)) return;
+        const f4 q = rotation_to_z(normal);
+        const f3 wo = rotate_point(q, shDir);
+        f3 sampleThroughput;
+        float bsdfPdf;
+        if (!orc_bsdf_eval_f3(material, wi, wo, &sampleThroughput, &bsdfPdf)) return;
+        const float weight = orc_power_heuristic(lightPdf, bsdfPdf);
+        const f3 radiance = div3s(mul3(mul3(scale3(throughput, weight), sampleThroughput), sample_background(s, shDir)), lightPdf);
+        const int32_t slot = w->q.traceShadowSize[bounce]++;
+        w->shDistance[slot] = 1e30f;
+        w->shRadiance[slot] = radiance;
+        w->shOrigin[slot] = offset_ray(hitPoint, scale3(hitGNormal, sgnE(dot3(shDir, normal))));
+        w->shDirection[slot] = shDir;
+        w->shPixel[slot] = pixelIdx;
+        return;
+    }
+    const nx_light light = s->lights[pick];
     if (light.type != NX_LIGHT_MESH) return;
 
     const nx_bvh_instance *inst = &s->instances[light.mesh.meshId];
@@ -274,7 +388,7 @@ static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *mat
     const float dSquared = dot3(toLight, toLight);
     const float area = tri_area(mat_point(&inst->transform, ld3(tri->pos0)), mat_point(&inst->transform, ld3(tri->pos1)),
                                 mat_point(&inst->transform, ld3(tri->pos2)));
-    float lightPdf = 1.0f / ((float)(s->lightCount * bvh->triCount) * area);
+    float lightPdf = 1.0f / ((float)(nLights * bvh->triCount) * area);
     lightPdf *= dSquared / cosThetaO;
     if (!orc_pdf_valid(lightPdf)) return;
 
@@ -340,7 +454,7 @@ static void shade(orc_wavefront *w, uint32_t bounce, int type)
                 const float dSquared = squaref(length3(sub3(p, w->rayOrigin[pixelIdx])));
                 const float area = tri_area(mat_point(&inst->transform, ld3(tri->pos0)), mat_point(&inst->transform, ld3(tri->pos1)),
                                             mat_point(&inst->transform, ld3(tri->pos2)));
-                float lightPdf = 1.0f / ((float)(s->lightCount * bvh->triCount) * area);
+                float lightPdf = 1.0f / ((float)(nee_light_count(s) * bvh->triCount) * area);
                 lightPdf *= dSquared / cosThetaO;
                 if (!orc_pdf_valid(lightPdf)) weight = 0.0f;
                 else weight = orc_power_heuristic(lastPdf, lightPdf);

@@ -50,6 +50,7 @@ class _Scene(C.Structure):
         ("lights", C.c_void_p), ("lightCount", C.c_uint32),
         ("diffuseMaps", C.c_void_p), ("emissiveMaps", C.c_void_p), ("hdrMap", C.c_void_p),
         ("camera", C.c_uint8 * 88), ("settings", C.c_uint8 * 20),
+        ("envSampling", C.c_int32), ("envMarginalCdf", C.c_void_p), ("envRowCdf", C.c_void_p), ("envDensity", C.c_void_p),
     ]
 
 
@@ -195,7 +196,7 @@ class OracleScene:
     """Owns the numpy buffers behind an ``orc_scene``."""
 
     def __init__(self, blas_list, instances, tlas_nodes, tlas_idx, materials=None, lights=None, camera=None, settings=None,
-                 diffuse_maps=(), emissive_maps=(), hdr_map=None):
+                 diffuse_maps=(), emissive_maps=(), hdr_map=None, env_sampling=False):
         # blas_list: list of (nodes NODE_DT[], tris TRI_DT[], triIdx u32[])
         self.keep = []
         self.blas_arr = (_Blas * max(1, len(blas_list)))()
@@ -222,6 +223,16 @@ class OracleScene:
         s.emissiveMaps = C.cast(self._emaps, C.c_void_p) if self._emaps is not None else None
         self._hdr = self._tex_array([hdr_map]) if hdr_map is not None else None
         s.hdrMap = C.cast(self._hdr, C.c_void_p) if self._hdr is not None else None
+        s.envSampling = 0
+        if env_sampling and hdr_map is not None:  # the extension of nxhip_set_env_sampling, restated in orc_wavefront.c
+            h, w = np.asarray(hdr_map).shape[:2]
+            self.env_marginal = np.zeros(h, np.float32)
+            self.env_row = np.zeros(h * w, np.float32)
+            self.env_density = np.zeros(h * w, np.float32)
+            lib().orc_env_distribution.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib().orc_env_distribution(C.cast(self._hdr, C.c_void_p), _ptr(self.env_marginal), _ptr(self.env_row), _ptr(self.env_density))
+            s.envSampling = 1
+            s.envMarginalCdf, s.envRowCdf, s.envDensity = _ptr(self.env_marginal), _ptr(self.env_row), _ptr(self.env_density)
         self.c = s
         if camera is not None:
             self.set_camera(camera)

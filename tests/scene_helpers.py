@@ -11,7 +11,7 @@ class BuiltScene(workloads.Workload):
 
     def oracle(self):
         return O.OracleScene(self.blas, self.instances, self.tlas_nodes, self.tlas_idx, self.materials, self.lights, self.camera, self.settings,
-                             self.diffuse_maps, self.emissive_maps, self.hdr_map)
+                             self.diffuse_maps, self.emissive_maps, self.hdr_map, env_sampling=self.env_sampling)
 
 
 mesh_lights = workloads.mesh_lights
