@@ -66,13 +66,19 @@ def build_workload(args):
         sc = workloads.config2(args.width, args.height, args.nu, args.nv, args.path_length)
         name = ("configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
                 % (sc.triangles, sc.bvh8_nodes, args.width, args.height, args.path_length))
+    elif args.config == 4:
+        sc = workloads.config4(args.width, args.height, args.path_length)
+        sc.env_sampling = True  # configs[3] asks for "HDR envmap NEE/MIS": the extension of nxhip_set_env_sampling
+        name = ("configs[3]: %d instances of a %d-triangle BLAS (BVH8 %d nodes) on a jittered lattice, random rotations / scales, DIELECTRIC roughness 0.2 ior 1.45, "
+                "2048x1024 procedural environment with NEE / MIS importance sampling (extension), %dx%d, pathLength %d"
+                % (len(sc.instances), sc.unique_triangles, sc.bvh8_nodes, args.width, args.height, args.path_length))
     elif args.config == 5:
         sc = workloads.config5(args.width, args.height, args.path_length)
         name = ("configs[4] on 1 GPU: displaced room shell + instanced props, %d triangles in the TLAS (%d unique, BVH8 %d nodes, %.0f MB of nodes + "
                 "intersection records: beyond the 256 MiB Infinity Cache), all four material types, textured emissive panels, %dx%d, pathLength %d"
                 % (sc.triangles, sc.unique_triangles, sc.bvh8_nodes, sc.scene_bytes() / 1e6, args.width, args.height, args.path_length))
     else:
-        raise SystemExit("--config must be 2 or 5")
+        raise SystemExit("--config must be 2, 4 or 5")
     return sc, name, time.time() - t0
 
 
@@ -120,7 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="frames timed per repetition (default 512; --config 5: 64)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default 64; --config 5: 16)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-frame timed region; the median is reported")
-    ap.add_argument("--config", type=int, default=2, help="2 = BASELINE.json configs[1] (the metric's workload); 5 = configs[4] on one GPU (HBM-resident scene)")
+    ap.add_argument("--config", type=int, default=2, help="2 = BASELINE.json configs[1] (the metric's workload); 4 = configs[3] (instanced TLAS, dielectric, environment NEE / MIS); 5 = configs[4] on one GPU (HBM-resident scene)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--path-length", type=int, default=None)
