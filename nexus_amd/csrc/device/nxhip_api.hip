@@ -34,6 +34,9 @@ void set_error(const std::string& msg) { g_lastError = msg; }
 bool hip_ok(hipError_t e, const char* what, const char* file, int line)
 {
     if (e == hipSuccess) return true;
+    // the failure is reported through the status + message of this call; it must not stay behind as HIP's "last error"
+    // (library code that polls hipGetLastError after its launches — rocPRIM does — would report it as its own)
+    (void)hipGetLastError();
     char buf[512];
     std::snprintf(buf, sizeof buf, "HIP error %d (%s) in '%s' at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
     set_error(buf);
