@@ -192,6 +192,9 @@ def main():
         return [S] * (frames // S) + ([frames % S] if frames % S else [])
 
     sc, workload_name, t_build = build_workload(args)
+    if os.environ.get("NX_BENCH_NO_MIS"):  # experiment only: how much of the shade kernels is next-event estimation
+        sc.settings["useMIS"] = 0
+        workload_name += " [useMIS off: experiment]"
 
     dist = None
     torch = None
