@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     int sp = 0;
 
     bool active = false;
+    bool resultPending = false;  // this lane's ray has finished and its result has not been written yet
     f3 org = mk3(0.0f), dir = mk3(0.0f), idir = mk3(0.0f);
     float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
     uint32_t hitTri = 0xffffffffu, hitInst = 0xffffffffu;
@@ -261,6 +262,25 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 #define NX_STAMP(k) do { if (STATS) { const unsigned long long tNow = (unsigned long long)clock64(); cyc[k] += tNow - tPrev; tPrev = tNow; } } while (0)
 
     for (;;) {
+        // ---- flush: write the results of the rays that finished since the last refill point.  Done here, outside the
+        //      traversal loop, because a retirement inside it made EVERY iteration pay for a handful of lanes: the store
+        //      sequence (closest hit) or, worse, a dependent load -> add -> store of the pixel's radiance with its memory
+        //      round trip (any hit), executed whenever at least one of the 64 lanes retired — nearly always.
+        if (resultPending) {
+            resultPending = false;
+            if (ANY_HIT) {
+                // unoccluded: pathRadiance[pixelIdx] += radiance (BVH8Traversal.cuh:515-516);
+                // at most one shadow ray per pixel and bounce, so no atomic is needed
+                const float4 r = S->shadow.radiance[rayIdx];
+                NX_G float4* dst = &S->radiance[pixelBits];
+                float4 cur = *dst;
+                cur.x += r.x; cur.y += r.y; cur.z += r.z;
+                *dst = cur;
+            } else {
+                S->trace.hit[rayIdx] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
+                S->trace.hitInst[rayIdx] = hitInst;
+            }
+        }
         // ---- refill idle lanes from the wave's reserved range; one atomic reserves kReserve rays of a shard at a time
         //      (a returning atomic on a contended head costs microseconds during which the whole wave stalls, so it
         //      must not be paid per refill)
@@ -343,19 +363,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             // A: acquire work from the stack, or retire the ray
             if (active && tg.y == 0u && (ng.y & 0xff000000u) == 0u) {
                 if (sp == 0) {
+                    // the ray is finished; its result stays in the lane's registers and is written out at the next refill
+                    // point (see "flush"), for all lanes that finished since the last one together
                     active = false;
-                    if (ANY_HIT) {
-                        // unoccluded: pathRadiance[pixelIdx] += radiance (BVH8Traversal.cuh:515-516);
-                        // at most one shadow ray per pixel and bounce, so no atomic is needed
-                        const float4 r = S->shadow.radiance[rayIdx];
-                        NX_G float4* dst = &S->radiance[pixelBits];
-                        float4 cur = *dst;
-                        cur.x += r.x; cur.y += r.y; cur.z += r.z;
-                        *dst = cur;
-                    } else {
-                        S->trace.hit[rayIdx] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
-                        S->trace.hitInst[rayIdx] = hitInst;
-                    }
+                    resultPending = true;
                 } else {
                     if (sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
                         if (xformed) {
