@@ -180,7 +180,7 @@ def main():
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
     S = max(1, min(args.frames_per_pass * world, 512, args.steps))
     n_passes = (args.steps + S - 1) // S
-    R = args.passes_in_flight if args.passes_in_flight else (4 if S <= 4 else 3)   # measured: 1 frame per pass +40 % at 4, 20 frames per pass +13 % at 3
+    R = args.passes_in_flight if args.passes_in_flight else (6 if S <= 4 else 3)   # measured: 1 frame per pass +55 % at 6, 20 frames per pass +13 % at 3
     R = max(1, min(R, 8, n_passes))  # a timed region of fewer passes than that has nothing to overlap with
     if R > 1:
         # concurrent passes need a hardware queue per stream and graph branch; the HIP runtime's default of 4 serialises them.

@@ -79,6 +79,7 @@ struct PassSlot {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graphExec = nullptr;
     bool graphValid = false;
+    bool graphSerialShade = false;  // the shape the graph was built with (see serial_shade)
     // pass bookkeeping (slots >= 1 and slot 0 alike)
     hipEvent_t done = nullptr, accumulated = nullptr;
     bool awaitingAccumulate = false;   // holds a rendered pass that nxhip_accumulate has not consumed yet
@@ -151,4 +152,5 @@ struct nxhip_ctx : nxd::PassSlot {
 
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;
     int shadeBlocksPerCU = 4, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
+    bool serialShade = false;  // the four material kernels of a bounce as one graph branch instead of four
 };

@@ -339,6 +339,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             const int n = std::atoi(e);
             if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
         }
+        if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
             const int n = std::atoi(e);
             if (n >= 1 && n <= 65536) c->traceBlocks = c->shadowBlocks = n;
@@ -1016,6 +1017,12 @@ int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t fram
     return NXHIP_OK;
 }
 
+// Small passes: the four material kernels of a bounce as ONE graph branch.  Parallel branches are spread over hardware
+// queues by the runtime, and with many queues configured (passes in flight need them) the cross-queue hand-offs cost more
+// than the overlap of four short kernels gives: one frame per pass 288 -> 375 Msamples/s at 24 queues, and 6 passes in flight
+// then fit the queues (584 against 537 with 4).  Large passes keep the four branches (20 frames per pass: 1 560 vs 1 505).
+bool serial_shade(const nxhip_ctx* c) { return c->serialShade || c->framesPerPass <= 4u; }
+
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
 std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
@@ -1039,7 +1046,9 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_PLASTIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
         shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIELECTRIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
         if (c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_CONDUCTOR, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
-        if (ordered) for (auto& l : shade) levels.push_back({l});  // serial slot order needs the kernels one after the other
+        // serial slot order needs the kernels one after the other; so do several passes in flight, which would otherwise ask
+        // for four hardware queues per slot (the material kernels of one bounce serialise on the CUs anyway: each grid fills them)
+        if (ordered || serial_shade(c)) for (auto& l : shade) levels.push_back({l});
         else levels.push_back(shade);
         levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce),
                           make_launch(trace_kernel_ptr(true, stats), c->shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
@@ -1130,6 +1139,7 @@ static int build_graph(nxhip_ctx* c, PassSlot* q)
     }
     NX_HIP(hipGraphInstantiate(&q->graphExec, q->graph, nullptr, nullptr, 0));
     q->graphValid = true;
+    q->graphSerialShade = serial_shade(c);
     return NXHIP_OK;
 }
 
@@ -1195,7 +1205,7 @@ try {
                 if (c->timerPool.size() > before) c->timerClass.push_back(l.klass);
             }
     } else {
-        if (!q->graphValid) {
+        if (!q->graphValid || q->graphSerialShade != serial_shade(c)) {  // (the pass size crossed the small-pass threshold)
             rc = build_graph(c, q);
             if (rc != NXHIP_OK) return rc;
         }
