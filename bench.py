@@ -137,7 +137,7 @@ def main():
                          "rank's pass keeps its size); a step budget that is not a multiple ends with one shorter pass")
     ap.add_argument("--passes-in-flight", type=int, default=None,
                     help="passes rendered concurrently on separate streams (nxhip_set_passes_in_flight): the drain of one pass overlaps the bulk of the next. "
-                         "Default: 3 when the timed region has at least 3 passes, else 1")
+                         "Default: 6 for passes of up to 4 frames, else 4; never more than the timed region has passes")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--device-bvh", action="store_true", help="build the BLASes on the GPU (nxhip_build_blas, LBVH) instead of uploading the host SAH builder's: "
                                                               "a faster build, a tree of lower quality; not the metric's configuration")
@@ -180,7 +180,7 @@ def main():
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
     S = max(1, min(args.frames_per_pass * world, 512, args.steps))
     n_passes = (args.steps + S - 1) // S
-    R = args.passes_in_flight if args.passes_in_flight else (6 if S <= 4 else 3)   # measured: 1 frame per pass +55 % at 6, 20 frames per pass +13 % at 3
+    R = args.passes_in_flight if args.passes_in_flight else (6 if S <= 4 else 4)   # measured (sweep in DESIGN.md section 6): 1 frame per pass 418 -> 904 at 6, 20 frames 1 344 -> 1 596 at 4
     R = max(1, min(R, 8, n_passes))  # a timed region of fewer passes than that has nothing to overlap with
     if R > 1:
         # concurrent passes need a hardware queue per stream and graph branch; the HIP runtime's default of 4 serialises them.

@@ -79,7 +79,8 @@ struct PassSlot {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graphExec = nullptr;
     bool graphValid = false;
-    bool graphSerialShade = false;  // the shape the graph was built with (see serial_shade)
+    bool graphSerialShade = false;  // the shape the graph was built with (see serial_shade, trace_blocks)
+    int graphTraceBlocks = 0;
     // pass bookkeeping (slots >= 1 and slot 0 alike)
     hipEvent_t done = nullptr, accumulated = nullptr;
     bool awaitingAccumulate = false;   // holds a rendered pass that nxhip_accumulate has not consumed yet
@@ -150,7 +151,8 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t mgpuTileRows = 0;
     nxd::DevBuf mgpuGathered, mgpuMaps, mgpuFullAccum, mgpuFullRgba8;
 
-    int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;
+    int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;  // full-chip persistent grids (see trace_blocks)
+    bool traceGridForced = false;                            // NX_TRACE_BLOCKS_*: use them as they are
     int shadeBlocksPerCU = 4, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
     bool serialShade = false;  // the four material kernels of a bounce as one graph branch instead of four
 };

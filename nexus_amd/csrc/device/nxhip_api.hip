@@ -317,6 +317,11 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         h.rngMode = NX_RNG_REFERENCE_SLOT;
         h.compactMode = NX_COMPACT_FAST;
         h.conductorMode = NX_CONDUCTOR_REFERENCE;
+        h.traceRaysPerWave = kWave;
+        if (const char* e = std::getenv("NX_TRACE_RAYS_PER_WAVE")) {  // tuning experiments only
+            const int n = std::atoi(e);
+            if (n >= 64 && n <= 65536) h.traceRaysPerWave = n;
+        }
         rc = alloc_paths(c, width * height);
         if (rc != NXHIP_OK) break;
 
@@ -329,7 +334,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         c->wideBlocks = 8 * c->numCUs;
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_PER_CU")) {  // tuning experiments only
             const int n = std::atoi(e);
-            if (n >= 1 && n <= 16) c->traceBlocks = c->shadowBlocks = n * c->numCUs;
+            if (n >= 1 && n <= 16) { c->traceBlocks = c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
         }
         if (const char* e = std::getenv("NX_SHADE_BLOCKS_PER_CU")) {  // tuning experiments only
             const int n = std::atoi(e);
@@ -342,7 +347,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
             const int n = std::atoi(e);
-            if (n >= 1 && n <= 65536) c->traceBlocks = c->shadowBlocks = n;
+            if (n >= 1 && n <= 65536) { c->traceBlocks = c->shadowBlocks = n; c->traceGridForced = true; }
         }
     } while (false);
     if (rc != NXHIP_OK) {
@@ -1023,6 +1028,32 @@ int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t fram
 // then fit the queues (584 against 537 with 4).  Large passes keep the four branches (20 frames per pass: 1 560 vs 1 505).
 bool serial_shade(const nxhip_ctx* c) { return c->serialShade || c->framesPerPass <= 4u; }
 
+// Passes in flight right now: kernel timing and the counting variant measure one pass at a time, and a caller-bound
+// radiance buffer exists once.
+uint32_t effective_slots(const nxhip_ctx* c)
+{
+    if (c->timingEnabled || c->statsEnabled || c->radianceBoundCapacity != 0) return 1u;
+    return std::min<uint32_t>(c->passesInFlight, (uint32_t)c->extra.size());
+}
+
+// Workgroups of a persistent trace launch.  The grid that fills the chip (6 workgroups per CU) is right for ONE large pass.
+// With several passes in flight every slot's closest-hit and any-hit launches would each claim the whole chip and the short
+// logic / shade kernels of the other slots queue behind their drains (one frame per pass, 6 in flight: 580 Msamples/s with
+// full grids, 912 with one workgroup per CU and launch; the logic kernel alone took 9x its solo time).  Throughput saturates
+// at 2-3 waves per SIMD, so the slots share the CU: about 6 / R workgroups per CU each, half as many again for large passes.
+// A single small pass also drains faster on a half-size grid (1 frame per pass 368 -> 419, 8 frames 1 019 -> 1 065).
+int trace_blocks(const nxhip_ctx* c, int fullGrid)
+{
+    if (c->traceGridForced) return fullGrid;
+    const int maxPerCU = std::max(1, fullGrid / std::max(1, c->numCUs));
+    const int R = (int)std::max(1u, effective_slots(c));
+    const bool small = c->framesPerPass <= 8u;
+    int perCU;
+    if (R == 1) perCU = small ? std::min(3, maxPerCU) : maxPerCU;
+    else perCU = ((small ? 2 : 3) * maxPerCU + 2 * R - 1) / (2 * R);
+    return std::min(std::max(perCU, 1), maxPerCU) * c->numCUs;
+}
+
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
 std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
@@ -1034,7 +1065,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int wideThreads = kWideBlockThreads;
     std::vector<std::vector<Launch>> levels;
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
-    levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
+    const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
+    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
     const int og = ordered ? 1 : c->shadeBlocksPerCU * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
     const int lg = ordered ? 1 : c->logicBlocksPerCU * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
@@ -1050,8 +1082,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         // for four hardware queues per slot (the material kernels of one bounce serialise on the CUs anyway: each grid fills them)
         if (ordered || serial_shade(c)) for (auto& l : shade) levels.push_back({l});
         else levels.push_back(shade);
-        levels.push_back({make_launch(trace_kernel_ptr(false, stats), c->traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce),
-                          make_launch(trace_kernel_ptr(true, stats), c->shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
+        levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce),
+                          make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
     }
     return levels;
 }
@@ -1140,16 +1172,10 @@ static int build_graph(nxhip_ctx* c, PassSlot* q)
     NX_HIP(hipGraphInstantiate(&q->graphExec, q->graph, nullptr, nullptr, 0));
     q->graphValid = true;
     q->graphSerialShade = serial_shade(c);
+    q->graphTraceBlocks = trace_blocks(c, c->traceBlocks);
     return NXHIP_OK;
 }
 
-// Passes in flight right now: kernel timing and the counting variant measure one pass at a time, and a caller-bound
-// radiance buffer exists once.
-static uint32_t effective_slots(const nxhip_ctx* c)
-{
-    if (c->timingEnabled || c->statsEnabled || c->radianceBoundCapacity != 0) return 1u;
-    return std::min<uint32_t>(c->passesInFlight, (uint32_t)c->extra.size());
-}
 // Where pass number i of the round robin renders.  One pass at a time: the context itself, on its own stream.  R > 1: the R
 // extra slots, each on a stream of its own — the context's stream then only carries the accumulates (and whatever the caller
 // puts behind them, e.g. the multi-GPU gather), so that no pass ever queues behind the accumulate of its predecessor.
@@ -1205,7 +1231,8 @@ try {
                 if (c->timerPool.size() > before) c->timerClass.push_back(l.klass);
             }
     } else {
-        if (!q->graphValid || q->graphSerialShade != serial_shade(c)) {  // (the pass size crossed the small-pass threshold)
+        // (rebuilt when the pass size crossed the small-pass threshold or the number of passes in flight changed)
+        if (!q->graphValid || q->graphSerialShade != serial_shade(c) || q->graphTraceBlocks != trace_blocks(c, c->traceBlocks)) {
             rc = build_graph(c, q);
             if (rc != NXHIP_OK) return rc;
         }
