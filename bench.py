@@ -20,7 +20,7 @@ to rank 0 with ONE RCCL gather per pass, where they are scattered into the full 
 bit-identical to the 1-GPU one.  Total work per step is fixed (one frame): strong scaling.
 
 Rank 0 prints ONE JSON line.  It also carries
-  roofline     : the closest-hit trace kernel against the two ceilings that could bind it, both from live launch durations
+  roofline     : the closest-hit trace kernel against the three ceilings that could bind it, all from live launch durations
                  (hipEvents recorded by event nodes around every kernel node of the production hipGraph, last replay of a
                  back-to-back series on the context's stream):
                    hbm        : memory-side bytes per launch (`traffic`) = this run's rays per launch x the bytes per ray
@@ -33,6 +33,11 @@ Rank 0 prints ONE JSON line.  It also carries
                    valu-issue : VALU wave-instructions per launch (rays x the profiled instructions per ray) x 2 cycles
                                 (a wave64 VALU instruction on a SIMD-32 with several waves resident, MI355X_MICROARCH.md)
                                 / (1024 SIMDs x the clock the profile measured) / duration.
+                   l1-gather  : 16-byte per-lane loads per launch (rays x TCP_TOTAL_CACHE_ACCESSES per ray of the profile)
+                                / duration / 256 CUs against the 3.8 per ns and CU that tools/micro/gather.hip measures for
+                                dependent per-lane record gathers that all hit (the traversal's access pattern; 2.4 when they
+                                come from the Infinity Cache, 1.0 from HBM).  VALU issue and the gather share the kernel's
+                                time nearly additively: neither fraction alone can approach 1.
                  `bound` names the ceiling with the larger fraction; `frac`, `achieved`, `peak`, `unit` belong to it.
   cpu_baseline : the CPU oracle (port of the reference algorithm) on full frames of the same scene, timed on the
                  host cores of this box.  A reported baseline, not a target.
@@ -56,6 +61,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievabl
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
 SIMDS = 256 * 4         # 256 CUs x 4 SIMD-32
 VALU_ISSUE_CYCLES = 2   # wave64 VALU instruction, several waves resident (MI355X_MICROARCH.md, execution model)
+L1_GATHER_PEAK = 3.8    # 16-byte per-lane loads a CU's vector L1 serves per ns when all of them hit (tools/micro/gather.hip)
+CUS = 256
 TILE_ROWS = 5           # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "trace_counters.json")
 
@@ -395,6 +402,10 @@ def main():
             peak_ginst = SIMDS * clock / VALU_ISSUE_CYCLES
             ceilings["valu-issue"] = {"achieved": round(ginst, 1), "peak": round(peak_ginst, 1), "unit": "G wave-instructions/s", "frac": round(ginst / peak_ginst, 4),
                                       "valu_insts_per_ray": round(ck["valu_insts_per_ray"], 1), "cycles_per_instruction": VALU_ISSUE_CYCLES, "clock_GHz": clock}
+            if "l1_accesses_per_ray" in ck:
+                loads = rays_per_launch * ck["l1_accesses_per_ray"] / (dur_s * 1e9) / CUS
+                ceilings["l1-gather"] = {"achieved": round(loads, 3), "peak": L1_GATHER_PEAK, "unit": "16-B lane-loads/ns/CU", "frac": round(loads / L1_GATHER_PEAK, 4),
+                                         "lane_loads_per_ray": round(ck["l1_accesses_per_ray"], 1)}
         bound = max(ceilings, key=lambda k: ceilings[k]["frac"]) if ceilings else "hbm"
         top = ceilings.get(bound, {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
         out["roofline"] = {

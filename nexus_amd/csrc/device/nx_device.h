@@ -143,8 +143,6 @@ struct DeviceState {
     nx_camera camera;
     nx_render_settings settings;
     int32_t rngMode, compactMode, conductorMode;
-    // a trace launch uses one wave per this many rays of its queue (at most the whole grid): see trace_kernel
-    int32_t traceRaysPerWave;
     // environment importance sampling (extension, nxhip_set_env_sampling): piecewise-constant distribution over the texels of
     // hdrMap — marginal cdf over rows [height], conditional cdf per row [height][width], pdf per solid angle x cos(latitude)
     int32_t envSampling;

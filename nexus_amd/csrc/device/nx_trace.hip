@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // fetch head.  The grid is sized for the largest queue; on a small one most waves would otherwise each walk all 8
     // heads with returning atomics to find out that nothing is left, which made every launch cost about 0.5 ms however
     // few rays it carried.
-    const int raysPerWave = S->traceRaysPerWave;
-    if (rankInShard * raysPerWave >= homeRays) return;
+    if (rankInShard * kWave >= homeRays) return;
 #ifdef NX_STAGGER
     // experiment: desynchronise the waves of a launch (they all start in the same microsecond and would otherwise hit
     // the memory pipeline and the issue slots in lockstep)
@@ -228,8 +227,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // every wave draws a few times and the launch does not end with a handful of waves still holding full blocks
     // (one frame per pass: +14 %; 64 frames per pass: within noise).
     const int gridWaves = (int)(gridDim.x * (kTraceBlock / kWave));
-    const int wavesAtWork = min(gridWaves, size / raysPerWave + kXcds);
-    const int reserve = min(kReserve, max(kWave, (size / (wavesAtWork * 2)) & ~(kWave - 1)));
+    const int reserve = min(kReserve, max(kWave, (size / (gridWaves * 2)) & ~(kWave - 1)));
     int shard = homeShard;
     bool exhausted = false;
     int rngCur = 0, rngEnd = 0;  // rays reserved by this wave and not handed to a lane yet

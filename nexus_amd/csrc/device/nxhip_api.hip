@@ -317,11 +317,6 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         h.rngMode = NX_RNG_REFERENCE_SLOT;
         h.compactMode = NX_COMPACT_FAST;
         h.conductorMode = NX_CONDUCTOR_REFERENCE;
-        h.traceRaysPerWave = kWave;
-        if (const char* e = std::getenv("NX_TRACE_RAYS_PER_WAVE")) {  // tuning experiments only
-            const int n = std::atoi(e);
-            if (n >= 64 && n <= 65536) h.traceRaysPerWave = n;
-        }
         rc = alloc_paths(c, width * height);
         if (rc != NXHIP_OK) break;
 
