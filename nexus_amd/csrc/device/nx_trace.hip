@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     uint2 stackSpill[kSpillDepth];
     int sp = 0;
 
+#ifdef NX_EXTRA_VALU
+    float dummy0 = (float)lane, dummy1 = dummy0 + 1.0f, dummy2 = dummy0 + 2.0f, dummy3 = dummy0 + 3.0f;
+#endif
     bool active = false;
     bool resultPending = false;  // this lane's ray has finished and its result has not been written yet
     f3 org = mk3(0.0f), dir = mk3(0.0f), idir = mk3(0.0f);
@@ -492,10 +495,22 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 }
             }
             NX_STAMP(5);
+#ifdef NX_EXTRA_VALU
+            // experiment: how does the kernel's rate respond to its VALU instruction count?  NX_EXTRA_VALU
+            // independent FMAs per iteration that change no result: +64 on the ~330 of an iteration costs 15 % of the kernel's time
+#pragma unroll
+            for (int k = 0; k < NX_EXTRA_VALU; k += 4) {
+                dummy0 = fmaf(dummy0, 1.0001f, 0.5f); dummy1 = fmaf(dummy1, 1.0001f, 0.5f);
+                dummy2 = fmaf(dummy2, 1.0001f, 0.5f); dummy3 = fmaf(dummy3, 1.0001f, 0.5f);
+            }
+#endif
             activeMask = __ballot(active);
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
     }
 
+#ifdef NX_EXTRA_VALU
+    if (dummy0 + dummy1 + dummy2 + dummy3 == 123.456f) S->traceStats[0].rays = 1;  // keeps the filler alive
+#endif
     if (STATS) {
         // wave-level reduction, one atomic per wave and counter
         for (int o = 32; o > 0; o >>= 1) {
