@@ -48,6 +48,8 @@ struct DevBuf {
 struct BlasHost {
     DevBuf nodes, isect, tris, triIdx;
     uint32_t nodeCount = 0, triCount = 0;
+    uint4 root[5] = {};      // host copy of node 0 (embedded in every InstTrav record of this BLAS), read back on first use
+    bool rootKnown = false;
 };
 
 struct TextureHost {

@@ -6,7 +6,7 @@
 //                                           built at upload so the trace kernel needs no triangleIdx
 //                                           indirection and reads 48 B instead of 4 + 96
 //              tris    nx_triangle[triCount] original 96-byte triangles (shading only)
-//   TLAS     : nodes, instIdx u32[], instTrav InstTrav[instanceCount] (64 B: inverse transform rows + the
+//   TLAS     : nodes, instIdx u32[], instTrav InstTrav[instanceCount] (160 B: inverse transform rows, the BLAS root node + the
 //              BLAS pointers, replaces the reference's 160-B instance + 32-B D_BVH8 double fetch),
 //              instances nx_bvh_instance[] (shading only)
 //   queues   : trace   rayO float4 (origin, -), rayD float4 (direction, pixelIdx), hit float4 (t,u,v,triIdx),
@@ -64,15 +64,16 @@ struct BlasDev {
 static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
 
 // Traversal record of one TLAS leaf, stored in TLAS *leaf order* (entry k belongs to tlasInstIdx[k]) so that entering an
-// instance is one 80-byte fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id.
+// instance is one fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id, the BLAS root.
 struct __attribute__((aligned(16))) InstTrav {
     float4 r0, r1, r2;  // rows 0..2 of invTransform
     const NX_G uint4* nodes;
     const NX_G float4* isect;
     uint32_t instIdx;
     uint32_t pad_[3];
+    uint4 root[5];      // a copy of the BLAS's root node: entering the instance and testing its root are one loop iteration
 };
-static_assert(sizeof(InstTrav) == 80, "InstTrav layout");
+static_assert(sizeof(InstTrav) == 160, "InstTrav layout");
 
 struct TextureDev {
     const NX_G uint32_t* texels;  // RGBA8, row 0 first

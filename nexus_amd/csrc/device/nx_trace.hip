@@ -181,10 +181,11 @@ NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t inv
 }
 
 template <bool ANY_HIT, bool STATS>
-// 6 waves per SIMD for both variants (80 VGPRs; the any-hit variant spills 64 B): measured best with the SLP vectorizer off
-// (5: -3 %, 7: -0.3 %, 8: -1.5 %)
+// 5 waves per SIMD for both variants (96 VGPRs, no spills in the loop).  Before an instance entry also carried its BLAS
+// root (17 more live registers in the fetch), 6 waves at 80 VGPRs was the best point (5: -3 %, 7: -0.3 %, 8: -1.5 %); with it,
+// 6 waves spill 23 VGPRs inside the loop (-10 %), 5 and 4 measure +4.5 % and +1 % over the old kernel at 6.
 #ifndef NX_WAVES_PER_EU
-#define NX_WAVES_PER_EU 6
+#define NX_WAVES_PER_EU 5
 #endif
 __attribute__((amdgpu_waves_per_eu(NX_WAVES_PER_EU, NX_WAVES_PER_EU)))
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             }
 #endif
             if (STATS) {
-                wNode += __popcll(__ballot(wantNode));
+                wNode += __popcll(__ballot(wantNode || wantInst));  // an instance entry also tests the BLAS root (below)
                 wPrim += __popcll(__ballot(wantInst || wantTri));
             }
             unsigned long long recAddr = 0ull;
@@ -436,23 +437,27 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 tg.y &= ~(1u << off);
                 recAddr = (unsigned long long)(isect + (size_t)(tg.x + (uint32_t)off) * (unsigned)kTriStride);
             }
+            // An instance record carries a copy of its BLAS's root node behind the transform: the lane fetches both, enters the
+            // instance and tests the root in this same iteration (the reference's next step for that ray, BVH8Traversal.cuh:
+            // 259-266 then :180 — no other record of the ray lies between them), which saves one iteration per instance
+            // visit and puts the lane into the node block that runs for the other lanes anyway.
             uint4 rc[5];
-            coop_fetch(wantNode || wantInst, wantTri, recAddr, waveAddr, waveStage, lane, rc);
-            NX_STAMP(2);
-            if (wantNode) {
-                child_trace(rc, org, dir, idir, invOct4, hitT, ng, tg);
-                if (STATS) nNodes++;
-            }
-            NX_STAMP(3);
+            uint4 ri[4];
+            uint32_t riInst = 0u;
             if (wantInst) {
-                const float4 r0 = make_float4(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z), __uint_as_float(rc[0].w));
-                const float4 r1 = make_float4(__uint_as_float(rc[1].x), __uint_as_float(rc[1].y), __uint_as_float(rc[1].z), __uint_as_float(rc[1].w));
-                const float4 r2 = make_float4(__uint_as_float(rc[2].x), __uint_as_float(rc[2].y), __uint_as_float(rc[2].z), __uint_as_float(rc[2].w));
-                nodes = (GU4)(((unsigned long long)rc[3].y << 32) | rc[3].x);
-                isect = (GF4)(((unsigned long long)rc[3].w << 32) | rc[3].z);
-                instIdx = rc[4].x;
-                ng = make_uint2(0u, 0x80000000u);
-                tg = make_uint2(0u, 0u);
+                GU4 p = (GU4)recAddr;
+                ri[0] = p[0]; ri[1] = p[1]; ri[2] = p[2]; ri[3] = p[3];
+                riInst = *(const NX_G uint32_t*)(p + 4);
+            }
+            coop_fetch(wantNode || wantInst, wantTri, recAddr + (wantInst ? 80ull : 0ull), waveAddr, waveStage, lane, rc);
+            NX_STAMP(2);
+            if (wantInst) {
+                const float4 r0 = make_float4(__uint_as_float(ri[0].x), __uint_as_float(ri[0].y), __uint_as_float(ri[0].z), __uint_as_float(ri[0].w));
+                const float4 r1 = make_float4(__uint_as_float(ri[1].x), __uint_as_float(ri[1].y), __uint_as_float(ri[1].z), __uint_as_float(ri[1].w));
+                const float4 r2 = make_float4(__uint_as_float(ri[2].x), __uint_as_float(ri[2].y), __uint_as_float(ri[2].z), __uint_as_float(ri[2].w));
+                nodes = (GU4)(((unsigned long long)ri[3].y << 32) | ri[3].x);
+                isect = (GF4)(((unsigned long long)ri[3].w << 32) | ri[3].z);
+                instIdx = riInst;
                 // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
                 // A transform that maps this ray onto itself bit for bit (in practice: the identity) leaves 1/dir as it
                 // is, so the three divisions here and the reload + three divisions on exit are skipped.  Compared as bit
@@ -469,6 +474,11 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 if (STATS) nInst++;
             }
             NX_STAMP(4);
+            if (wantNode || wantInst) {
+                child_trace(rc, org, dir, idir, invOct4, hitT, ng, tg);
+                if (STATS) nNodes++;
+            }
+            NX_STAMP(3);
             if (wantTri) {
                 // Moeller-Trumbore on the leaf-ordered stream — Triangle.cuh:53-86 / :89-118
                 const f3 p0 = mk3(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z));
@@ -495,6 +505,14 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 }
             }
             NX_STAMP(5);
+#ifndef NX_NO_EARLY_RETIRE
+            // a ray that has nothing left (no pending child, no pending leaf, empty stack) retires now instead of spending the
+            // next iteration's acquire step on finding that out: its lane counts as free one iteration earlier
+            if (active && tg.y == 0u && (ng.y & 0xff000000u) == 0u && sp == 0) {
+                active = false;
+                resultPending = true;
+            }
+#endif
 #ifdef NX_EXTRA_VALU
             // experiment: how does the kernel's rate respond to its VALU instruction count?  NX_EXTRA_VALU
             // independent FMAs per iteration that change no result: +64 on the ~330 of an iteration costs 15 % of the kernel's time

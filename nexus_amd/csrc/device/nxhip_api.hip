@@ -447,9 +447,15 @@ static int refresh_inst_trav(nxhip_ctx* c)
         trav[k].r0 = make_float4(m[0], m[1], m[2], m[3]);
         trav[k].r1 = make_float4(m[4], m[5], m[6], m[7]);
         trav[k].r2 = make_float4(m[8], m[9], m[10], m[11]);
-        trav[k].nodes = c->blas[inst.bvhIdx].nodes.as<uint4>();
-        trav[k].isect = c->blas[inst.bvhIdx].isect.as<float4>();
+        BlasHost& b = c->blas[inst.bvhIdx];
+        if (!b.rootKnown) {
+            if (b.nodeCount) NX_HIP(hipMemcpy(b.root, b.nodes.p, sizeof b.root, hipMemcpyDeviceToHost));
+            b.rootKnown = true;
+        }
+        trav[k].nodes = b.nodes.as<uint4>();
+        trav[k].isect = b.isect.as<float4>();
         trav[k].instIdx = i;
+        for (int q = 0; q < 5; q++) trav[k].root[q] = b.root[q];
     }
     NX_SYNC_ALL(c);
     NX_ALLOC(c->instTrav, trav.size() * sizeof(InstTrav));
