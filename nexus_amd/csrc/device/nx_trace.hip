@@ -16,8 +16,9 @@
 //     it": the three fetch kinds of a wave are issued together and waited for once, so an iteration has a single
 //     memory round trip, and the 64 lanes reconverge at every stage (the reference's `while (triangleEntry.y)` inner
 //     loop serialises lanes with long triangle lists on a 64-wide wave).  Per-ray visiting order is unchanged;
-//   * a record is an 80-byte node (five 16-byte loads), a 48-byte triangle record or an 80-byte instance record; each
-//     lane loads its own (a cooperative LDS-staged fetch exists behind -DNX_COOP_FETCH and measured slower);
+//   * a record is an 80-byte node (five 16-byte loads), a 48-byte triangle record or a 160-byte instance record (transform,
+//     BLAS pointers and a copy of the BLAS root node: entering an instance and testing its root share an iteration); each
+//     lane loads its own with 16-byte global loads;
 //   * quantised bounds are converted with v_cvt_f32_ubyteN and the slab test is 6 v_fma per child + integer
 //     max3/min3 on the float bit patterns (identical ordering to the reference's vmax.s32/vmin.s32 PTX, including
 //     its NaN behaviour);
@@ -39,9 +40,6 @@ constexpr int kTraceBlock = 256;  // 4 waves
 #endif
 constexpr int kLdsDepth = NX_LDS_DEPTH;        // stack entries per lane held in LDS (2 KiB each per workgroup)
 constexpr int kSpillDepth = 32 - kLdsDepth;  // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
-#ifdef NX_COOP_FETCH
-constexpr int kMaxChunks = 5;     // 16-byte chunks of the largest cooperatively fetched record (a node)
-#endif
 #ifndef NX_RESERVE
 #define NX_RESERVE 256
 #endif
@@ -54,59 +52,17 @@ constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer t
 using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
 using GF4 = const NX_G float4*;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;  // one stack entry (uint2) as a 64-bit scalar
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void g_cvoid;
 
-// Record fetch, ONE per loop iteration for all three record kinds.  Must be reached by all lanes of the wave.
-// Two forms.  Default (measured faster: 5.2 vs 3.9 Grays/s on the 1M-triangle bench): each lane issues its own 16-byte
-// global loads.  -DNX_COOP_FETCH: the cooperative LDS-staged form described next, kept for comparison — it needs 2-3x
-// fewer L1 lookups but pays two LDS round trips and a direct-to-LDS load per iteration, and 22 KiB more LDS per workgroup.
-// Lanes with kind5 (an 80-byte node or instance record) or kind3 (a 48-byte triangle record)
-// publish `addr`; the wave's lanes then stream every requested record into waveStage with direct-to-LDS loads of
-// consecutive 16-byte chunks (5-chunk records first, then 3-chunk ones) and each requester reads its record back.
-// waveAddr / waveStage are this wave's LDS scratch (64 x 8 B, 64 x kMaxChunks x 16 B).
-NXD void coop_fetch(bool kind5, bool kind3, unsigned long long addr, lds_u64* waveAddr, lds_u32* waveStage, int lane, uint4 (&out)[5])
+// Record fetch, ONE per loop iteration for all record kinds: every lane issues the 16-byte global loads of its own record (3
+// or 5 in flight) and the wave waits once.  Must be reached by all lanes of the wave.  (A cooperative LDS-staged form — lanes
+// publish addresses, the wave streams the records into LDS with global_load ... lds of consecutive chunks — measured slower
+// in round 1 and was removed: tools/micro/gather.hip shows the L1's cost is per lane-load, coalesced or not.)
+NXD void fetch_record(bool kind5, bool kind3, unsigned long long addr, uint4 (&out)[5])
 {
-#ifndef NX_COOP_FETCH
-    // default: every lane loads its own record with 16-byte global loads (3 or 5 in flight per lane)
     if (kind5 || kind3) {
         GU4 p = (GU4)addr;
         out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
         if (kind5) { out[3] = p[3]; out[4] = p[4]; }
-    }
-    return;
-#endif
-    const unsigned long long mask5 = __ballot(kind5), mask3 = __ballot(kind3);
-    const int n5 = __popcll(mask5), n3 = __popcll(mask3);
-    const int rank5 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask5 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask5, 0u));
-    const int rank3 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask3, 0u));
-    const int total5 = n5 * 5, total = total5 + n3 * 3;
-    const int rec = kind5 ? rank5 : n5 + rank3;                       // slot in the address table
-    const int firstChunk = kind5 ? rank5 * 5 : total5 + rank3 * 3;    // where this lane's record lands
-    // earlier ds_reads of the staging area must have returned before the DMA below may overwrite it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (kind5 || kind3) waveAddr[rec] = addr;
-    for (int base = 0; base < total; base += kWave) {
-        const int c = base + lane;
-        if (c < total) {
-            int r, part;
-            if (c < total5) { r = c / 5; part = c - r * 5; }
-            else { const int d = c - total5; const int q = d / 3; r = n5 + q; part = d - q * 3; }
-            const unsigned long long a = waveAddr[r] + (unsigned long long)(part * 16);
-            // lane L of this instruction lands at (waveStage + base*16 bytes) + L*16: chunk c at byte 16*c
-            __builtin_amdgcn_global_load_lds((g_cvoid*)a, (lds_void*)(waveStage + base * 4), 16, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (kind5 || kind3) {
-        const lds_u32* p = waveStage + firstChunk * 4;
-#pragma unroll
-        for (int k = 0; k < 3; k++) out[k] = make_uint4(p[4 * k + 0], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-        if (kind5) {
-#pragma unroll
-            for (int k = 3; k < 5; k++) out[k] = make_uint4(p[4 * k + 0], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-        }
     }
 }
 
@@ -191,10 +147,6 @@ __attribute__((amdgpu_waves_per_eu(NX_WAVES_PER_EU, NX_WAVES_PER_EU)))
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
-#ifdef NX_COOP_FETCH
-    __shared__ unsigned long long ldsAddr[kTraceBlock];
-    __shared__ __attribute__((aligned(16))) uint32_t ldsStage[kTraceBlock * kMaxChunks * 4];
-#endif
 
     NX_G Counters* C = S->counters;
     const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
@@ -234,14 +186,6 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     int rngCur = 0, rngEnd = 0;  // rays reserved by this wave and not handed to a lane yet
 
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
-#ifdef NX_COOP_FETCH
-    const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    lds_u64* const waveAddr = (lds_u64*)&ldsAddr[waveInBlock * kWave];
-    lds_u32* const waveStage = (lds_u32*)&ldsStage[waveInBlock * kWave * kMaxChunks * 4];
-#else
-    lds_u64* const waveAddr = nullptr;
-    lds_u32* const waveStage = nullptr;
-#endif
     uint2 stackSpill[kSpillDepth];
     int sp = 0;
 
@@ -390,29 +334,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             NX_STAMP(1);
             // Every busy lane now needs exactly one record: a node (its node group has unvisited children and no leaf
             // work is pending), an instance record (pending TLAS leaf) or a triangle record (pending BLAS leaf).
-            bool wantNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
+            const bool wantNode = active && tg.y == 0u && (ng.y & 0xff000000u) != 0u;
             const bool wantInst = active && tg.y != 0u && instSp < 0;
-            bool wantTri = active && tg.y != 0u && instSp >= 0;
-#if defined(NX_POSTPONE_TRI) || defined(NX_POSTPONE_NODE)
-            {
-                // vote: a record kind wanted by only a few lanes waits (those lanes idle this iteration) while the other
-                // kind has work, so that each of the two long code blocks runs with more of its lanes enabled.  The order
-                // in which a ray visits its records does not change.
-                const int cN = __popcll(__ballot(wantNode)), cT = __popcll(__ballot(wantTri));
-#ifdef NX_POSTPONE_TRI
-                const bool holdTri = cT < NX_POSTPONE_TRI && cN > 0 && cN >= cT;
-#else
-                const bool holdTri = false;
-#endif
-#ifdef NX_POSTPONE_NODE
-                const bool holdNode = !holdTri && cN < NX_POSTPONE_NODE && cT > cN;
-#else
-                const bool holdNode = false;
-#endif
-                if (holdTri) wantTri = false;
-                if (holdNode) wantNode = false;
-            }
-#endif
+            const bool wantTri = active && tg.y != 0u && instSp >= 0;
             if (STATS) {
                 wNode += __popcll(__ballot(wantNode || wantInst));  // an instance entry also tests the BLAS root (below)
                 wPrim += __popcll(__ballot(wantInst || wantTri));
@@ -449,7 +373,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 ri[0] = p[0]; ri[1] = p[1]; ri[2] = p[2]; ri[3] = p[3];
                 riInst = *(const NX_G uint32_t*)(p + 4);
             }
-            coop_fetch(wantNode || wantInst, wantTri, recAddr + (wantInst ? 80ull : 0ull), waveAddr, waveStage, lane, rc);
+            fetch_record(wantNode || wantInst, wantTri, recAddr + (wantInst ? 80ull : 0ull), rc);
             NX_STAMP(2);
             if (wantInst) {
                 const float4 r0 = make_float4(__uint_as_float(ri[0].x), __uint_as_float(ri[0].y), __uint_as_float(ri[0].z), __uint_as_float(ri[0].w));
