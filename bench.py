@@ -128,6 +128,10 @@ def cpu_baseline(sc, width, height, threads, frames, single_core=True):
 
 
 def main():
+    # A run that stops making progress (a hung device call) dumps every thread's Python stack to stderr and exits (status 1)
+    # instead of sitting silently until somebody's timeout kills it: the traceback says which call never returned.
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("NX_BENCH_WATCHDOG", "1500")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="frames timed per repetition (default 512; --config 5: 64)")

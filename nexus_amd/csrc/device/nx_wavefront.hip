@@ -488,10 +488,12 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
                 }
                 radiance = ((emissive * weight) * material.intensity) * throughput;
             }
-            {
-                float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
-                if (bounce == 1) r = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                else { r.x += radiance.x; r.y += radiance.y; r.z += radiance.z; }
+            if (bounce == 1) {
+                S->radiance[pixelIdx] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            } else if (radiance.x != 0.0f || radiance.y != 0.0f || radiance.z != 0.0f) {
+                // (most hits emit nothing: adding zeros would cost a 16-byte read and write per path and bounce)
+                float4 r = S->radiance[pixelIdx];
+                r.x += radiance.x; r.y += radiance.y; r.z += radiance.z;
                 S->radiance[pixelIdx] = r;
             }
 
