@@ -113,7 +113,8 @@ int nxhip_set_frames_per_pass(nxhip_ctx *ctx, uint32_t frames);
  * stream and graph instance, so that the drain phase of a pass — a few long rays, most of the GPU idle, at one frame per
  * pass more than half of the pass — overlaps with the bulk of the next passes.  nxhip_accumulate folds every finished pass
  * into the one accumulation, oldest first: the image is bit-identical to R = 1.  Worth it for small passes (one frame per
- * pass: +45 % at R = 4; 20 frames per pass: +15 % at R = 3).  Needs enough hardware queues: export GPU_MAX_HW_QUEUES=24
+ * pass: 2.2x at R = 6; 20 frames per pass: +20 % at R = 4; the persistent trace launches of the slots are sized to share the
+ * CUs).  Needs enough hardware queues: export GPU_MAX_HW_QUEUES=24
  * before the process touches HIP (the runtime's default of 4 serialises the slots).  Kernel timing, the counting variant and
  * a bound radiance buffer fall back to one pass at a time. */
 int nxhip_set_passes_in_flight(nxhip_ctx *ctx, uint32_t passes);
