@@ -1027,7 +1027,12 @@ int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t fram
 // queues by the runtime, and with many queues configured (passes in flight need them) the cross-queue hand-offs cost more
 // than the overlap of four short kernels gives: one frame per pass 288 -> 375 Msamples/s at 24 queues, and 6 passes in flight
 // then fit the queues (584 against 537 with 4).  Large passes keep the four branches (20 frames per pass: 1 560 vs 1 505).
-bool serial_shade(const nxhip_ctx* c) { return c->serialShade || c->framesPerPass <= 4u; }
+// "Small" = up to 4 frames' worth of paths at 1080p.
+// The size of a pass in 1080p frames: what the small-pass rules below were measured in.  A rank of a tile split renders a
+// fraction of the image, so its 20-frame pass is a small one (8 ranks: 2.5 frames' worth of paths).
+double pass_size_in_frames(const nxhip_ctx* c) { return (double)c->localCount * (double)c->framesPerPass / (1920.0 * 1080.0); }
+
+bool serial_shade(const nxhip_ctx* c) { return c->serialShade || pass_size_in_frames(c) <= 4.0; }
 
 // Passes in flight right now: kernel timing and the counting variant measure one pass at a time, and a caller-bound
 // radiance buffer exists once.
@@ -1048,7 +1053,7 @@ int trace_blocks(const nxhip_ctx* c, int fullGrid)
     if (c->traceGridForced) return fullGrid;
     const int maxPerCU = std::max(1, fullGrid / std::max(1, c->numCUs));
     const int R = (int)std::max(1u, effective_slots(c));
-    const bool small = c->framesPerPass <= 8u;
+    const bool small = pass_size_in_frames(c) <= 8.0;
     int perCU;
     if (R == 1) perCU = small ? std::min(3, maxPerCU) : maxPerCU;
     else perCU = ((small ? 2 : 3) * maxPerCU + 2 * R - 1) / (2 * R);
