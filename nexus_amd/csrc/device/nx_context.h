@@ -155,6 +155,6 @@ struct nxhip_ctx : nxd::PassSlot {
 
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;  // full-chip persistent grids (see trace_blocks)
     bool traceGridForced = false;                            // NX_TRACE_BLOCKS_*: use them as they are
-    int shadeBlocksPerCU = 4, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
+    int shadeBlocksPerCU = 10, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
     bool serialShade = false;  // the four material kernels of a bounce as one graph branch instead of four
 };

@@ -24,7 +24,7 @@ namespace nxd {
 
 constexpr int kWideBlock = 256;     // generate / accumulate
 #ifndef NX_SHADE_BLOCK
-#define NX_SHADE_BLOCK 512
+#define NX_SHADE_BLOCK 256
 #endif
 #ifndef NX_LOGIC_BLOCK
 #define NX_LOGIC_BLOCK 1024
@@ -415,9 +415,13 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
     return true;
 }
 
+// Workgroups of 256 at 5 waves per SIMD (96 VGPRs, 5-11 spilled once per path), 10 workgroups per CU: equal to 512 threads
+// at 4 waves (126 VGPRs) for one large pass, +4.5 % for one-frame passes in flight, where a smaller register footprint lets
+// the material kernels of one slot share SIMDs with the trace waves of another.  6 and 8 waves per SIMD spill 30-87 VGPRs and
+// double the kernel's time: it is sensitive to memory traffic, not short of waves.
 template <int TYPE, bool ORDERED>
 #ifndef NX_SHADE_WAVES
-#define NX_SHADE_WAVES 4
+#define NX_SHADE_WAVES 5
 #endif
 __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {

@@ -57,7 +57,7 @@ bool DevBuf::alloc(size_t n)
 constexpr int kTraceBlockThreads = 256;
 constexpr int kWideBlockThreads = 256;
 #ifndef NX_SHADE_BLOCK
-#define NX_SHADE_BLOCK 512
+#define NX_SHADE_BLOCK 256
 #endif
 #ifndef NX_LOGIC_BLOCK
 #define NX_LOGIC_BLOCK 1024
