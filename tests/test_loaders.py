@@ -314,3 +314,45 @@ def test_glb_textures_cpp_equals_python_and_reach_the_asset_manager(tmp_path):
     texs, dt, et, warns = capi.load_scene_textures(broken)
     assert len(texs) == 1 and list(dt) == [-1] and list(et) == [0] and len(warns) == 1 and "JPEG" in warns[0]
     assert loaders.load_glb(broken).material_diffuse_texture == [-1]
+
+
+def test_cpp_decoders_survive_mutated_files(tmp_path):
+    """Byte-level mutations of valid files: the C++ PNG decoder and .glb reader must either decode or raise NexusError,
+    never read out of bounds (this test is also part of the AddressSanitizer run, tools/run_sanitized_cpu_tests.sh)."""
+    import struct
+    from nexus_amd import capi
+    rng = np.random.RandomState(11)
+    pngs = [_png(9, 7, 6, 8, 4, rng)[0], _png(5, 6, 0, 1, 1, rng)[0], _png(6, 4, 2, 16, 3, rng)[0],
+            _png(7, 5, 3, 4, 1, rng, palette=bytes(rng.randint(0, 256, size=48).astype(np.uint8)))[0]]
+    outcomes = {"ok": 0, "refused": 0}
+    for data in pngs:
+        for _ in range(60):
+            bad = bytearray(data)
+            for _ in range(rng.randint(1, 4)):
+                k = rng.randint(8, len(bad))
+                bad[k] = rng.randint(0, 256)
+            if rng.randint(0, 4) == 0:
+                bad = bad[: rng.randint(8, len(bad))]
+            try:
+                img, ch = capi.decode_png(bytes(bad))
+                assert img.ndim == 3 and ch in (1, 2, 3, 4)
+                outcomes["ok"] += 1
+            except capi.NexusError:
+                outcomes["refused"] += 1
+    glb = open(os.path.join(SH.GOLDEN, "cornell_box_sphere.glb"), "rb").read()
+    json_len = struct.unpack_from("<I", glb, 12)[0]
+    for i in range(40):
+        bad = bytearray(glb)
+        # mostly inside the JSON chunk (accessor counts, offsets, indices), sometimes in the binary chunk / the headers
+        lo, hi = (20, 20 + json_len) if i % 4 else (0, len(bad))
+        for _ in range(rng.randint(1, 3)):
+            k = rng.randint(lo, hi)
+            bad[k] = rng.randint(32, 127) if i % 4 else rng.randint(0, 256)
+        path = tmp_path / ("m%d.glb" % i)
+        path.write_bytes(bytes(bad))
+        try:
+            capi.load_scene_file(str(path))
+            outcomes["ok"] += 1
+        except capi.NexusError:
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 20 and outcomes["ok"] + outcomes["refused"] == 4 * 60 + 40
