@@ -119,6 +119,17 @@ int nxhip_set_frames_per_pass(nxhip_ctx *ctx, uint32_t frames);
  * a bound radiance buffer fall back to one pass at a time. */
 int nxhip_set_passes_in_flight(nxhip_ctx *ctx, uint32_t passes);
 
+/* Tail kernel (no counterpart in the reference, whose graph has one node per kernel and bounce, PathTracer.cpp:114-124).
+ * From bounce `bounce` on — 2 .. pathLength, 0 = off — the rest of every path is run by ONE launch after the trace of
+ * bounce - 1: each wave takes 64 paths and loops logic -> shade -> shadow ray -> continuation ray per lane.  Late bounces
+ * carry a few per cent of a pass's rays but each costs a trace level as long as its slowest ray plus five more launches.
+ * Default NXHIP_TAIL_AUTO: bounce 5 for passes of up to four 1080p frames' worth of paths (one frame per pass +9 %, with six
+ * passes in flight +16 %), off for larger ones (where it loses).  Same functions and the same order of additions per pixel:
+ * the image is bit-identical.  Only with NX_RNG_PIXEL_KEYED and NX_COMPACT_FAST, and not while kernel timing or the counting
+ * variant is enabled (those passes use the level-by-level graph). */
+#define NXHIP_TAIL_AUTO 0xffffffffu
+int nxhip_set_tail_bounce(nxhip_ctx *ctx, uint32_t bounce);
+
 /* ---- rendering ----------------------------------------------------------------------------------- */
 
 /* PathTracer::ResetFrameNumber — PathTracer.cpp:243-246 */

@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
-    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
 ]
@@ -563,6 +563,13 @@ class Context:
     def set_env_sampling(self, on=True):
         self.L.nxhip_set_env_sampling.argtypes = [C.c_void_p, C.c_int]
         check(self.L.nxhip_set_env_sampling(self.h, 1 if on else 0), "nxhip_set_env_sampling")
+
+    TAIL_AUTO = 0xFFFFFFFF
+
+    def set_tail_bounce(self, bounce):
+        """0 = off, 2 .. pathLength = from that bounce on, Context.TAIL_AUTO = the default rule (include/nexus_hip.h)"""
+        self.L.nxhip_set_tail_bounce.argtypes = [C.c_void_p, C.c_uint32]
+        check(self.L.nxhip_set_tail_bounce(self.h, bounce), "nxhip_set_tail_bounce")
 
     def set_passes_in_flight(self, passes):
         self.L.nxhip_set_passes_in_flight.argtypes = [C.c_void_p, C.c_uint32]

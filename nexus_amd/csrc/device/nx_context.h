@@ -83,6 +83,7 @@ struct PassSlot {
     bool graphValid = false;
     bool graphSerialShade = false;  // the shape the graph was built with (see serial_shade, trace_blocks)
     int graphTraceBlocks = 0;
+    int graphTailBounce = 0;
     // pass bookkeeping (slots >= 1 and slot 0 alike)
     hipEvent_t done = nullptr, accumulated = nullptr;
     bool awaitingAccumulate = false;   // holds a rendered pass that nxhip_accumulate has not consumed yet
@@ -154,6 +155,8 @@ struct nxhip_ctx : nxd::PassSlot {
     nxd::DevBuf mgpuGathered, mgpuMaps, mgpuFullAccum, mgpuFullRgba8;
 
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;  // full-chip persistent grids (see trace_blocks)
+    int tailBlocks = 0;
+    int tailBounce = -1;  // first bounce of the tail kernel, 0 = off, -1 = automatic (see tail_bounce in nxhip_api.hip)
     bool traceGridForced = false;                            // NX_TRACE_BLOCKS_*: use them as they are
     int shadeBlocksPerCU = 10, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
     bool serialShade = false;  // the four material kernels of a bounce as one graph branch instead of four

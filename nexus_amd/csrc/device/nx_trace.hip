@@ -29,17 +29,10 @@
 //     instance is left instead of being kept in 6 VGPRs.
 // No MFMA: this is pointer chasing, bounded by memory latency / bandwidth.
 #define NX_KERNEL_TU 1
-#include "nx_device.h"
-#include "nx_math.h"
+#include "nx_traverse.h"
 
 namespace nxd {
 
-constexpr int kTraceBlock = 256;  // 4 waves
-#ifndef NX_LDS_DEPTH
-#define NX_LDS_DEPTH 8
-#endif
-constexpr int kLdsDepth = NX_LDS_DEPTH;        // stack entries per lane held in LDS (2 KiB each per workgroup)
-constexpr int kSpillDepth = 32 - kLdsDepth;  // further entries in scratch; 32 in total as the reference (BVH8Traversal.cuh:17)
 #ifndef NX_RESERVE
 #define NX_RESERVE 256
 #endif
@@ -48,93 +41,6 @@ constexpr int kReserve = NX_RESERVE;  // most rays reserved per fetch atomic (me
 #define NX_REFILL_BELOW 40
 #endif
 constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer than this many of the 64 are still traversing
-
-using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
-using GF4 = const NX_G float4*;
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;  // one stack entry (uint2) as a 64-bit scalar
-
-// Record fetch, ONE per loop iteration for all record kinds: every lane issues the 16-byte global loads of its own record (3
-// or 5 in flight) and the wave waits once.  Must be reached by all lanes of the wave.  (A cooperative LDS-staged form — lanes
-// publish addresses, the wave streams the records into LDS with global_load ... lds of consecutive chunks — measured slower
-// in round 1 and was removed: tools/micro/gather.hip shows the L1's cost is per lane-load, coalesced or not.)
-NXD void fetch_record(bool kind5, bool kind3, unsigned long long addr, uint4 (&out)[5])
-{
-    if (kind5 || kind3) {
-        GU4 p = (GU4)addr;
-        out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
-        if (kind5) { out[3] = p[3]; out[4] = p[4]; }
-    }
-}
-
-// Traversal stack: entries [0, kLdsDepth) live in LDS (entry-major: lane stride 1, depth stride kTraceBlock), the rest in
-// a scratch array.  The stack pointer and the LDS base stay in registers: they are deliberately NOT members of a struct
-// together with the scratch array (a struct holding a dynamically indexed array is kept in scratch as a whole, which
-// turned every push / pop into scratch loads of its own stack pointer).
-NXD void stack_push(lds_u64* lds, uint2* spill, int& sp, uint2 e)
-{
-    if (sp < kLdsDepth) lds[sp * kTraceBlock] = ((unsigned long long)e.y << 32) | e.x;
-    else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = e;
-    sp++;
-}
-NXD uint2 stack_pop(lds_u64* lds, const uint2* spill, int& sp)
-{
-    sp--;
-    if (sp < kLdsDepth) {
-        const unsigned long long v = lds[sp * kTraceBlock];
-        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-    }
-    if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
-    return make_uint2(0u, 0u);
-}
-
-NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
-NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
-NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
-
-// ChildTrace — BVH8Traversal.cuh:55-146
-NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
-{
-    const uint4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
-
-    const f3 p = mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
-    const uint32_t e_imask = n0.w;
-    const f3 tdir = mk3(__uint_as_float((e_imask & 0xffu) << 23) * idir.x, __uint_as_float((e_imask << 15) & 0x7f800000u) * idir.y,
-                        __uint_as_float((e_imask << 7) & 0x7f800000u) * idir.z);
-    const f3 torg = (p - org) * idir;
-    const bool nx = dir.x < 0.0f, ny = dir.y < 0.0f, nz = dir.z < 0.0f;
-
-    uint32_t hitMask = 0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t meta4 = i ? n1.w : n1.z;
-        const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;  // per byte 0xff where inner (reference: prmt sign extension)
-        const uint32_t bitIndex4 = (meta4 ^ (invOct4 & innerMask4)) & 0x1f1f1f1fu;
-        const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
-
-        const uint32_t qlox = i ? n2.y : n2.x, qloy = i ? n2.w : n2.z, qloz = i ? n3.y : n3.x;
-        const uint32_t qhix = i ? n3.w : n3.z, qhiy = i ? n4.y : n4.x, qhiz = i ? n4.w : n4.z;
-        const uint32_t xMin = nx ? qhix : qlox, xMax = nx ? qlox : qhix;
-        const uint32_t yMin = ny ? qhiy : qloy, yMax = ny ? qloy : qhiy;
-        const uint32_t zMin = nz ? qhiz : qloz, zMax = nz ? qloz : qhiz;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float tminx = fmaf(ubyte_f(xMin, j), tdir.x, torg.x);
-            const float tminy = fmaf(ubyte_f(yMin, j), tdir.y, torg.y);
-            const float tminz = fmaf(ubyte_f(zMin, j), tdir.z, torg.z);
-            const float tmaxx = fmaf(ubyte_f(xMax, j), tdir.x, torg.x);
-            const float tmaxy = fmaf(ubyte_f(yMax, j), tdir.y, torg.y);
-            const float tmaxz = fmaf(ubyte_f(zMax, j), tdir.z, torg.z);
-            const float tmin = __int_as_float(imax3(__float_as_int(tminx), __float_as_int(tminy), __float_as_int(fmaxf(tminz, 0.0f))));
-            const float tmax = __int_as_float(imin3(__float_as_int(tmaxx), __float_as_int(tmaxy), __float_as_int(fminf(tmaxz, tmaxRay))));
-            const uint32_t childBits = (childBits4 >> (8 * j)) & 0xffu;
-            const uint32_t bitIndex = (bitIndex4 >> (8 * j)) & 0xffu;
-            hitMask |= (tmin <= tmax) ? (childBits << bitIndex) : 0u;
-        }
-    }
-    ng = make_uint2(n1.x, (hitMask & 0xff000000u) | (e_imask >> 24));
-    tg = make_uint2(n1.y, hitMask & 0x00ffffffu);
-}
 
 template <bool ANY_HIT, bool STATS>
 // 5 waves per SIMD for both variants (96 VGPRs, no spills in the loop).  Before an instance entry also carried its BLAS

@@ -19,6 +19,7 @@
 #include "nx_device.h"
 #include "nx_math.h"
 #include "nx_texture.h"
+#include "nx_traverse.h"
 
 namespace nxd {
 
@@ -251,6 +252,40 @@ NXD uint32_t nee_light_count(const DeviceState* S) { return S->lightCount + ((S-
 // ------------------------------------------------------------------------------------------------------
 // LogicKernel — PathTracer.cu:136-210
 
+// LogicKernel's decision for one path (PathTracer.cu:136-210), without the queue traffic: a miss ends the path and adds the
+// (MIS-weighted) environment `bg`; a hit survives Russian roulette with probability max(throughput) — `survived`, the
+// throughput divided by it in `throughputOut` — and is shaded as the returned material type, or ends (-1).
+template <class HitInst>
+NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame, const uint32_t seedSlot, const uint32_t pixelIdx, const float hitT, const f3 dir,
+                   const float4 tp, HitInst hitInst, bool& miss, f3& bg, bool& survived, f3& throughputOut, uint32_t& inst)
+{
+    const f3 throughput = mk3(tp.x, tp.y, tp.z);
+    int type = -1;
+    miss = false;
+    survived = false;
+    if (hitT == 1e30f) {
+        miss = true;
+        bg = throughput * sample_background(S, dir);
+        if (S->envSampling && S->hdrMap.texels && bounce > 1 && S->settings.useMIS) {
+            // the NEE samples the environment too: weight the BSDF-sampled miss against it (extension)
+            const float envPdf = env_pdf(S, dir) / (float)nee_light_count(S);
+            if (pdf_valid(envPdf)) bg = bg * power_heuristic(tp.w, envPdf);
+        }
+    } else {
+        uint32_t rng = seed_for(S, seedSlot, pixelIdx, (uint32_t)bounce, 0u, frame);
+        const float probability = maxcomp3(throughput);
+        if (rng_next(rng) < probability) {
+            survived = true;
+            throughputOut = throughput / probability;
+            inst = hitInst();
+            const int materialId = S->instances[inst].materialId;
+            type = S->materials[materialId].type;
+            if (type < 0 || type > 3) type = -1;
+        }
+    }
+    return type;
+}
+
 template <bool ORDERED>
 __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
@@ -273,33 +308,18 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
             hit = S->trace.hit[index];
             dirPix = S->trace.rayD[index];
             pixelIdx = __float_as_uint(dirPix.w);
-            const f3 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
             const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
-            const f3 throughput = mk3(tp.x, tp.y, tp.z);
-            if (hit.x == 1e30f) {
-                f3 bg = throughput * sample_background(S, dir);
-                if (S->envSampling && S->hdrMap.texels && bounce > 1 && S->settings.useMIS) {
-                    // the NEE samples the environment too: weight the BSDF-sampled miss against it (extension)
-                    const float envPdf = env_pdf(S, dir) / (float)nee_light_count(S);
-                    if (pdf_valid(envPdf)) bg = bg * power_heuristic(tp.w, envPdf);
-                }
+            bool miss, survived;
+            f3 bg = mk3(0.0f), t = mk3(0.0f);
+            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[index]; }, miss, bg, survived, t, inst);
+            if (miss) {
                 float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
                 r.x += bg.x; r.y += bg.y; r.z += bg.z;
                 if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 S->radiance[pixelIdx] = r;
                 if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
-            } else {
-                uint32_t rng = seed_for(S, (uint32_t)index, pixelIdx, (uint32_t)bounce, 0u, frame);
-                const float probability = maxcomp3(throughput);
-                if (rng_next(rng) < probability) {
-                    const f3 t = throughput / probability;
-                    S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
-                    inst = S->trace.hitInst[index];
-                    const int materialId = S->instances[inst].materialId;
-                    type = S->materials[materialId].type;
-                    if (type < 0 || type > 3) type = -1;
-                }
             }
+            if (survived) S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
         }
         const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
         int slot[4];
@@ -415,6 +435,98 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
     return true;
 }
 
+// Shade<BSDF> for one path (PathTracer.cu:311-458), without the queue traffic: shade_kernel wraps it with the material-queue
+// loads and the slot allocation, tail_kernel calls it in its per-path loop.  prevOrigin() returns the path's previous vertex
+// (only read for an emissive hit under MIS).  emit(radiance, instance) receives what the hit emits towards the path; what comes out: the shadow ray of its
+// light sample, the continuation ray and the path state that goes with it.  (Separate references, not a struct: the
+// compiler kept a struct of these in scratch memory, +30 % on the material kernels.)
+template <int TYPE, class PrevOrigin, class Emit>
+NXD void shade_path(const DeviceState* S, const int bounce, const uint32_t frame, const uint32_t seedSlot, const uint32_t pixelIdx, const float hu, const float hv,
+                    const uint32_t triIdx, const uint32_t instanceIdx, const f3 rayDirection, const float4 tpdf, PrevOrigin prevOrigin, Emit emit,
+                    bool& wantShadow, ShadowPayload& sh, bool& wantTrace, bool& updatePath, f3& nextOrigin, f3& nextDir, f3& nextThroughput, float& nextPdf)
+{
+    wantShadow = false; wantTrace = false; updatePath = false;
+    nextOrigin = mk3(0.0f); nextDir = mk3(0.0f); nextThroughput = mk3(0.0f);
+    nextPdf = 0.0f;
+    f3 throughput = mk3(tpdf.x, tpdf.y, tpdf.z);
+    uint32_t rng = seed_for(S, seedSlot, pixelIdx, (uint32_t)bounce, 1u, frame);
+
+    const nx_bvh_instance* inst = &S->instances[instanceIdx];
+    const BlasDev* bvh = &S->blas[inst->bvhIdx];
+    const nx_triangle* tri = &bvh->tris[triIdx];
+    const nx_material material = S->materials[inst->materialId];
+    MatParams mp = load_params(material);
+    const float* T = inst->transform.cell;
+    const float* IT = inst->invTransform.cell;
+    const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
+
+    const f3 p = mat_point(T, bary3(tp0, tp1, tp2, hu, hv));
+    f3 normal = bary3(ld3(tri->normal0), ld3(tri->normal1), ld3(tri->normal2), hu, hv);
+    const f2 texUv = bary2(tri->texCoord0, tri->texCoord1, tri->texCoord2, hu, hv);
+    normal = normalize3(mat_vec_transposed(IT, normal));
+    f3 gNormal = normalize3(mat_vec_transposed(IT, cross3(tp1 - tp0, tp2 - tp0)));
+
+    f3 emissive = ld3(material.emissive);
+    if (material.emissiveMapId != -1) {
+        const float4 c = tex2d(S->emissiveMaps[material.emissiveMapId], S->srgbLut, texUv.x, texUv.y);
+        emissive = mk3(c.x, c.y, c.z);
+    }
+    const bool useMIS = S->settings.useMIS != 0;
+    const bool allowMIS = bounce > 1 && useMIS;
+    f3 radiance = mk3(0.0f);
+    if (maxcomp3(emissive * material.intensity) > 0.0f) {
+        float weight = 1.0f;
+        if (allowMIS) {
+            const float lastPdf = tpdf.w;
+            const float cosThetaO = fabsf(dot3(normal, rayDirection));
+            const float4 ro = prevOrigin();
+            const float dSquared = squaref(length3(p - mk3(ro.x, ro.y, ro.z)));
+            const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
+            float lightPdf = 1.0f / ((float)(nee_light_count(S) * bvh->triCount) * area);
+            lightPdf *= dSquared / cosThetaO;
+            if (!pdf_valid(lightPdf)) weight = 0.0f;
+            else weight = power_heuristic(lastPdf, lightPdf);
+        }
+        radiance = ((emissive * weight) * material.intensity) * throughput;
+    }
+    emit(radiance, instanceIdx);  // (here, before the sampling code: the three values need not live across it)
+
+    if (bounce != (int)S->settings.pathLength) {
+        float4 color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (material.diffuseMapId != -1) {
+            color = tex2d(S->diffuseMaps[material.diffuseMapId], S->srgbLut, texUv.x, texUv.y);
+            mp.albedo = mk3(color.x, color.y, color.z);
+        }
+        if (dot3(gNormal, rayDirection) > 0.0f && TYPE != NX_MAT_DIELECTRIC) { normal = -normal; gNormal = -gNormal; }
+
+        const float4 q = rotation_to_z(normal);
+        const f3 wi = rotate_point(q, -rayDirection);
+        f3 wo;
+        if (rng_next(rng) > material.opacity || (material.diffuseMapId != -1 && rng_next(rng) > color.w)) {
+            // texture / opacity pass-through: continue straight, path state untouched
+            wo = normalize3(rotate_point(invert_rotation(q), -wi));
+            const float od = sgnE(dot3(wo, normal));
+            nextOrigin = offset_ray(p, gNormal * od);
+            nextDir = wo;
+            wantTrace = true;
+        } else {
+            if (useMIS) wantShadow = next_event_estimation<TYPE>(S, wi, mp, p, normal, gNormal, throughput, rng, sh);
+            float pdf;
+            f3 sampleThroughput;
+            if (Bsdf<TYPE>::sample(mp, wi, rng, wo, sampleThroughput, pdf)) {
+                wo = normalize3(rotate_point(invert_rotation(q), wo));
+                const float od = sgnE(dot3(wo, normal));
+                nextOrigin = offset_ray(p, gNormal * od);
+                nextDir = wo;
+                nextThroughput = throughput * sampleThroughput;
+                nextPdf = pdf;
+                wantTrace = true;
+                updatePath = true;
+            }
+        }
+    }
+}
+
 // Workgroups of 256 at 5 waves per SIMD (96 VGPRs, 5-11 spilled once per path), 10 workgroups per CU: equal to 512 threads
 // at 4 waves (126 VGPRs) for one large pass, +4.5 % for one-frame passes in flight, where a smaller register footprint lets
 // the material kernels of one slot share SIMDs with the trace waves of another.  6 and 8 waves per SIMD spill 30-87 VGPRs and
@@ -446,97 +558,23 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             const float4 hit = mq.hit[requestIdx];
             const float4 dirInst = mq.dirInst[requestIdx];
             pixelIdx = mq.pixel[requestIdx];
-            const f3 rayDirection = mk3(dirInst.x, dirInst.y, dirInst.z);
-            const uint32_t instanceIdx = __float_as_uint(dirInst.w), triIdx = __float_as_uint(hit.w);
-            const float hu = hit.y, hv = hit.z;
-
+            const uint32_t instanceIdx = __float_as_uint(dirInst.w);
             const float4 tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
-            f3 throughput = mk3(tpdf.x, tpdf.y, tpdf.z);
-            uint32_t rng = seed_for(S, (uint32_t)requestIdx, pixelIdx, (uint32_t)bounce, 1u, frame);
-
-            const nx_bvh_instance* inst = &S->instances[instanceIdx];
-            const BlasDev* bvh = &S->blas[inst->bvhIdx];
-            const nx_triangle* tri = &bvh->tris[triIdx];
-            const nx_material material = S->materials[inst->materialId];
-            MatParams mp = load_params(material);
-            const float* T = inst->transform.cell;
-            const float* IT = inst->invTransform.cell;
-            const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
-
-            const f3 p = mat_point(T, bary3(tp0, tp1, tp2, hu, hv));
-            f3 normal = bary3(ld3(tri->normal0), ld3(tri->normal1), ld3(tri->normal2), hu, hv);
-            const f2 texUv = bary2(tri->texCoord0, tri->texCoord1, tri->texCoord2, hu, hv);
-            normal = normalize3(mat_vec_transposed(IT, normal));
-            f3 gNormal = normalize3(mat_vec_transposed(IT, cross3(tp1 - tp0, tp2 - tp0)));
-
-            f3 emissive = ld3(material.emissive);
-            if (material.emissiveMapId != -1) {
-                const float4 c = tex2d(S->emissiveMaps[material.emissiveMapId], S->srgbLut, texUv.x, texUv.y);
-                emissive = mk3(c.x, c.y, c.z);
-            }
-            const bool useMIS = S->settings.useMIS != 0;
-            const bool allowMIS = bounce > 1 && useMIS;
-            f3 radiance = mk3(0.0f);
-            if (maxcomp3(emissive * material.intensity) > 0.0f) {
-                float weight = 1.0f;
-                if (allowMIS) {
-                    const float lastPdf = tpdf.w;
-                    const float cosThetaO = fabsf(dot3(normal, rayDirection));
-                    const float4 ro = S->rayOrigin[pixelIdx];
-                    const float dSquared = squaref(length3(p - mk3(ro.x, ro.y, ro.z)));
-                    const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
-                    float lightPdf = 1.0f / ((float)(nee_light_count(S) * bvh->triCount) * area);
-                    lightPdf *= dSquared / cosThetaO;
-                    if (!pdf_valid(lightPdf)) weight = 0.0f;
-                    else weight = power_heuristic(lastPdf, lightPdf);
-                }
-                radiance = ((emissive * weight) * material.intensity) * throughput;
-            }
-            if (bounce == 1) {
-                S->radiance[pixelIdx] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            } else if (radiance.x != 0.0f || radiance.y != 0.0f || radiance.z != 0.0f) {
-                // (most hits emit nothing: adding zeros would cost a 16-byte read and write per path and bounce)
-                float4 r = S->radiance[pixelIdx];
-                r.x += radiance.x; r.y += radiance.y; r.z += radiance.z;
-                S->radiance[pixelIdx] = r;
-            }
-
-            if (bounce != (int)S->settings.pathLength) {
-                if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = (int)instanceIdx;
-
-                float4 color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                if (material.diffuseMapId != -1) {
-                    color = tex2d(S->diffuseMaps[material.diffuseMapId], S->srgbLut, texUv.x, texUv.y);
-                    mp.albedo = mk3(color.x, color.y, color.z);
-                }
-                if (dot3(gNormal, rayDirection) > 0.0f && TYPE != NX_MAT_DIELECTRIC) { normal = -normal; gNormal = -gNormal; }
-
-                const float4 q = rotation_to_z(normal);
-                const f3 wi = rotate_point(q, -rayDirection);
-                f3 wo;
-                if (rng_next(rng) > material.opacity || (material.diffuseMapId != -1 && rng_next(rng) > color.w)) {
-                    // texture / opacity pass-through: continue straight, path state untouched
-                    wo = normalize3(rotate_point(invert_rotation(q), -wi));
-                    const float od = sgnE(dot3(wo, normal));
-                    nextOrigin = offset_ray(p, gNormal * od);
-                    nextDir = wo;
-                    wantTrace = true;
-                } else {
-                    if (useMIS) wantShadow = next_event_estimation<TYPE>(S, wi, mp, p, normal, gNormal, throughput, rng, sh);
-                    float pdf;
-                    f3 sampleThroughput;
-                    if (Bsdf<TYPE>::sample(mp, wi, rng, wo, sampleThroughput, pdf)) {
-                        wo = normalize3(rotate_point(invert_rotation(q), wo));
-                        const float od = sgnE(dot3(wo, normal));
-                        nextOrigin = offset_ray(p, gNormal * od);
-                        nextDir = wo;
-                        nextThroughput = throughput * sampleThroughput;
-                        nextPdf = pdf;
-                        wantTrace = true;
-                        updatePath = true;
-                    }
-                }
-            }
+            shade_path<TYPE>(S, bounce, frame, (uint32_t)requestIdx, pixelIdx, hit.y, hit.z, __float_as_uint(hit.w), instanceIdx, mk3(dirInst.x, dirInst.y, dirInst.z), tpdf,
+                             [&]() { return S->rayOrigin[pixelIdx]; },
+                             [&](f3 emitted, uint32_t instIdx) {
+                                 if (bounce == 1) {
+                                     S->radiance[pixelIdx] = make_float4(emitted.x, emitted.y, emitted.z, 0.0f);
+                                     if (bounce != (int)S->settings.pathLength && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx))
+                                         S->frame->pixelQueryInstance = (int)instIdx;
+                                 } else if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+                                     // (most hits emit nothing: adding zeros would cost a 16-byte read and write per path and bounce)
+                                     float4 r = S->radiance[pixelIdx];
+                                     r.x += emitted.x; r.y += emitted.y; r.z += emitted.z;
+                                     S->radiance[pixelIdx] = r;
+                                 }
+                             },
+                             wantShadow, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
         }
         const bool want[2] = {wantShadow, wantTrace};
         int slot[2];
@@ -557,6 +595,109 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         }
     }
     slots.finish();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Tail kernel: the late bounces of a pass without the graph.  From bounce `firstBounce` on a pass carries a few per cent of
+// its rays, yet every bounce still costs a trace level as long as its slowest ray plus a logic and four material launches.
+// Here a wave takes 64 paths of the trace queue after trace(firstBounce - 1) and runs each lane's path to its end —
+// logic, shade (the material kinds present in the wave, one after the other), the shadow ray of the light sample, the
+// continuation ray — with traverse_wave for the rays.  Same functions, same order of radiance additions per pixel, and the
+// random numbers are keyed by pixel, bounce and stage: the image is bit-identical to the level-by-level pipeline
+// (tests/test_gpu_tail.py).  Pixel-keyed random numbers and the workgroup-aggregated compaction only.
+__global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __restrict__ S, const int firstBounce)
+{
+    __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
+    Counters* C = S->counters;
+    const int size = C->traceSize[firstBounce - 1];
+    if (size <= 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
+    const uint32_t frame = S->frame->frameNumber;
+    const int pathLength = (int)S->settings.pathLength;
+    const int tiles = (size + kWave - 1) / kWave;
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(&C->tailHead, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= tiles) break;
+        const int index = tile * kWave + lane;
+        bool alive = index < size;
+        bool dirty = false;
+        uint32_t pixelIdx = 0, inst = 0, tri = 0;
+        float hitT = 1e30f, hu = 0.0f, hv = 0.0f;
+        f3 dir = mk3(0.0f);
+        float4 tp = make_float4(0, 0, 0, 0), ro = make_float4(0, 0, 0, 0), rad = make_float4(0, 0, 0, 0);
+        if (alive) {
+            const float4 hit = S->trace.hit[index];
+            const float4 dirPix = S->trace.rayD[index];
+            inst = S->trace.hitInst[index];
+            pixelIdx = __float_as_uint(dirPix.w);
+            dir = mk3(dirPix.x, dirPix.y, dirPix.z);
+            hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
+            tp = S->throughputPdf[pixelIdx];
+            ro = S->rayOrigin[pixelIdx];
+            rad = S->radiance[pixelIdx];
+        }
+        for (int bounce = firstBounce; bounce <= pathLength; bounce++) {
+            int type = -1;
+            if (alive) {
+                bool miss, survived;
+                f3 bg = mk3(0.0f), t = mk3(0.0f);
+                type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hitT, dir, tp, [&]() { return inst; }, miss, bg, survived, t, inst);
+                if (miss) { rad.x += bg.x; rad.y += bg.y; rad.z += bg.z; dirty = true; }
+                if (survived) { tp.x = t.x; tp.y = t.y; tp.z = t.z; }
+                if (type < 0) alive = false;
+            }
+            bool wantShadowRay = false, wantTrace = false, updatePath = false;
+            ShadowPayload sh;
+            sh.origin = mk3(0.0f); sh.direction = mk3(0.0f); sh.radiance = mk3(0.0f); sh.distance = 0.0f;
+            f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
+            float nextPdf = 0.0f;
+            const auto prevOrigin = [&]() { return ro; };
+            const auto emit = [&](f3 emitted, uint32_t) {
+                if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+                    rad.x += emitted.x; rad.y += emitted.y; rad.z += emitted.z;
+                    dirty = true;
+                }
+            };
+            if (__ballot(alive && type == NX_MAT_DIFFUSE) != 0ull) {
+                if (alive && type == NX_MAT_DIFFUSE) shade_path<NX_MAT_DIFFUSE>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+            }
+            if (__ballot(alive && type == NX_MAT_PLASTIC) != 0ull) {
+                if (alive && type == NX_MAT_PLASTIC) shade_path<NX_MAT_PLASTIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+            }
+            if (__ballot(alive && type == NX_MAT_DIELECTRIC) != 0ull) {
+                if (alive && type == NX_MAT_DIELECTRIC) shade_path<NX_MAT_DIELECTRIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+            }
+            if (__ballot(alive && type == NX_MAT_CONDUCTOR) != 0ull) {
+                if (alive && type == NX_MAT_CONDUCTOR) {
+                    if (S->conductorMode == NX_CONDUCTOR_EXTENDED) shade_path<NX_MAT_CONDUCTOR>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+                    else alive = false;  // (the reference's graph has no conductor kernel: such a path ends unshaded)
+                }
+            }
+            // the light sample's shadow ray: traced now, added when unoccluded (the shadow launch of this bounce, BVH8Traversal.cuh:515)
+            const bool wantShadow = alive && wantShadowRay;
+            if (__ballot(wantShadow) != 0ull) {
+                float t = wantShadow ? sh.distance : 0.0f, su, sv;
+                uint32_t st, si;
+                const bool occluded = traverse_wave<true>(S, stackLds, wantShadow, sh.origin, sh.direction, t, su, sv, st, si);
+                if (wantShadow && !occluded) {
+                    rad.x += sh.radiance.x; rad.y += sh.radiance.y; rad.z += sh.radiance.z;
+                    dirty = true;
+                }
+            }
+            alive = alive && wantTrace;
+            if (alive && updatePath) {
+                ro = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
+                tp = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
+            }
+            if (__ballot(alive) == 0ull) break;
+            dir = nextDir;
+            traverse_wave<false>(S, stackLds, alive, nextOrigin, nextDir, hitT, hu, hv, tri, inst);
+        }
+        if (dirty) S->radiance[pixelIdx] = rad;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -677,6 +818,7 @@ const void* shade_kernel_ptr(int type, bool ordered)
     default: return ordered ? (const void*)shade_kernel<NX_MAT_CONDUCTOR, true> : (const void*)shade_kernel<NX_MAT_CONDUCTOR, false>;
     }
 }
+const void* tail_kernel_ptr() { return (const void*)tail_kernel; }
 const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
 const void* generate_kernel_ptr() { return (const void*)generate_kernel; }
 const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }

@@ -15,6 +15,7 @@
 namespace nxd {
 
 const void* trace_kernel_ptr(bool anyHit, bool stats);
+const void* tail_kernel_ptr();
 const void* logic_kernel_ptr(bool ordered);
 const void* shade_kernel_ptr(int type, bool ordered);
 const void* begin_frame_kernel_ptr();
@@ -327,6 +328,12 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel_ptr(true, false), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
         c->shadowBlocks = std::max(1, perCU) * c->numCUs;
         c->wideBlocks = 8 * c->numCUs;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, tail_kernel_ptr(), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 2;
+        c->tailBlocks = std::max(1, perCU) * c->numCUs;
+        if (const char* e = std::getenv("NX_TAIL_BOUNCE")) {  // tuning experiments only: 0 = off
+            const int n = std::atoi(e);
+            if (n == 0 || n == -1 || (n >= 2 && n <= NX_PATH_MAX_LENGTH)) c->tailBounce = n;
+        }
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_PER_CU")) {  // tuning experiments only
             const int n = std::atoi(e);
             if (n >= 1 && n <= 16) { c->traceBlocks = c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
@@ -1060,6 +1067,21 @@ int trace_blocks(const nxhip_ctx* c, int fullGrid)
     return std::min(std::max(perCU, 1), maxPerCU) * c->numCUs;
 }
 
+// The bounce from which the tail kernel (nx_wavefront.hip) runs the rest of every path, 0 = never.  It needs random numbers
+// that do not depend on queue slots and has no ordered-compaction or instrumented form.
+// Automatic choice: bounce 5 for passes of up to 4 frames' worth of paths (by then a pass carries ~2 % of its primary rays): one
+// frame per pass 969 -> 1 123 Msamples/s with 6 passes in flight, 424 -> 460 with one; 4 frames +2 … +6 %.  Larger passes lose
+// (20 frames -1 %, 64 frames -7 %: a wave of the tail kernel keeps 64 lanes for as long as its longest path, and there the level-by-
+// level launches are already amortised), an earlier start loses as soon as several passes are in flight (bounce 4, 4 frames: -9 %).
+int tail_bounce(const nxhip_ctx* c)
+{
+    int bounce = c->tailBounce;
+    if (bounce < 0) bounce = (pass_size_in_frames(c) <= 4.0 && c->h.settings.pathLength >= 5u) ? 5 : 0;
+    if (bounce < 2 || bounce > (int)c->h.settings.pathLength) return 0;
+    if (c->h.rngMode != NX_RNG_PIXEL_KEYED || c->h.compactMode != NX_COMPACT_FAST || c->statsEnabled || c->timingEnabled) return 0;
+    return bounce;
+}
+
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
 std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
@@ -1076,7 +1098,12 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int pathLength = c->h.settings.pathLength;
     const int og = ordered ? 1 : c->shadeBlocksPerCU * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
     const int lg = ordered ? 1 : c->logicBlocksPerCU * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
+    const int tailFrom = tail_bounce(c);
     for (int bounce = 1; bounce <= pathLength; bounce++) {
+        if (bounce == tailFrom) {  // the rest of the pass in one launch
+            levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce)});
+            break;
+        }
         levels.push_back({make_launch(logic_kernel_ptr(ordered), lg, lb, NXHIP_K_LOGIC, S, bounce)});
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
         std::vector<Launch> shade;
@@ -1179,6 +1206,7 @@ static int build_graph(nxhip_ctx* c, PassSlot* q)
     q->graphValid = true;
     q->graphSerialShade = serial_shade(c);
     q->graphTraceBlocks = trace_blocks(c, c->traceBlocks);
+    q->graphTailBounce = tail_bounce(c);
     return NXHIP_OK;
 }
 
@@ -1238,7 +1266,8 @@ try {
             }
     } else {
         // (rebuilt when the pass size crossed the small-pass threshold or the number of passes in flight changed)
-        if (!q->graphValid || q->graphSerialShade != serial_shade(c) || q->graphTraceBlocks != trace_blocks(c, c->traceBlocks)) {
+        if (!q->graphValid || q->graphSerialShade != serial_shade(c) || q->graphTraceBlocks != trace_blocks(c, c->traceBlocks) ||
+            q->graphTailBounce != tail_bounce(c)) {
             rc = build_graph(c, q);
             if (rc != NXHIP_OK) return rc;
         }
@@ -1311,6 +1340,18 @@ int nxhip_accumulate(nxhip_ctx* c)
         q->awaitingAccumulate = false;
     }
     c->pending.clear();
+    return NXHIP_OK;
+}
+
+// Tail kernel: from `bounce` on (2 .. pathLength; 0 = off; NXHIP_TAIL_AUTO = the default) every path is finished by one launch
+// instead of a graph level per kernel and bounce.  Takes effect with pixel-keyed random numbers and the workgroup-aggregated
+// compaction only.
+int nxhip_set_tail_bounce(nxhip_ctx* c, uint32_t bounce)
+{
+    NX_CHECK_CTX(c);
+    if (bounce != NXHIP_TAIL_AUTO && (bounce == 1u || bounce > (uint32_t)NX_PATH_MAX_LENGTH))
+        return fail_invalid("nxhip_set_tail_bounce: bounce must be 0 (off), NXHIP_TAIL_AUTO or in [2, NX_PATH_MAX_LENGTH]");
+    c->tailBounce = bounce == NXHIP_TAIL_AUTO ? -1 : (int)bounce;  // the graphs notice at their next use (render_frame compares tail_bounce())
     return NXHIP_OK;
 }
 

@@ -92,6 +92,7 @@ def test_material_zoo_matches_oracle(gpu_ctx_factory, rng_mode, compact_mode, co
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     ctx.set_modes(rng_mode, compact_mode, conductor_mode)
+    ctx.set_tail_bounce(0)  # the queues of every bounce are inspected below (the tail kernel is covered by test_gpu_tail.py)
     got = _render_gpu(ctx, 4)
     orc, want = _render_oracle(scene, W * H, 4, rng_mode, conductor_mode)
     q = orc.queue_sizes()
