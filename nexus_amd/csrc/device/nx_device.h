@@ -107,7 +107,7 @@ struct Counters {
     int32_t shadowHead[kMaxBounceSlots][kXcds];
     // ordered-compaction running bases (single-workgroup mode)
     int32_t orderedBase[8];
-    int32_t tailHead;      // next 64-path tile of the tail kernel
+    int32_t tailHead;      // paths of the tail kernel's queue handed out so far
     int32_t pad_[3];
 };
 

@@ -605,6 +605,9 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
 // continuation ray — with traverse_wave for the rays.  Same functions, same order of radiance additions per pixel, and the
 // random numbers are keyed by pixel, bounce and stage: the image is bit-identical to the level-by-level pipeline
 // (tests/test_gpu_tail.py).  Pixel-keyed random numbers and the workgroup-aggregated compaction only.
+#ifndef NX_TAIL_REFILL_BELOW
+#define NX_TAIL_REFILL_BELOW 40
+#endif
 __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __restrict__ S, const int firstBounce)
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
@@ -612,92 +615,116 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
     const int size = C->traceSize[firstBounce - 1];
     if (size <= 0) return;
     const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
     lds_u64* const stackLds = (lds_u64*)&ldsStack[threadIdx.x];
     const uint32_t frame = S->frame->frameNumber;
-    const int pathLength = (int)S->settings.pathLength;
-    const int tiles = (size + kWave - 1) / kWave;
+
+    // per-lane path state; a lane whose path has ended takes the next path of the queue when the wave refills
+    bool alive = false, dirty = false;
+    int bounce = firstBounce, index = 0;
+    uint32_t pixelIdx = 0, inst = 0, tri = 0;
+    float hitT = 1e30f, hu = 0.0f, hv = 0.0f;
+    f3 dir = mk3(0.0f);
+    float4 tp = make_float4(0, 0, 0, 0), ro = make_float4(0, 0, 0, 0), rad = make_float4(0, 0, 0, 0);
+    bool exhausted = false;
+
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(&C->tailHead, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= tiles) break;
-        const int index = tile * kWave + lane;
-        bool alive = index < size;
-        bool dirty = false;
-        uint32_t pixelIdx = 0, inst = 0, tri = 0;
-        float hitT = 1e30f, hu = 0.0f, hv = 0.0f;
-        f3 dir = mk3(0.0f);
-        float4 tp = make_float4(0, 0, 0, 0), ro = make_float4(0, 0, 0, 0), rad = make_float4(0, 0, 0, 0);
+        // ---- refill: paths are handed out one by one (the head counts paths), 64 - alive at a time
+        unsigned long long aliveMask = __ballot(alive);
+        if (!exhausted && __popcll(aliveMask) < NX_TAIL_REFILL_BELOW) {
+            if (!alive && dirty) { S->radiance[pixelIdx] = rad; dirty = false; }
+            const unsigned long long needMask = ~aliveMask;
+            const int need = (int)__popcll(needMask);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&C->tailHead, need);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + need >= size) exhausted = true;
+            const int mine = base + (int)__popcll(needMask & laneLt);
+            if (!alive && mine < size) {
+                index = mine;
+                const float4 hit = S->trace.hit[index];
+                const float4 dirPix = S->trace.rayD[index];
+                inst = S->trace.hitInst[index];
+                pixelIdx = __float_as_uint(dirPix.w);
+                dir = mk3(dirPix.x, dirPix.y, dirPix.z);
+                hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
+                tp = S->throughputPdf[pixelIdx];
+                ro = S->rayOrigin[pixelIdx];
+                rad = S->radiance[pixelIdx];
+                bounce = firstBounce;
+                alive = true;
+            }
+            aliveMask = __ballot(alive);
+        }
+        if (aliveMask == 0ull) break;
+
+        // ---- logic and shade of every live path at its own bounce
+        int type = -1;
         if (alive) {
-            const float4 hit = S->trace.hit[index];
-            const float4 dirPix = S->trace.rayD[index];
-            inst = S->trace.hitInst[index];
-            pixelIdx = __float_as_uint(dirPix.w);
-            dir = mk3(dirPix.x, dirPix.y, dirPix.z);
-            hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
-            tp = S->throughputPdf[pixelIdx];
-            ro = S->rayOrigin[pixelIdx];
-            rad = S->radiance[pixelIdx];
+            bool miss, survived;
+            f3 bg = mk3(0.0f), t = mk3(0.0f);
+            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hitT, dir, tp, [&]() { return inst; }, miss, bg, survived, t, inst);
+            if (miss) { rad.x += bg.x; rad.y += bg.y; rad.z += bg.z; dirty = true; }
+            if (survived) { tp.x = t.x; tp.y = t.y; tp.z = t.z; }
+            if (type < 0) alive = false;
         }
-        for (int bounce = firstBounce; bounce <= pathLength; bounce++) {
-            int type = -1;
-            if (alive) {
-                bool miss, survived;
-                f3 bg = mk3(0.0f), t = mk3(0.0f);
-                type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hitT, dir, tp, [&]() { return inst; }, miss, bg, survived, t, inst);
-                if (miss) { rad.x += bg.x; rad.y += bg.y; rad.z += bg.z; dirty = true; }
-                if (survived) { tp.x = t.x; tp.y = t.y; tp.z = t.z; }
-                if (type < 0) alive = false;
+        bool wantShadowRay = false, wantTrace = false, updatePath = false;
+        ShadowPayload sh;
+        sh.origin = mk3(0.0f); sh.direction = mk3(0.0f); sh.radiance = mk3(0.0f); sh.distance = 0.0f;
+        f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
+        float nextPdf = 0.0f;
+        const auto prevOrigin = [&]() { return ro; };
+        const auto emit = [&](f3 emitted, uint32_t) {
+            if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+                rad.x += emitted.x; rad.y += emitted.y; rad.z += emitted.z;
+                dirty = true;
             }
-            bool wantShadowRay = false, wantTrace = false, updatePath = false;
-            ShadowPayload sh;
-            sh.origin = mk3(0.0f); sh.direction = mk3(0.0f); sh.radiance = mk3(0.0f); sh.distance = 0.0f;
-            f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
-            float nextPdf = 0.0f;
-            const auto prevOrigin = [&]() { return ro; };
-            const auto emit = [&](f3 emitted, uint32_t) {
-                if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
-                    rad.x += emitted.x; rad.y += emitted.y; rad.z += emitted.z;
-                    dirty = true;
-                }
-            };
-            if (__ballot(alive && type == NX_MAT_DIFFUSE) != 0ull) {
-                if (alive && type == NX_MAT_DIFFUSE) shade_path<NX_MAT_DIFFUSE>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
-            }
-            if (__ballot(alive && type == NX_MAT_PLASTIC) != 0ull) {
-                if (alive && type == NX_MAT_PLASTIC) shade_path<NX_MAT_PLASTIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
-            }
-            if (__ballot(alive && type == NX_MAT_DIELECTRIC) != 0ull) {
-                if (alive && type == NX_MAT_DIELECTRIC) shade_path<NX_MAT_DIELECTRIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
-            }
-            if (__ballot(alive && type == NX_MAT_CONDUCTOR) != 0ull) {
-                if (alive && type == NX_MAT_CONDUCTOR) {
-                    if (S->conductorMode == NX_CONDUCTOR_EXTENDED) shade_path<NX_MAT_CONDUCTOR>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
-                    else alive = false;  // (the reference's graph has no conductor kernel: such a path ends unshaded)
-                }
-            }
-            // the light sample's shadow ray: traced now, added when unoccluded (the shadow launch of this bounce, BVH8Traversal.cuh:515)
-            const bool wantShadow = alive && wantShadowRay;
-            if (__ballot(wantShadow) != 0ull) {
-                float t = wantShadow ? sh.distance : 0.0f, su, sv;
-                uint32_t st, si;
-                const bool occluded = traverse_wave<true>(S, stackLds, wantShadow, sh.origin, sh.direction, t, su, sv, st, si);
-                if (wantShadow && !occluded) {
-                    rad.x += sh.radiance.x; rad.y += sh.radiance.y; rad.z += sh.radiance.z;
-                    dirty = true;
-                }
-            }
-            alive = alive && wantTrace;
-            if (alive && updatePath) {
-                ro = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
-                tp = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
-            }
-            if (__ballot(alive) == 0ull) break;
-            dir = nextDir;
-            traverse_wave<false>(S, stackLds, alive, nextOrigin, nextDir, hitT, hu, hv, tri, inst);
+        };
+        if (__ballot(alive && type == NX_MAT_DIFFUSE) != 0ull) {
+            if (alive && type == NX_MAT_DIFFUSE)
+                shade_path<NX_MAT_DIFFUSE>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
         }
-        if (dirty) S->radiance[pixelIdx] = rad;
+        if (__ballot(alive && type == NX_MAT_PLASTIC) != 0ull) {
+            if (alive && type == NX_MAT_PLASTIC)
+                shade_path<NX_MAT_PLASTIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+        }
+        if (__ballot(alive && type == NX_MAT_DIELECTRIC) != 0ull) {
+            if (alive && type == NX_MAT_DIELECTRIC)
+                shade_path<NX_MAT_DIELECTRIC>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+        }
+        if (__ballot(alive && type == NX_MAT_CONDUCTOR) != 0ull) {
+            if (alive && type == NX_MAT_CONDUCTOR) {
+                if (S->conductorMode == NX_CONDUCTOR_EXTENDED)
+                    shade_path<NX_MAT_CONDUCTOR>(S, bounce, frame, (uint32_t)index, pixelIdx, hu, hv, tri, inst, dir, tp, prevOrigin, emit, wantShadowRay, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+                else alive = false;  // (the reference's graph has no conductor kernel: such a path ends unshaded)
+            }
+        }
+        // ---- the light sample's shadow ray: traced now, added when unoccluded (the shadow launch of this bounce, BVH8Traversal.cuh:515)
+        const bool wantShadow = alive && wantShadowRay;
+        if (__ballot(wantShadow) != 0ull) {
+            float t = wantShadow ? sh.distance : 0.0f, su, sv;
+            uint32_t st, si;
+            const bool occluded = traverse_wave<true>(S, stackLds, wantShadow, sh.origin, sh.direction, t, su, sv, st, si);
+            if (wantShadow && !occluded) {
+                rad.x += sh.radiance.x; rad.y += sh.radiance.y; rad.z += sh.radiance.z;
+                dirty = true;
+            }
+        }
+        // ---- the continuation ray (a path shaded at bounce == pathLength never asks for one)
+        alive = alive && wantTrace;
+        if (alive && updatePath) {
+            ro = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
+            tp = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
+        }
+        if (__ballot(alive) != 0ull) {
+            if (alive) dir = nextDir;
+            float nt = 1e30f, nu = 0.0f, nv = 0.0f;
+            uint32_t ntri = 0xffffffffu, ninst = 0xffffffffu;
+            traverse_wave<false>(S, stackLds, alive, nextOrigin, nextDir, nt, nu, nv, ntri, ninst);
+            if (alive) { hitT = nt; hu = nu; hv = nv; tri = ntri; inst = ninst; bounce++; }
+        }
     }
+    if (dirty) S->radiance[pixelIdx] = rad;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -1076,7 +1076,12 @@ int trace_blocks(const nxhip_ctx* c, int fullGrid)
 int tail_bounce(const nxhip_ctx* c)
 {
     int bounce = c->tailBounce;
-    if (bounce < 0) bounce = (pass_size_in_frames(c) <= 4.0 && c->h.settings.pathLength >= 5u) ? 5 : 0;
+    if (bounce < 0) {
+        const double frames = pass_size_in_frames(c);
+        if (frames > 4.0) bounce = 0;
+        else bounce = (frames <= 1.5 && effective_slots(c) <= 1u) ? 3 : 5;  // one small pass at a time: 424 -> 522 from bounce 3
+        if (bounce > (int)c->h.settings.pathLength) bounce = 0;
+    }
     if (bounce < 2 || bounce > (int)c->h.settings.pathLength) return 0;
     if (c->h.rngMode != NX_RNG_PIXEL_KEYED || c->h.compactMode != NX_COMPACT_FAST || c->statsEnabled || c->timingEnabled) return 0;
     return bounce;

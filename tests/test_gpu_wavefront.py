@@ -57,6 +57,7 @@ def test_cornell_frames_match_oracle(gpu_ctx_factory, rng_mode, compact_mode):
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     ctx.set_modes(rng_mode, compact_mode, pod.CONDUCTOR_REFERENCE)
+    ctx.set_tail_bounce(0)  # the queues of every bounce are inspected below
     got = _render_gpu(ctx, 3)
     orc, want = _render_oracle(scene, W * H, 3, rng_mode, pod.CONDUCTOR_REFERENCE)
     for f in range(3):
@@ -78,6 +79,7 @@ def test_config1_cornell_512_single_frame(gpu_ctx_factory):
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, pod.CONDUCTOR_REFERENCE)
+    ctx.set_tail_bounce(0)  # the queues of every bounce are inspected below
     got = _render_gpu(ctx, 1)[0]
     orc, want = _render_oracle(scene, W * H, 1, pod.RNG_REFERENCE_SLOT, pod.CONDUCTOR_REFERENCE)
     assert SH.image_agreement(got, want[0], PIXEL_TOL) >= MIN_AGREE
@@ -411,6 +413,7 @@ def test_passes_in_flight_render_the_same_image(gpu_ctx_factory):
         ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
         ctx.set_frames_per_pass(3)
         ctx.set_passes_in_flight(R)
+        ctx.set_tail_bounce(0)  # queue sizes are compared below; the tail kernel with passes in flight: test_gpu_tail.py
         ctx.set_pixel_query(40, 30)
         for i, n in enumerate(schedule):
             ctx.set_frames_per_pass(n)
