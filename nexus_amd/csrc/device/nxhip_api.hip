@@ -1079,7 +1079,7 @@ int tail_bounce(const nxhip_ctx* c)
     if (bounce < 0) {
         const double frames = pass_size_in_frames(c);
         if (frames > 4.0) bounce = 0;
-        else bounce = (frames <= 1.5 && effective_slots(c) <= 1u) ? 3 : 5;  // one small pass at a time: 424 -> 522 from bounce 3
+        else bounce = (frames <= 2.5 && effective_slots(c) <= 3u) ? 3 : 5;  // few small passes at a time: earlier (1 frame, R = 1: 424 -> 515; R = 3: 832 -> 889)
         if (bounce > (int)c->h.settings.pathLength) bounce = 0;
     }
     if (bounce < 2 || bounce > (int)c->h.settings.pathLength) return 0;
