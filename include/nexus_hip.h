@@ -123,8 +123,9 @@ int nxhip_set_passes_in_flight(nxhip_ctx *ctx, uint32_t passes);
  * From bounce `bounce` on — 2 .. pathLength, 0 = off — the rest of every path is run by ONE launch after the trace of
  * bounce - 1: each wave takes 64 paths and loops logic -> shade -> shadow ray -> continuation ray per lane.  Late bounces
  * carry a few per cent of a pass's rays but each costs a trace level as long as its slowest ray plus five more launches.
- * Default NXHIP_TAIL_AUTO: bounce 5 for passes of up to four 1080p frames' worth of paths (one frame per pass +9 %, with six
- * passes in flight +16 %), off for larger ones (where it loses).  Same functions and the same order of additions per pixel:
+ * Default NXHIP_TAIL_AUTO: for passes of up to four 1080p frames' worth of paths, bounce 5 (bounce 3 for up to 2.5 frames with
+ * at most three passes in flight) — one frame per pass +21 %, with six passes in flight +16 % — off for larger ones (where it
+ * loses).  Same functions and the same order of additions per pixel:
  * the image is bit-identical.  Only with NX_RNG_PIXEL_KEYED and NX_COMPACT_FAST, and not while kernel timing or the counting
  * variant is enabled (those passes use the level-by-level graph). */
 #define NXHIP_TAIL_AUTO 0xffffffffu
