@@ -72,22 +72,16 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const int homeRays = max(0, min(size, homeBegin + chunk) - homeBegin);
     // this wave's rank among the waves that call this shard home
     const int rankInShard = (int)(blockIdx.x >> 3) * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
-    // A wave whose rank is beyond the shard's ray count (one ray per lane) is not needed: it leaves without touching a
-    // fetch head.  The grid is sized for the largest queue; on a small one most waves would otherwise each walk all 8
-    // heads with returning atomics to find out that nothing is left, which made every launch cost about 0.5 ms however
-    // few rays it carried.
-    // How many waves work on a queue.  Up to 64 K rays: one wave per 64 rays — every ray has a lane at once, the launch is as
+    // A wave the queue does not need leaves without touching a fetch head.  The grid is sized for the largest queue; on a
+    // small one most waves would otherwise each walk all 8 heads with returning atomics to find out that nothing is left,
+    // which made every launch cost about 0.5 ms however few rays it carried.
+    // How many waves a queue needs.  Up to 64 K rays: one wave per 64 rays — every ray has a lane at once, the launch is as
     // long as its slowest ray, and at most one wave sits on each SIMD.  Larger queues first give those waves more rays
     // each (up to 256, refilled as lanes free up: a wave with a backlog keeps its lanes busy through what would be its
     // drain), then use more waves.  Against one wave per 64 rays throughout: the driver's 20-frame pass +4 % (its late
     // bounces carry 0.3-4 M rays), one-frame passes unchanged; 256 rays per wave throughout: one-frame passes -5 %.
     const int raysPerWave = min(256, max(kWave, (size >> 10) & ~(kWave - 1)));
     if (rankInShard * raysPerWave >= homeRays) return;
-#ifdef NX_STAGGER
-    // experiment: desynchronise the waves of a launch (they all start in the same microsecond and would otherwise hit
-    // the memory pipeline and the issue slots in lockstep)
-    for (int k = rankInShard % NX_STAGGER; k > 0; k--) __builtin_amdgcn_s_sleep(32);
-#endif
     // Reservation size: kReserve rays, but no more than half a wave's even share of the queue, so that on a small queue
     // every wave draws a few times and the launch does not end with a handful of waves still holding full blocks
     // (one frame per pass: +14 %; 64 frames per pass: within noise).
