@@ -30,6 +30,12 @@ public:
     const std::vector<uint32_t>& GetPixelBuffer();
     // Extensions (see nexus_pod.h)
     void SetModes(int rngMode, int compactMode, int conductorMode);
+    // Render() renders `frames` consecutive frames per call (bit-identical to as many single calls), lets `passes`
+    // consecutive calls overlap on the GPU, and finishes the late bounces of small passes in one launch: the three
+    // small-pass measures of the device layer (include/nexus_hip.h), none of which changes the image.
+    void SetFramesPerPass(uint32_t frames);
+    void SetPassesInFlight(uint32_t passes);
+    void SetTailBounce(uint32_t bounce);
     // Multi-GPU extension (no counterpart in the reference): one PathTracer per GPU, each renders and
     // accumulates the interleaved row tiles of its rank; Render() then ends with ONE RCCL gather of the accumulated tiles to
     // rank 0, whose GetPixelBuffer() returns the full frame.  `id128`: the 128 bytes rank 0 obtained from
@@ -45,6 +51,7 @@ public:
 private:
     nxhip_ctx* m_Ctx = nullptr;
     uint32_t m_FrameNumber = 0;
+    uint32_t m_FramesPerPass = 1;
     uint32_t m_ViewportWidth = 0, m_ViewportHeight = 0;
     std::vector<uint32_t> m_Pixels;
     bool m_PixelQueryPending = false;

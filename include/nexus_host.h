@@ -112,6 +112,10 @@ uint32_t nxs_scene_instance_count(const nxs_scene *s);
 int nxs_pathtracer_create(uint32_t width, uint32_t height, int device, nxs_pathtracer **out);
 void nxs_pathtracer_destroy(nxs_pathtracer *p);
 int nxs_pathtracer_set_modes(nxs_pathtracer *p, int rngMode, int compactMode, int conductorMode);
+/* PathTracer::SetFramesPerPass / SetPassesInFlight (extensions, include/nexus/PathTracer.h): frames per Render() call,
+ * Render() calls in flight */
+int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer *p, uint32_t frames);
+int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer *p, uint32_t passes);
 int nxs_pathtracer_update_device_scene(nxs_pathtracer *p, nxs_scene *s);
 int nxs_pathtracer_render(nxs_pathtracer *p, nxs_scene *s);
 int nxs_pathtracer_reset_frame_number(nxs_pathtracer *p);

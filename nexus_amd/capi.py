@@ -41,7 +41,7 @@ HOST_SYMBOLS = [
     "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
-    "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes",
+    "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes", "nxs_pathtracer_set_frames_per_pass", "nxs_pathtracer_set_passes_in_flight",
     "nxs_pathtracer_update_device_scene", "nxs_pathtracer_render", "nxs_pathtracer_reset_frame_number", "nxs_pathtracer_frame_number",
     "nxs_pathtracer_read_pixels", "nxs_pathtracer_device_context",
 ]
@@ -200,6 +200,8 @@ def lib():
     L.nxs_pathtracer_destroy.argtypes = [vp]
     L.nxs_pathtracer_destroy.restype = None
     L.nxs_pathtracer_set_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.nxs_pathtracer_set_frames_per_pass.argtypes = [vp, C.c_uint32]
+    L.nxs_pathtracer_set_passes_in_flight.argtypes = [vp, C.c_uint32]
     L.nxs_pathtracer_update_device_scene.argtypes = [vp, vp]
     L.nxs_pathtracer_render.argtypes = [vp, vp]
     L.nxs_pathtracer_reset_frame_number.argtypes = [vp]
@@ -902,6 +904,12 @@ class PathTracer:
 
     def set_modes(self, rng_mode, compact_mode, conductor_mode):
         _scheck(self.L.nxs_pathtracer_set_modes(self.h, rng_mode, compact_mode, conductor_mode), "nxs_pathtracer_set_modes")
+
+    def set_frames_per_pass(self, frames):
+        _scheck(self.L.nxs_pathtracer_set_frames_per_pass(self.h, frames), "nxs_pathtracer_set_frames_per_pass")
+
+    def set_passes_in_flight(self, passes):
+        _scheck(self.L.nxs_pathtracer_set_passes_in_flight(self.h, passes), "nxs_pathtracer_set_passes_in_flight")
 
     def update_device_scene(self, scene):
         _scheck(self.L.nxs_pathtracer_update_device_scene(self.h, scene.h), "nxs_pathtracer_update_device_scene")

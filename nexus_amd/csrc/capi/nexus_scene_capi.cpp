@@ -254,6 +254,8 @@ int nxs_pathtracer_set_modes(nxs_pathtracer* p, int rngMode, int compactMode, in
 {
     return guarded([&] { p->pt.SetModes(rngMode, compactMode, conductorMode); });
 }
+int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer* p, uint32_t frames) { return guarded([&] { p->pt.SetFramesPerPass(frames); }); }
+int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer* p, uint32_t passes) { return guarded([&] { p->pt.SetPassesInFlight(passes); }); }
 int nxs_pathtracer_update_device_scene(nxs_pathtracer* p, nxs_scene* s)
 {
     return guarded([&] { p->pt.UpdateDeviceScene(s->scene); });

@@ -106,9 +106,17 @@ void PathTracer::UpdateDeviceScene(const Scene& scene)
     Check(nxhip_set_render_settings(m_Ctx, reinterpret_cast<const nx_render_settings*>(&scene.GetRenderSettings())), "nxhip_set_render_settings");
 }
 
+void PathTracer::SetFramesPerPass(uint32_t frames)
+{
+    Check(nxhip_set_frames_per_pass(m_Ctx, frames), "nxhip_set_frames_per_pass");
+    m_FramesPerPass = frames;
+}
+void PathTracer::SetPassesInFlight(uint32_t passes) { Check(nxhip_set_passes_in_flight(m_Ctx, passes), "nxhip_set_passes_in_flight"); }
+void PathTracer::SetTailBounce(uint32_t bounce) { Check(nxhip_set_tail_bounce(m_Ctx, bounce), "nxhip_set_tail_bounce"); }
+
 void PathTracer::Render(const Scene&)
 {
-    m_FrameNumber++;
+    m_FrameNumber += m_FramesPerPass;
     Check(nxhip_render_frame(m_Ctx), "nxhip_render_frame");
     Check(nxhip_accumulate(m_Ctx), "nxhip_accumulate");
     if (m_TileSplit) Check(nxhip_mgpu_gather(m_Ctx), "nxhip_mgpu_gather");

@@ -58,6 +58,29 @@ def test_facade_frame_equals_direct_capi_frame(gpu_ctx_factory):
     pt.close()
 
 
+@pytest.mark.gpu
+def test_facade_small_pass_measures_do_not_change_the_image():
+    """PathTracer::SetFramesPerPass / SetPassesInFlight (and the tail kernel that small keyed passes use by default): six
+    frames as six Render() calls, as three calls of two frames, and with three calls in flight — the same pixels."""
+    W, H = 96, 64
+    images = []
+    for frames, in_flight in ((1, 1), (2, 1), (1, 3), (2, 3)):
+        sc = _cornell_facade(W, H, 6)
+        pt = capi.PathTracer(W, H)
+        pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+        pt.update_device_scene(sc)
+        pt.set_frames_per_pass(frames)
+        pt.set_passes_in_flight(in_flight)
+        for _ in range(6 // frames):
+            pt.render(sc)
+        assert pt.frame_number() == 6
+        images.append(pt.read_pixels())
+        pt.close()
+    for img in images[1:]:
+        assert np.array_equal(img, images[0])
+    assert len(np.unique(images[0])) > 16
+
+
 def _cornell_from_file(width, height, path_length):
     """The reference's own call: Scene::CreateMeshInstanceFromFile (C++ glb reader), materials as the file gives them."""
     sc = capi.Scene(width, height)
