@@ -896,6 +896,9 @@ int nxhip_set_camera(nxhip_ctx* c, const nx_camera* camera)
     if (!camera) return fail_invalid("nxhip_set_camera: null camera");
     if (camera->resolution[0] != c->width || camera->resolution[1] != c->height)
         return fail_invalid("nxhip_set_camera: camera resolution differs from the context viewport (call nxhip_resize first)");
+    // (the reference's Render loop hands the camera and the settings over every frame: an unchanged one must not cost the
+    //  state upload, which waits for every pass in flight)
+    if (std::memcmp(&c->h.camera, camera, sizeof *camera) == 0) return NXHIP_OK;
     c->h.camera = *camera;
     c->stateDirty = true;
     return NXHIP_OK;
@@ -906,6 +909,7 @@ int nxhip_set_render_settings(nxhip_ctx* c, const nx_render_settings* s)
     NX_CHECK_CTX(c);
     if (!s) return fail_invalid("nxhip_set_render_settings: null settings");
     if (s->pathLength < 1 || s->pathLength > NX_PATH_MAX_LENGTH - 2) return fail_invalid("nxhip_set_render_settings: pathLength must be in [1, 98]");
+    if (std::memcmp(&c->h.settings, s, sizeof *s) == 0) return NXHIP_OK;
     if (s->pathLength != c->h.settings.pathLength) invalidate_graph(c);
     c->h.settings = *s;
     c->stateDirty = true;
@@ -917,6 +921,7 @@ int nxhip_set_modes(nxhip_ctx* c, int rngMode, int compactMode, int conductorMod
     NX_CHECK_CTX(c);
     if (rngMode < 0 || rngMode > 1 || compactMode < 0 || compactMode > 1 || conductorMode < 0 || conductorMode > 1)
         return fail_invalid("nxhip_set_modes: unknown mode");
+    if (rngMode == c->h.rngMode && compactMode == c->h.compactMode && conductorMode == c->h.conductorMode) return NXHIP_OK;
     if (compactMode != c->h.compactMode || conductorMode != c->h.conductorMode) invalidate_graph(c);
     c->h.rngMode = rngMode;
     c->h.compactMode = compactMode;
