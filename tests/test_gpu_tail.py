@@ -73,3 +73,16 @@ def test_tail_kernel_with_environment_sampling(gpu_ctx_factory):
     got = _render(gpu_ctx_factory, scene, W, H, 2, env_sampling=True)
     assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
     assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+
+
+def test_tail_kernel_at_the_benchmark_size(gpu_ctx_factory):
+    """BASELINE.json configs[1] (1 M triangles, 1920x1080, 8 bounces), two frames, passes in flight: the accumulation with the
+    tail kernel from bounce 3 and from bounce 5 equals the level-by-level one bit for bit."""
+    from tests import config_scenes as CS
+    W, H = 1920, 1080
+    scene = CS.config2(W, H)
+    want = _render(gpu_ctx_factory, scene, W, H, 0, frames_per_pass=1, passes=2)
+    for tail, R in ((3, 1), (5, 2)):
+        got = _render(gpu_ctx_factory, scene, W, H, tail, frames_per_pass=1, passes=2, in_flight=R)
+        assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (tail, R)
+        assert np.array_equal(got[2], want[2])
