@@ -25,8 +25,8 @@
 //   * triangles come from a leaf-ordered 48-byte stream (p0|id, e0, e1) built at upload: no triangleIdx
 //     indirection; instances from an 80-byte leaf-ordered traversal record;
 //   * the traversal stack lives in LDS, entry-major ([depth][lane]) so ds_read/write_b64 are
-//     conflict-free, with a scratch overflow; the world-space ray is re-read from the queue when an
-//     instance is left instead of being kept in 6 VGPRs.
+//     conflict-free, with a scratch overflow; the world-space ray of a lane inside a transformed instance is
+//     parked in LDS instead of being kept in 9 VGPRs.
 // No MFMA: this is pointer chasing, bounded by memory latency / bandwidth.
 #define NX_KERNEL_TU 1
 #include "nx_traverse.h"
@@ -53,6 +53,10 @@ __attribute__((amdgpu_waves_per_eu(NX_WAVES_PER_EU, NX_WAVES_PER_EU)))
 __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
+    // the world-space ray (origin, direction, 1 / direction) of a lane that is inside a transformed instance: parked here on
+    // entry and taken back on exit.  (Re-reading the ray from its queue on exit put a second, dependent memory round trip
+    // and three IEEE divisions into every iteration in which any lane left an instance — most of them on instanced scenes.)
+    __shared__ float ldsWorld[9 * kTraceBlock];
 
     NX_G Counters* C = S->counters;
     const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
@@ -225,10 +229,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 } else {
                     if (sp == instSp) {  // leaving the instance: back to the world-space ray and the TLAS
                         if (xformed) {
-                            const float4 o = rayO[rayIdx], d = rayD[rayIdx];
-                            org = mk3(o.x, o.y, o.z);
-                            dir = mk3(d.x, d.y, d.z);
-                            idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                            const float* w = &ldsWorld[threadIdx.x];
+                            org = mk3(w[0 * kTraceBlock], w[1 * kTraceBlock], w[2 * kTraceBlock]);
+                            dir = mk3(w[3 * kTraceBlock], w[4 * kTraceBlock], w[5 * kTraceBlock]);
+                            idir = mk3(w[6 * kTraceBlock], w[7 * kTraceBlock], w[8 * kTraceBlock]);
                         }
                         nodes = tlasNodes;
                         instSp = -1;
@@ -298,6 +302,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 xformed = ((__float_as_uint(o2.x) ^ __float_as_uint(org.x)) | (__float_as_uint(o2.y) ^ __float_as_uint(org.y)) | (__float_as_uint(o2.z) ^ __float_as_uint(org.z)) |
                            (__float_as_uint(d2.x) ^ __float_as_uint(dir.x)) | (__float_as_uint(d2.y) ^ __float_as_uint(dir.y)) | (__float_as_uint(d2.z) ^ __float_as_uint(dir.z))) != 0u;
                 if (xformed) {
+                    float* w = &ldsWorld[threadIdx.x];
+                    w[0 * kTraceBlock] = org.x; w[1 * kTraceBlock] = org.y; w[2 * kTraceBlock] = org.z;
+                    w[3 * kTraceBlock] = dir.x; w[4 * kTraceBlock] = dir.y; w[5 * kTraceBlock] = dir.z;
+                    w[6 * kTraceBlock] = idir.x; w[7 * kTraceBlock] = idir.y; w[8 * kTraceBlock] = idir.z;
                     org = o2;
                     dir = d2;
                     idir = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
