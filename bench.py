@@ -207,6 +207,10 @@ def main():
         sc.settings["useMIS"] = 0
         workload_name += " [useMIS off: experiment]"
 
+    if os.environ.get("NX_BENCH_NO_ENV_SAMPLING"):  # experiment only: the share of environment importance sampling
+        sc.env_sampling = False
+        workload_name += " [environment sampling off: experiment]"
+
     dist = None
     torch = None
     if dist_mode:

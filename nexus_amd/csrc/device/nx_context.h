@@ -131,7 +131,7 @@ struct nxhip_ctx : nxd::PassSlot {
     // environment importance sampling (extension): host copy of the hdr map and the tables built from it
     std::vector<uint8_t> hostHdr;
     bool envSampling = false;
-    nxd::DevBuf envMarginalCdf, envRowCdf, envDensity;
+    nxd::DevBuf envMarginalCdf, envRowCdf, envDensity, envMarginalGuide, envRowGuide;
     // paths / queues
     nxd::DevBuf pixelMap, accumulation, rgba8;
     nxd::DevBuf traceStats;

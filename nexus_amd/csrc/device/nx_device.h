@@ -50,6 +50,7 @@ constexpr int kNodeStride = NX_NODE_STRIDE;
 constexpr int kTriStride = NX_TRI_STRIDE;
 
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with its own L2
+constexpr int kEnvGuide = 64;   // buckets of the environment sampler's cdf search guides
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;
 
@@ -152,6 +153,10 @@ struct DeviceState {
     const NX_G float* envMarginalCdf;
     const NX_G float* envRowCdf;
     const NX_G float* envDensity;
+    // search guides: entry b of a guide = the first index whose cdf exceeds b / kEnvGuide (kEnvGuide + 1 entries per cdf), so
+    // that inverting a cdf at r starts from the bracket of bucket floor(r * kEnvGuide) instead of the whole array
+    const NX_G uint32_t* envMarginalGuide;
+    const NX_G uint32_t* envRowGuide;
     // paths: a pass renders framesPerPass consecutive frames at once; path p belongs to frame slice p / localCount
     // and to local pixel p % localCount.  Batching frames keeps every kernel large (the tail of a trace launch is
     // set by its slowest ray) and uses HBM capacity instead of launches.

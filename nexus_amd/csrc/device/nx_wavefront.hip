@@ -219,9 +219,13 @@ NXD float env_pdf(const DeviceState* S, f3 d)
     return S->envDensity[env_texel(S, d)] / cosLat;
 }
 
-NXD int cdf_find(const NX_G float* cdf, int n, float r)  // first index whose cdf exceeds r
+// first index whose cdf exceeds r (n - 1 when none does).  `guide` brackets the answer: entry b is the first index whose cdf
+// exceeds b / kEnvGuide, r lies in bucket floor(r * kEnvGuide), so the search starts from [guide[b], guide[b + 1]] instead
+// of [0, n - 1] — the same index after 2-5 dependent loads instead of 10-11.
+NXD int cdf_find(const NX_G float* cdf, const NX_G uint32_t* guide, int n, float r)
 {
-    int lo = 0, hi = n - 1;
+    const int b = min(kEnvGuide - 1, max(0, (int)(r * (float)kEnvGuide)));
+    int lo = (int)guide[b], hi = min(n - 1, (int)guide[b + 1]);
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (cdf[mid] > r) hi = mid;
@@ -233,11 +237,11 @@ NXD int cdf_find(const NX_G float* cdf, int n, float r)  // first index whose cd
 NXD f3 env_sample(const DeviceState* S, float r1, float r2)
 {
     const int W = (int)S->hdrMap.width, H = (int)S->hdrMap.height;
-    const int y = cdf_find(S->envMarginalCdf, H, r1);
+    const int y = cdf_find(S->envMarginalCdf, S->envMarginalGuide, H, r1);
     const float ylo = y ? S->envMarginalCdf[y - 1] : 0.0f;
     const float fy = (r1 - ylo) / (S->envMarginalCdf[y] - ylo);
     const NX_G float* row = S->envRowCdf + (size_t)y * (size_t)W;
-    const int x = cdf_find(row, W, r2);
+    const int x = cdf_find(row, S->envRowGuide + (size_t)y * (size_t)(kEnvGuide + 1), W, r2);
     const float xlo = x ? row[x - 1] : 0.0f;
     const float fx = (r2 - xlo) / (row[x] - xlo);
     const float u = ((float)x + fx) / (float)W, v = ((float)y + fy) / (float)H;
@@ -369,13 +373,14 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
         // the environment (extension): direction from the map's luminance distribution, shadow ray to infinity
         const float r1 = rng_next(rng), r2 = rng_next(rng);
         const f3 shDir = env_sample(S, r1, r2);
-        const float lightPdf = env_pdf(S, shDir) / (float)nLights;
-        if (!pdf_valid(lightPdf)) return false;
+        // (the BSDF first: a direction it rejects — most of them on a near-specular surface — needs no density lookup)
         const float4 q = rotation_to_z(normal);
         const f3 wo = rotate_point(q, shDir);
         f3 sampleThroughput;
         float bsdfPdf;
         if (!Bsdf<TYPE>::eval(mp, wi, wo, sampleThroughput, bsdfPdf)) return false;
+        const float lightPdf = env_pdf(S, shDir) / (float)nLights;
+        if (!pdf_valid(lightPdf)) return false;
         const float weight = power_heuristic(lightPdf, bsdfPdf);
         out.radiance = (((throughput * weight) * sampleThroughput) * sample_background(S, shDir)) / lightPdf;
         out.origin = offset_ray(hitPoint, hitGNormal * sgnE(dot3(shDir, normal)));

@@ -782,6 +782,7 @@ static int build_env_tables(nxhip_ctx* c)
     if (!c->envSampling || W == 0 || H == 0 || c->hostHdr.size() != (size_t)W * H * 4) {
         c->h.envSampling = 0;
         c->h.envMarginalCdf = c->h.envRowCdf = c->h.envDensity = nullptr;
+        c->h.envMarginalGuide = c->h.envRowGuide = nullptr;
         c->stateDirty = true;
         return NXHIP_OK;
     }
@@ -818,7 +819,25 @@ static int build_env_tables(nxhip_ctx* c)
         run += rowSum[y];
         marginal[y] = y == H - 1 ? 1.0f : (float)(run / total);
     }
+    // guides for the device's cdf inversion (nx_wavefront.hip cdf_find): bracket per bucket of the random number
+    auto make_guide = [](const float* cdf, uint32_t n, uint32_t* guide) {
+        uint32_t idx = 0;
+        for (int b = 0; b <= kEnvGuide; b++) {
+            const float bound = (float)b / (float)kEnvGuide;
+            while (idx < n - 1 && !(cdf[idx] > bound)) idx++;
+            guide[b] = idx;
+        }
+    };
+    std::vector<uint32_t> marginalGuide(kEnvGuide + 1), rowGuide((size_t)H * (kEnvGuide + 1));
+    make_guide(marginal.data(), H, marginalGuide.data());
+    for (uint32_t y = 0; y < H; y++) make_guide(&row[(size_t)y * W], W, &rowGuide[(size_t)y * (kEnvGuide + 1)]);
     NX_SYNC_ALL(c);
+    NX_ALLOC(c->envMarginalGuide, marginalGuide.size() * 4);
+    NX_ALLOC(c->envRowGuide, rowGuide.size() * 4);
+    NX_HIP(hipMemcpy(c->envMarginalGuide.p, marginalGuide.data(), marginalGuide.size() * 4, hipMemcpyHostToDevice));
+    NX_HIP(hipMemcpy(c->envRowGuide.p, rowGuide.data(), rowGuide.size() * 4, hipMemcpyHostToDevice));
+    c->h.envMarginalGuide = c->envMarginalGuide.as<uint32_t>();
+    c->h.envRowGuide = c->envRowGuide.as<uint32_t>();
     NX_ALLOC(c->envMarginalCdf, marginal.size() * 4);
     NX_ALLOC(c->envRowCdf, row.size() * 4);
     NX_ALLOC(c->envDensity, density.size() * 4);
