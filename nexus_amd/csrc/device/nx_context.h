@@ -75,7 +75,7 @@ struct PassSlot {
     DevBuf throughputPdf, radiance, rayOrigin;
     DevBuf trRayO, trRayD, trHit, trHitInst;
     DevBuf shRayO, shRayD, shRadiance;
-    DevBuf mqHit[4], mqDirInst[4], mqPixel[4];
+    DevBuf mqHit[4], mqDirInst[4];
     DevBuf counters, frame, dState;
     size_t pathCapacity = 0;  // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
     hipGraph_t graph = nullptr;

@@ -13,7 +13,7 @@
 //                      hitInst u32            — reference D_TraceRequestSOA, Cuda/PathTracer/PathTracer.cuh:32-37
 //              shadow  rayO float4 (origin, tmax), rayD float4 (direction, pixelIdx), rad float4
 //                                             — D_ShadowTraceRequestSOA, PathTracer.cuh:39-45
-//              material[4] hit float4, dirInst float4 (direction, instanceIdx), pixel u32
+//              material[4] hit float4 (pathIdx, u, v, triIdx), dirInst float4 (direction, instanceIdx)
 //                                             — D_MaterialRequestSOA, PathTracer.cuh:47-52
 //              path    throughput float4 (rgb, lastPdf), radiance float4, rayOrigin float4
 //                                             — D_PathStateSOA, PathTracer.cuh:19-30
@@ -93,9 +93,8 @@ struct ShadowQueue {
     NX_G float4* radiance;
 };
 struct MaterialQueue {
-    NX_G float4* hit;
-    NX_G float4* dirInst;
-    NX_G uint32_t* pixel;
+    NX_G float4* hit;      // (path index, u, v, triangle)
+    NX_G float4* dirInst;  // (ray direction, instance)
 };
 
 // Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize

@@ -171,7 +171,10 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         const f3 offset = camRight * rdx + camUp * rdy;
         const f3 origin = camPos + offset;
         const f3 direction = normalize3((((llc + vpX * x) + vpY * y) - camPos) - offset);
-        S->rayOrigin[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+        // the path's radiance starts at zero here (a coalesced 16-byte store) so that the first hit adds to it only when it
+        // emits, like every later one.  (rayOrigin needs no initial value: it is read from bounce 2 on, after the bounce-1
+        // material kernels have written it.)
+        S->radiance[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
         // reading them back, and the logic kernel stores them for every path that survives its first hit
         S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
@@ -331,9 +334,10 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
         if (type >= 0) {
             const MaterialQueue mq = S->material[type];
             const int sl = type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3]));
-            mq.hit[sl] = hit;
+            // the hit distance is of no use to the material kernels (they work from u, v): its slot carries the path index,
+            // which saves a third array (4 B written and read per path, one load and one store instruction each)
+            mq.hit[sl] = make_float4(__uint_as_float(pixelIdx), hit.y, hit.z, hit.w);
             mq.dirInst[sl] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
-            mq.pixel[sl] = pixelIdx;
         }
     }
     slots.finish();
@@ -562,17 +566,15 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         if (requestIdx < size) {
             const float4 hit = mq.hit[requestIdx];
             const float4 dirInst = mq.dirInst[requestIdx];
-            pixelIdx = mq.pixel[requestIdx];
+            pixelIdx = __float_as_uint(hit.x);
             const uint32_t instanceIdx = __float_as_uint(dirInst.w);
             const float4 tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
             shade_path<TYPE>(S, bounce, frame, (uint32_t)requestIdx, pixelIdx, hit.y, hit.z, __float_as_uint(hit.w), instanceIdx, mk3(dirInst.x, dirInst.y, dirInst.z), tpdf,
                              [&]() { return S->rayOrigin[pixelIdx]; },
                              [&](f3 emitted, uint32_t instIdx) {
-                                 if (bounce == 1) {
-                                     S->radiance[pixelIdx] = make_float4(emitted.x, emitted.y, emitted.z, 0.0f);
-                                     if (bounce != (int)S->settings.pathLength && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx))
-                                         S->frame->pixelQueryInstance = (int)instIdx;
-                                 } else if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+                                 if (bounce == 1 && bounce != (int)S->settings.pathLength && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx))
+                                     S->frame->pixelQueryInstance = (int)instIdx;
+                                 if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
                                      // (most hits emit nothing: adding zeros would cost a 16-byte read and write per path and bounce)
                                      float4 r = S->radiance[pixelIdx];
                                      r.x += emitted.x; r.y += emitted.y; r.z += emitted.z;

@@ -144,7 +144,7 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
         v.rayOrigin = s->rayOrigin.as<float4>();
         v.trace = TraceQueue{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trHit.as<float4>(), s->trHitInst.as<uint32_t>()};
         v.shadow = ShadowQueue{s->shRayO.as<float4>(), s->shRayD.as<float4>(), s->shRadiance.as<float4>()};
-        for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>(), s->mqPixel[m].as<uint32_t>()};
+        for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>()};
     }
     v.counters = s->counters.as<Counters>();
     v.frame = s->frame.as<FrameState>();
@@ -170,9 +170,9 @@ static int upload_state(nxhip_ctx* c)
 static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
 {
     DevBuf* const slots[] = {&q->throughputPdf, &q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->shRayO, &q->shRayD, &q->shRadiance,
-                             &q->mqHit[0], &q->mqDirInst[0], &q->mqPixel[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqPixel[1],
-                             &q->mqHit[2], &q->mqDirInst[2], &q->mqPixel[2], &q->mqHit[3], &q->mqDirInst[3], &q->mqPixel[3]};
-    const size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 4, 16, 16, 4, 16, 16, 4, 16, 16, 4};
+                             &q->mqHit[0], &q->mqDirInst[0], &q->mqHit[1], &q->mqDirInst[1],
+                             &q->mqHit[2], &q->mqDirInst[2], &q->mqHit[3], &q->mqDirInst[3]};
+    const size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
     static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
     DevBuf fresh[kCount];
@@ -190,7 +190,7 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
         h.rayOrigin = c->rayOrigin.as<float4>();
         h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
         h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
-        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqPixel[m].as<uint32_t>()};
+        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>()};
     }
     c->stateDirty = true;
     return NXHIP_OK;
