@@ -172,9 +172,12 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         const f3 origin = camPos + offset;
         const f3 direction = normalize3((((llc + vpX * x) + vpY * y) - camPos) - offset);
         // the path's radiance starts at zero here (a coalesced 16-byte store) so that the first hit adds to it only when it
-        // emits, like every later one.  (rayOrigin needs no initial value: it is read from bounce 2 on, after the bounce-1
-        // material kernels have written it.)
+        // emits, like every later one.  rayOrigin: the previous path vertex for the MIS weight of an emissive hit — read from
+        // bounce 2 on, normally after the bounce-1 material kernel has replaced it, but a bounce-1 pass-through (opacity,
+        // texture alpha) leaves the path state as it is and the camera origin is then what the reference uses
+        // (test_pass_through_at_the_first_hit_keeps_the_camera_origin_for_mis).
         S->radiance[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        S->rayOrigin[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
         // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
         // reading them back, and the logic kernel stores them for every path that survives its first hit
         S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);

@@ -426,3 +426,28 @@ def test_passes_in_flight_render_the_same_image(gpu_ctx_factory):
         assert np.array_equal(got[1], results[0][1])
         assert np.array_equal(got[2].view(np.uint32), results[0][2].view(np.uint32))
         assert np.array_equal(got[3], results[0][3]) and got[4] == results[0][4] and got[5] == results[0][5] == sum(schedule)
+
+
+def test_pass_through_at_the_first_hit_keeps_the_camera_origin_for_mis(gpu_ctx_factory):
+    """A half-transparent sheet in front of a light that fills the view: half of the paths pass through the sheet at bounce 1
+    (path state untouched, PathTracer.cu:372-386) and hit the emitter at bounce 2, where the MIS weight measures the
+    distance from the path's previous vertex — still the camera origin.  Pixelwise against the oracle."""
+    from nexus_amd import capi, scenegen
+    W, H = 96, 64
+    sheet = scenegen.quad((-3, -2, 0.0), (3, -2, 0.0), (3, 2, 0.0), (-3, 2, 0.0))
+    light = scenegen.quad((-4, -3, -2.0), (4, -3, -2.0), (4, 3, -2.0), (-4, 3, -2.0))
+    mats = np.array([pod.make_material(pod.MAT_DIFFUSE, albedo=(0.6, 0.6, 0.6), opacity=0.5),
+                     pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 0.8, 0.6), intensity=3.0)], dtype=pod.MAT_DT)
+    cam = capi.camera_init((0.0, 0.0, 3.0), (0.0, 0.0, -1.0), 40.0, W, H, 5.0, 0.0)
+    scene = SH.BuiltScene([sheet, light], [(0, 0, SH.IDENTITY), (1, 1, SH.IDENTITY)], materials=mats, camera=cam,
+                          settings=O.make_settings(use_mis=True, path_length=4, background=(0, 0, 0), background_intensity=0.0))
+    scene.lights = SH.mesh_lights(scene.instances, scene.materials)
+    for rng_mode, compact_mode in ((pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST), (pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED)):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(rng_mode, compact_mode, pod.CONDUCTOR_REFERENCE)
+        got = _render_gpu(ctx, 3)
+        _, want = _render_oracle(scene, W * H, 3, rng_mode, pod.CONDUCTOR_REFERENCE)
+        for f in range(3):
+            assert want[f].max() > 0.5
+            assert SH.image_agreement(got[f], want[f], PIXEL_TOL) >= 0.999, (rng_mode, f, SH.image_agreement(got[f], want[f], PIXEL_TOL))
