@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock) logic_k
                 S->radiance[pixelIdx] = r;
                 if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
             }
-            if (survived) S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
+            // (at bounce 1 every hit survives with throughput 1 and the material kernels use that constant instead of reading
+            //  it back: the store would be dead — except for a pass-through, which the material kernel then covers)
+            if (survived && bounce != 1) S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
         }
         const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
         int slot[4];
@@ -601,6 +603,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             if (updatePath) {
                 S->rayOrigin[pixelIdx] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
                 S->throughputPdf[pixelIdx] = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
+            } else if (bounce == 1) {
+                S->throughputPdf[pixelIdx] = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);  // pass-through at the first hit: what the logic kernel did not store
             }
         }
     }
