@@ -21,6 +21,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "nexus_pod.h"
@@ -50,6 +51,9 @@ constexpr int kNodeStride = NX_NODE_STRIDE;
 constexpr int kTriStride = NX_TRI_STRIDE;
 
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with its own L2
+constexpr int kMaterialTypeOffset = 56;  // nx_material::type (int8) and, in the device copy only, a derived flag in the
+constexpr int kMaterialFlagOffset = 57;  // padding byte behind it (nxhip_set_materials)
+static_assert(sizeof(nx_material) == 60 && offsetof(nx_material, type) == kMaterialTypeOffset, "nx_material layout");
 constexpr int kEnvGuide = 64;   // buckets of the environment sampler's cdf search guides
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;

@@ -172,12 +172,8 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         const f3 origin = camPos + offset;
         const f3 direction = normalize3((((llc + vpX * x) + vpY * y) - camPos) - offset);
         // the path's radiance starts at zero here (a coalesced 16-byte store) so that the first hit adds to it only when it
-        // emits, like every later one.  rayOrigin: the previous path vertex for the MIS weight of an emissive hit — read from
-        // bounce 2 on, normally after the bounce-1 material kernel has replaced it, but a bounce-1 pass-through (opacity,
-        // texture alpha) leaves the path state as it is and the camera origin is then what the reference uses
-        // (test_pass_through_at_the_first_hit_keeps_the_camera_origin_for_mis).
+        // emits, like every later one.  (The path's previous vertex is kept by the logic step: keep_previous_vertex.)
         S->radiance[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        S->rayOrigin[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
         // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
         // reading them back, and the logic kernel stores them for every path that survives its first hit
         S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
@@ -267,8 +263,9 @@ NXD uint32_t nee_light_count(const DeviceState* S) { return S->lightCount + ((S-
 // throughput divided by it in `throughputOut` — and is shaded as the returned material type, or ends (-1).
 template <class HitInst>
 NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame, const uint32_t seedSlot, const uint32_t pixelIdx, const float hitT, const f3 dir,
-                   const float4 tp, HitInst hitInst, bool& miss, f3& bg, bool& survived, f3& throughputOut, uint32_t& inst)
+                   const float4 tp, HitInst hitInst, bool& miss, f3& bg, bool& survived, f3& throughputOut, uint32_t& inst, bool& needsPrevVertex)
 {
+    needsPrevVertex = false;
     const f3 throughput = mk3(tp.x, tp.y, tp.z);
     int type = -1;
     miss = false;
@@ -289,11 +286,26 @@ NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame,
             throughputOut = throughput / probability;
             inst = hitInst();
             const int materialId = S->instances[inst].materialId;
-            type = S->materials[materialId].type;
+            // type and, behind it, the flag nxhip_set_materials derived: the material can emit (an emissive hit weighs itself
+            // against the light sampler by the distance from the path's previous vertex) or let a path pass through (which
+            // keeps the path state, PathTracer.cu:372-386) — see keep_previous_vertex below
+            const uint32_t typeAndFlag = *(const NX_G uint32_t*)((const NX_G char*)&S->materials[materialId] + kMaterialTypeOffset);
+            type = (int)(int8_t)(typeAndFlag & 0xffu);
             if (type < 0 || type > 3) type = -1;
+            needsPrevVertex = ((typeAndFlag >> 8) & 1u) != 0u;
         }
     }
     return type;
+}
+
+// The previous vertex of a path (D_PathStateSOA::rayOrigin, PathTracer.cuh:19-30) is the origin of its last SAMPLED ray.  The
+// material kernels used to store it per path and bounce (a scattered 16-byte store each: 7 % of their time) although it is
+// read only by the rare emissive hit under MIS.  Now the logic step stores it, and only for hits that can need it: the
+// origin of the ray that produced the hit — unless that ray was a pass-through continuation (flagged in the ray's w), whose
+// predecessor hit a pass-through-capable material and therefore stored the right vertex itself.  Same values as before.
+NXD void keep_previous_vertex(const DeviceState* S, const uint32_t pixelIdx, const float4 rayOrigin)
+{
+    if (rayOrigin.w == 0.0f) S->rayOrigin[pixelIdx] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
 }
 
 template <bool ORDERED>
@@ -324,9 +336,11 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
             dirPix = S->trace.rayD[index];
             pixelIdx = __float_as_uint(dirPix.w);
             const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
-            bool miss, survived;
+            bool miss, survived, needsPrevVertex;
             f3 bg = mk3(0.0f), t = mk3(0.0f);
-            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[index]; }, miss, bg, survived, t, inst);
+            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[index]; }, miss, bg, survived, t, inst,
+                              needsPrevVertex);
+            if (needsPrevVertex) keep_previous_vertex(S, pixelIdx, S->trace.rayO[index]);
             if (miss) {
                 float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
                 r.x += bg.x; r.y += bg.y; r.z += bg.z;
@@ -603,10 +617,10 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             S->shadow.radiance[shadowSlot] = make_float4(sh.radiance.x, sh.radiance.y, sh.radiance.z, 0.0f);
         }
         if (wantTrace) {
-            S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
+            // w: 1 for a pass-through continuation (the path's previous vertex stays what it was: keep_previous_vertex)
+            S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, updatePath ? 0.0f : 1.0f);
             S->trace.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
             if (updatePath) {
-                S->rayOrigin[pixelIdx] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, 0.0f);
                 S->throughputPdf[pixelIdx] = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
             } else if (bounce == 1) {
                 S->throughputPdf[pixelIdx] = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);  // pass-through at the first hit: what the logic kernel did not store
@@ -668,7 +682,10 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
                 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
                 hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
                 tp = S->throughputPdf[pixelIdx];
-                ro = S->rayOrigin[pixelIdx];
+                // the path's previous vertex: the origin of the ray that produced this hit, or, after a pass-through, what
+                // the logic step of the pass-through surface kept
+                ro = S->trace.rayO[index];
+                if (ro.w != 0.0f) ro = S->rayOrigin[pixelIdx];
                 rad = S->radiance[pixelIdx];
                 bounce = firstBounce;
                 alive = true;
@@ -680,9 +697,9 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
         // ---- logic and shade of every live path at its own bounce
         int type = -1;
         if (alive) {
-            bool miss, survived;
+            bool miss, survived, needsPrevVertex;
             f3 bg = mk3(0.0f), t = mk3(0.0f);
-            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hitT, dir, tp, [&]() { return inst; }, miss, bg, survived, t, inst);
+            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hitT, dir, tp, [&]() { return inst; }, miss, bg, survived, t, inst, needsPrevVertex);
             if (miss) { rad.x += bg.x; rad.y += bg.y; rad.z += bg.z; dirty = true; }
             if (survived) { tp.x = t.x; tp.y = t.y; tp.z = t.z; }
             if (type < 0) alive = false;

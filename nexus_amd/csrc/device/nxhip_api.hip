@@ -725,8 +725,17 @@ try {
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     NX_ALLOC(c->materials, (size_t)count * sizeof(nx_material));
-    NX_HIP(hipMemcpy(c->materials.p, materials, (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
     c->hostMaterials.assign(materials, materials + count);
+    // The device copy carries one derived flag in the padding byte behind `type` (offset 57 of the 60-byte record): the
+    // material can emit or let a path pass through, i.e. its shading may look at / must keep the path's previous vertex
+    // (nx_wavefront.hip keep_previous_vertex).  The logic kernel reads type and flag with the one load it already does.
+    std::vector<nx_material> dev(materials, materials + count);
+    for (nx_material& m : dev) {
+        const bool flag = m.emissiveMapId != -1 || m.diffuseMapId != -1 || m.opacity < 1.0f ||
+                          std::max(std::max(m.emissive[0], m.emissive[1]), m.emissive[2]) * m.intensity > 0.0f;
+        reinterpret_cast<unsigned char*>(&m)[kMaterialFlagOffset] = flag ? 1u : 0u;
+    }
+    NX_HIP(hipMemcpy(c->materials.p, dev.data(), (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
     c->h.materials = c->materials.as<nx_material>();
     c->stateDirty = true;
     return NXHIP_OK;
