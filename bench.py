@@ -127,11 +127,40 @@ def cpu_baseline(sc, width, height, threads, frames, single_core=True):
     return out
 
 
-def main():
-    # A run that stops making progress (a hung device call) dumps every thread's Python stack to stderr and exits (status 1)
-    # instead of sitting silently until somebody's timeout kills it: the traceback says which call never returned.
+_T0 = time.time()
+_WATCHDOG_S = float(os.environ.get("NX_BENCH_WATCHDOG", "150"))
+
+
+def stamp(phase):
+    """One line per phase on stderr, and the watchdog re-armed for the next one.  A run that stops making progress (a hung
+    device call, a runtime that never comes up) then leaves the name of the last phase it reached behind, and after
+    NX_BENCH_WATCHDOG seconds (default 150: below the 200-300 s `timeout` of the sweep scripts and of one bench run inside a
+    gpurun call) every thread's Python stack, instead of dying silently with both streams empty."""
     import faulthandler
-    faulthandler.dump_traceback_later(float(os.environ.get("NX_BENCH_WATCHDOG", "1500")), exit=True)
+
+    sys.stderr.write("[bench %7.2f s] %s\n" % (time.time() - _T0, phase))
+    sys.stderr.flush()
+    faulthandler.dump_traceback_later(_WATCHDOG_S, exit=True)
+
+
+def plan_schedule(steps, cap, passes_in_flight, explicit_pass_size, share):
+    """Pass size S and passes in flight R for a timed region of `steps` frames.  `cap`: the largest pass (frames), `share`: the
+    fraction of the image this process renders (1 / ranks).  A region shorter than a few full passes is cut into enough
+    passes to have several in flight — their drains overlap — instead of collapsing to one (the driver's 20-frame region:
+    one 20-frame pass 1 530, five 4-frame passes 1 590 Msamples/s before this round's kernel changes)."""
+    split_into = 5
+    if explicit_pass_size:
+        S = max(1, min(cap, steps))
+    else:
+        S = max(1, min(cap, -(-steps // split_into)))
+    n_passes = -(-steps // S)
+    small = S * share <= 4.0
+    R = passes_in_flight if passes_in_flight else (6 if small else 4)
+    return S, max(1, min(R, 8, n_passes)), n_passes
+
+
+def main():
+    stamp("start")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="frames timed per repetition (default 512; --config 5: 64)")
@@ -152,6 +181,13 @@ def main():
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--device-bvh", action="store_true", help="build the BLASes on the GPU (nxhip_build_blas, LBVH) instead of uploading the host SAH builder's: "
                                                               "a faster build, a tree of lower quality; not the metric's configuration")
+    ap.add_argument("--pass-sizes", type=str, default="", help="experiment: explicit pass sizes of the timed region, e.g. 8,6,4,2 (must sum to --steps)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0,
+                    help="N: after the full-frame measurement, render rank 0's share of an N-way tile split (same tiles, pass sizes and passes in flight as a "
+                         "rank of bench.py --gpus N, no collective) in this process and report per_rank_ms beside full_ms / N: the communication-free "
+                         "scaling efficiency a 1-GPU box can measure")
+    ap.add_argument("--from-obj", action="store_true", help="config 2: write the mesh as a Wavefront .obj, read it back with the product's OBJLoader and assert that "
+                                                            "the triangles equal the in-memory ones (untimed; configs[1] says 'single 1M-triangle .obj mesh')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -162,7 +198,6 @@ def main():
     args.path_length = args.path_length or (16 if big else 8)
     args.steps = args.steps if args.steps is not None else (64 if big else 512)
     args.warmup = args.warmup if args.warmup is not None else (16 if big else 64)
-    args.frames_per_pass = args.frames_per_pass or (16 if big else 64)
 
     # stdout carries exactly one line, the JSON: libraries that print banners to stdout (RCCL does at init) are sent to stderr
     json_fd = os.dup(1)
@@ -189,20 +224,33 @@ def main():
     W, H = args.width, args.height
     if args.steps < 1 or args.warmup < 0 or args.reps < 1:
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
-    S = max(1, min(args.frames_per_pass * world, 512, args.steps))
-    n_passes = (args.steps + S - 1) // S
-    R = args.passes_in_flight if args.passes_in_flight else (6 if S <= 4 else 4)   # measured (sweep in DESIGN.md section 6): 1 frame per pass 418 -> 904 at 6, 20 frames 1 344 -> 1 596 at 4
-    R = max(1, min(R, 8, n_passes))  # a timed region of fewer passes than that has nothing to overlap with
-    if R > 1:
+    explicit_fpp = args.frames_per_pass is not None
+    cap = max(1, min((args.frames_per_pass or (16 if big else 64)) * world, 512))
+    S, R, n_passes = plan_schedule(args.steps, cap, args.passes_in_flight, explicit_fpp, 1.0 / world)
+    pass_sizes = [int(x) for x in args.pass_sizes.split(",")] if args.pass_sizes else None
+    if pass_sizes:
+        if sum(pass_sizes) != args.steps or min(pass_sizes) < 1:
+            raise SystemExit("--pass-sizes must be positive and sum to --steps")
+        S = max(pass_sizes)
+        R = max(1, min(args.passes_in_flight or R, 8, len(pass_sizes)))
+    if R > 1 or args.emulate_rank_of > 1:
         # concurrent passes need a hardware queue per stream and graph branch; the HIP runtime's default of 4 serialises them.
         # Must be in the environment before the process first touches HIP (nothing has yet).
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
-    def schedule(frames):
+    def schedule(frames, size=None):
         """pass sizes that render exactly `frames` frames"""
-        return [S] * (frames // S) + ([frames % S] if frames % S else [])
+        size = size or S
+        if pass_sizes and frames == args.steps and size == S:
+            return list(pass_sizes)
+        return [size] * (frames // size) + ([frames % size] if frames % size else [])
 
     sc, workload_name, t_build = build_workload(args)
+    stamp("scene built on the host (%.1f s)" % t_build)
+    obj_check = None
+    if args.from_obj:
+        obj_check = workloads.check_obj_round_trip(sc)
+        stamp("mesh written as .obj, read back by OBJLoader and compared")
     if os.environ.get("NX_BENCH_NO_MIS"):  # experiment only: how much of the shade kernels is next-event estimation
         sc.settings["useMIS"] = 0
         workload_name += " [useMIS off: experiment]"
@@ -235,7 +283,9 @@ def main():
         ctx = capi.Context(W, H, device=dev, stream=side.cuda_stream)
     else:
         ctx = capi.Context(W, H, device=0)
+    stamp("device context created")
     upload(ctx, sc, device_bvh=args.device_bvh)
+    stamp("scene uploaded")
 
     if dist_mode:
         pm = tile_pixel_map(W, H, rank, world)
@@ -309,30 +359,66 @@ def main():
         def sync():
             ctx.sync()
 
-    if R > 1:
-        # untimed: let every slot build its graph instance and touch its queues once, then start the image over
-        for _ in range(R):
-            step(1)
-        sync()
-        ctx.reset_frame_number()
-    # one step = one frame; a pass renders up to S frames
-    for n in schedule(args.warmup):
-        step(n)
-    sync()
-    rep_s = []
-    for _ in range(args.reps):
-        sync()
-        t0 = time.perf_counter()
-        for n in schedule(args.steps):
+    def measure(steps, warmup, reps, size, label):
+        """`reps` timed regions of exactly `steps` frames (pass sizes: schedule(steps, size)), after `warmup` untimed frames in
+        passes of the same sizes — so that every slot has instantiated the graph the timed passes replay (a pass of another size
+        class would be a different graph: nxhip keeps one instance per shape) and touched its queues."""
+        if R > 1:
+            for n in schedule(max(warmup, 1), size)[:1] * R:  # every slot once, at the timed pass size
+                step(n)
+            sync()
+            ctx.reset_frame_number()
+        for n in schedule(warmup, size):
             step(n)
         sync()
-        elapsed = time.perf_counter() - t0
-        if dist_mode:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        rep_s.append(elapsed)
+        stamp("%s: warm-up done (%d frames)" % (label, warmup))
+        out = []
+        for k in range(reps):
+            sync()
+            t0 = time.perf_counter()
+            for n in schedule(steps, size):
+                step(n)
+            sync()
+            dt = time.perf_counter() - t0
+            if dist_mode:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            out.append(dt)
+            stamp("%s: repetition %d of %d: %.3f ms" % (label, k + 1, reps, dt * 1e3))
+        return out
+
+    # one step = one frame; a pass renders up to S frames
+    rep_s = measure(args.steps, args.warmup, args.reps, S, "timed region")
     elapsed = statistics.median(rep_s)
+
+    emulated = None
+    if args.emulate_rank_of > 1 and not dist_mode:
+        # Rank 0's share of an N-way split, as bench.py --gpus N would give it to a rank: its tiles, the pass plan of a rank,
+        # no collective.  per_rank_ms against full_ms / N is the scaling efficiency before communication.
+        N = args.emulate_rank_of
+        pm = tile_pixel_map(W, H, 0, N)
+        if args.pixel_order == "tiles":
+            pm = multigpu.tiled_order(pm, W)
+        capN = max(1, min((args.frames_per_pass or (16 if big else 64)) * N, 512))
+        S_full, R_full = S, R
+        S, R, _ = plan_schedule(args.steps, capN, args.passes_in_flight, explicit_fpp, 1.0 / N)
+        sync()
+        ctx.set_pixel_map(pm)
+        ctx.set_frames_per_pass(S)
+        ctx.set_passes_in_flight(max(R, 1))
+        rank_s = measure(args.steps, args.warmup, args.reps, S, "rank 0 of %d" % N)
+        per_rank = statistics.median(rank_s)
+        emulated = {"ranks": N, "local_pixels": int(len(pm)), "frames_per_pass": S, "passes_in_flight": R,
+                    "per_rank_ms": round(per_rank * 1e3, 3), "full_ms": round(elapsed * 1e3, 3), "ideal_ms": round(elapsed * 1e3 / N, 3),
+                    "efficiency_without_communication": round(elapsed / N / per_rank, 4),
+                    "msamples_per_s_if_all_ranks_matched": round(W * H * args.steps / per_rank / 1e6, 1), "rep_ms": [round(x * 1e3, 3) for x in rank_s]}
+        # back to the full frame for the roofline section below
+        S, R = S_full, R_full
+        sync()
+        ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W) if args.pixel_order == "tiles" else None)
+        ctx.set_frames_per_pass(S)
+        ctx.set_passes_in_flight(max(R, 1))
 
     value = W * H * args.steps / elapsed / 1e6
     out = {
@@ -355,12 +441,19 @@ def main():
             "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order,
             "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
+            "pass_sizes": schedule(args.steps),
             "host_scene_build_s": round(t_build, 2), "blas_builder": "device LBVH (nxhip_build_blas)" if args.device_bvh else "host binned-SAH + SAH-DP collapse (the reference's algorithm)",
         },
     }
 
+    if emulated:
+        out["emulated_rank"] = emulated
+    if obj_check:
+        out["config"]["obj_round_trip"] = obj_check
+
     # ---- roofline of the dominant kernel (closest-hit trace), rank 0 / single GPU only
     if rank == 0 and not dist_mode and not args.no_roofline:
+        stamp("roofline: counting variant + in-graph kernel timing")
         if ctx.frames_per_pass != S:
             ctx.set_frames_per_pass(S)
         passes = max(1, min(args.steps // S, 4))
@@ -455,6 +548,7 @@ def main():
 
     if rank == 0 and not dist_mode and not args.no_cpu_baseline:
         # a 1-GPU box's CPU share is 16 hardware threads
+        stamp("cpu baseline (oracle on the host cores)")
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         cb = cpu_baseline(sc, W, H, threads, 1 if big else 4, single_core=not big)
         cb["value"] = round(cb["value"], 4)
@@ -475,6 +569,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    stamp("done")
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
     if dist_mode:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,8 @@ enum {
     NXHIP_OK = 0,
     NXHIP_ERR_INVALID = 1, /* bad argument / state */
     NXHIP_ERR_HIP = 2,     /* a HIP runtime call failed */
-    NXHIP_ERR_NO_DEVICE = 3
+    NXHIP_ERR_NO_DEVICE = 3,
+    NXHIP_ERR_TRAVERSAL = 4 /* a trace kernel gave up on rays that made no progress (malformed BVH): reported by nxhip_sync and the read-backs */
 };
 
 /* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
@@ -227,6 +228,12 @@ int nxhip_get_selected_instance(nxhip_ctx *ctx, int32_t *instanceIdx);
 int nxhip_trace_batch(nxhip_ctx *ctx, const nx_ray *rays, uint32_t count, nx_hit *hits);
 /* TraceShadowKernel's any-hit test — BVH8Traversal.cuh:326-518.  occluded[i] = 1 if blocked within tmax[i]. */
 int nxhip_trace_shadow_batch(nxhip_ctx *ctx, const nx_ray *rays, const float *tmax, uint32_t count, uint8_t *occluded);
+
+/* Test hook: overwrite ONE node of an uploaded BLAS in device memory WITHOUT the checks of nxhip_upload_blas.  Exists so that
+ * the trace kernels' behaviour on a BVH that is not a tree (a child that points back at its parent) can be tested: they must
+ * abandon such rays and nxhip_sync must report NXHIP_ERR_TRAVERSAL (nx_device.h kStallLimit) instead of never returning.
+ * The node's child / leaf ranges must still lie inside the BLAS (that part is checked: a wild index is a wild device read). */
+int nxhip_debug_write_blas_node(nxhip_ctx *ctx, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node *node);
 
 /* Kernel-level test hooks for the shading functions (same role as nxhip_trace_batch for the traversal): run the device
  * BSDF sample / eval (the headers of Cuda/BSDF/ as restated in nx_bsdf.h) and the software texture fetch on host arrays.

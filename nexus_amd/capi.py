@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_has_gfx950_code",
+    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
@@ -495,6 +495,12 @@ class Context:
         idx = np.zeros(tri_count, dtype=np.uint32)
         check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
         return nodes, idx
+
+    def debug_write_blas_node(self, blas_id, node_idx, node):
+        """test hook: overwrite one node of an uploaded BLAS without the upload checks"""
+        node = np.ascontiguousarray(node, dtype=pod.NODE_DT).reshape(1)
+        self.L.nxhip_debug_write_blas_node.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
+        check(self.L.nxhip_debug_write_blas_node(self.h, blas_id, node_idx, _ptr(node)), "nxhip_debug_write_blas_node")
 
     def set_instance_transforms(self, instance_ids, transforms16):
         """move existing instances on the device (inverse, bounds, traversal records, TLAS refit): no scene re-upload"""

@@ -78,12 +78,16 @@ struct PassSlot {
     DevBuf mqHit[4], mqDirInst[4];
     DevBuf counters, frame, dState;
     size_t pathCapacity = 0;  // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graphExec = nullptr;
-    bool graphValid = false;
-    bool graphSerialShade = false;  // the shape the graph was built with (see serial_shade, trace_blocks)
-    int graphTraceBlocks = 0;
-    int graphTailBounce = 0;
+    // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in
+    // nxhip_api.hip: a small pass, a large pass and a pass among several in flight are different graphs).  A pass of another
+    // size class replays the instance built for that class instead of re-instantiating one inside the frame loop.
+    struct GraphInstance {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool serialShade = false;
+        int traceBlocks = 0, tailBounce = 0;
+    };
+    std::vector<GraphInstance> graphs;
     // pass bookkeeping (slots >= 1 and slot 0 alike)
     hipEvent_t done = nullptr, accumulated = nullptr;
     bool awaitingAccumulate = false;   // holds a rendered pass that nxhip_accumulate has not consumed yet
@@ -152,6 +156,8 @@ struct nxhip_ctx : nxd::PassSlot {
     bool mgpuOwnsComm = false;
     int mgpuWorld = 1, mgpuRank = 0;
     uint32_t mgpuTileRows = 0;
+    uint64_t pixelSetGeneration = 0;  // bumped whenever the context's pixel set changes (alloc_paths: resize, pixel map)
+    uint64_t mgpuPixelSet = 0;        // the generation the tile split was set up for (nxhip_mgpu_gather refuses another)
     nxd::DevBuf mgpuGathered, mgpuMaps, mgpuFullAccum, mgpuFullRgba8;
 
     int traceBlocks = 0, shadowBlocks = 0, wideBlocks = 0;  // full-chip persistent grids (see trace_blocks)

@@ -75,9 +75,23 @@ struct __attribute__((aligned(16))) InstTrav {
     const NX_G uint4* nodes;
     const NX_G float4* isect;
     uint32_t instIdx;
-    uint32_t pad_[3];
+    uint32_t flags;     // kInstIdentity: the inverse transform's first three rows are exactly those of the identity matrix
+    uint32_t pad_[2];
     uint4 root[5];      // a copy of the BLAS's root node: entering the instance and testing its root are one loop iteration
 };
+constexpr uint32_t kInstIdentity = 1u;
+constexpr uint32_t kSceneAllIdentity = 1u;  // DeviceState::sceneFlags
+// rows 0..2 of a row-major 4x4 matrix equal the identity's bit for bit (+0.0 and 1.0 exactly; -0.0 does not count)
+inline __host__ __device__ bool rows_are_identity(const float* m)
+{
+    bool same = true;
+    for (int i = 0; i < 12; i++) {
+        union { float f; uint32_t u; } v;
+        v.f = m[i];
+        same = same && v.u == ((i % 5 == 0) ? 0x3f800000u : 0u);
+    }
+    return same;
+}
 static_assert(sizeof(InstTrav) == 160, "InstTrav layout");
 
 struct TextureDev {
@@ -119,8 +133,15 @@ struct FrameState {
     uint32_t frameNumber;
     int32_t pixelQueryPixel;     // -1: none (D_PixelQuery, PathTracer.cuh:54-58)
     int32_t pixelQueryInstance;
-    uint32_t pad_;
+    uint32_t errorWord;          // kErrTraversalStalled: set by a trace kernel that abandoned rays (see kStallLimit), read and cleared by nxhip_sync
 };
+constexpr uint32_t kErrTraversalStalled = 1u;
+// A wave of a trace kernel that has run this many loop iterations (about a second) without a single one of its rays finishing gives up on them:
+// the rays end as misses / unoccluded, the error word is set and nxhip_sync reports NXHIP_ERR_TRAVERSAL.  A ray of a well-formed
+// tree visits every record at most once, so the bound is far above anything legitimate (the longest rays of the 10 M-triangle
+// scene take a few thousand iterations); it exists so that a BVH that is not a tree — which the upload checks reject, but a
+// device-side builder's output never passes through them — ends in an error status instead of a kernel that never returns.
+constexpr uint32_t kStallLimit = 1u << 20;
 
 struct TraceStatsDev {
     unsigned long long rays, nodes, tris, instances;
@@ -147,6 +168,7 @@ struct DeviceState {
     TextureDev hdrMap;     // texels == nullptr: flat background
     uint32_t lightCount;
     uint32_t instanceCount;
+    uint32_t sceneFlags;   // kSceneAllIdentity: every instance record carries kInstIdentity (the trace kernels then skip the transform rows)
     nx_camera camera;
     nx_render_settings settings;
     int32_t rngMode, compactMode, conductorMode;

@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
         t->r0 = make_float4(inv[0], inv[1], inv[2], inv[3]);
         t->r1 = make_float4(inv[4], inv[5], inv[6], inv[7]);
         t->r2 = make_float4(inv[8], inv[9], inv[10], inv[11]);
+        t->flags = rows_are_identity(inv) ? kInstIdentity : 0u;
     }
 }
 

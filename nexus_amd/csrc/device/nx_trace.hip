@@ -66,6 +66,11 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
     GU4 tlasNodes = S->tlasNodes;
     const NX_G InstTrav* instTrav = S->instTrav;
+#ifdef NX_NO_SCENE_FLAG
+    const bool sceneIdentity = false;
+#else
+    const bool sceneIdentity = (S->sceneFlags & kSceneAllIdentity) != 0u;  // wave-uniform: no instance of the scene transforms a ray
+#endif
 
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -212,6 +217,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
         unsigned long long activeMask = __ballot(active);
         NX_STAMP(0);
         if (activeMask == 0ull) break;
+        uint32_t stalled = 0u;           // iterations since a ray of this wave last finished (wave-uniform: scalar registers)
+        int busy = __popcll(activeMask);
 
         // ---- traverse until too many lanes have run out of work
         do {
@@ -277,30 +284,20 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             // 259-266 then :180 — no other record of the ray lies between them), which saves one iteration per instance
             // visit and puts the lane into the node block that runs for the other lanes anyway.
             uint4 rc[5];
-            uint4 ri[4];
-            uint32_t riInst = 0u;
-            if (wantInst) {
-                GU4 p = (GU4)recAddr;
-                ri[0] = p[0]; ri[1] = p[1]; ri[2] = p[2]; ri[3] = p[3];
-                riInst = *(const NX_G uint32_t*)(p + 4);
-            }
+            InstFetch fi;
+            if (wantInst) fetch_instance(recAddr, sceneIdentity, fi);
             fetch_record(wantNode || wantInst, wantTri, recAddr + (wantInst ? 80ull : 0ull), rc);
             NX_STAMP(2);
             if (wantInst) {
-                const float4 r0 = make_float4(__uint_as_float(ri[0].x), __uint_as_float(ri[0].y), __uint_as_float(ri[0].z), __uint_as_float(ri[0].w));
-                const float4 r1 = make_float4(__uint_as_float(ri[1].x), __uint_as_float(ri[1].y), __uint_as_float(ri[1].z), __uint_as_float(ri[1].w));
-                const float4 r2 = make_float4(__uint_as_float(ri[2].x), __uint_as_float(ri[2].y), __uint_as_float(ri[2].z), __uint_as_float(ri[2].w));
-                nodes = (GU4)(((unsigned long long)ri[3].y << 32) | ri[3].x);
-                isect = (GF4)(((unsigned long long)ri[3].w << 32) | ri[3].z);
-                instIdx = riInst;
+                nodes = fi.nodes();
+                isect = fi.isect();
+                instIdx = fi.idFlags.x;
                 // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
-                // A transform that maps this ray onto itself bit for bit (in practice: the identity) leaves 1/dir as it
-                // is, so the three divisions here and the reload + three divisions on exit are skipped.  Compared as bit
-                // patterns: a zero component whose sign the transform flips (-0 -> +0) counts as changed.
-                const f3 o2 = mat_point(r0, r1, r2, org);
-                const f3 d2 = mat_vec(r0, r1, r2, dir);
-                xformed = ((__float_as_uint(o2.x) ^ __float_as_uint(org.x)) | (__float_as_uint(o2.y) ^ __float_as_uint(org.y)) | (__float_as_uint(o2.z) ^ __float_as_uint(org.z)) |
-                           (__float_as_uint(d2.x) ^ __float_as_uint(dir.x)) | (__float_as_uint(d2.y) ^ __float_as_uint(dir.y)) | (__float_as_uint(d2.z) ^ __float_as_uint(dir.z))) != 0u;
+                // A transform that maps this ray onto itself bit for bit leaves 1/dir as it is, so the three divisions here and
+                // the reload + three divisions on exit are skipped; an instance flagged as carrying the identity does not even
+                // compute the transform (enter_instance).
+                f3 o2, d2;
+                xformed = enter_instance(fi, sceneIdentity, org, dir, o2, d2);
                 if (xformed) {
                     float* w = &ldsWorld[threadIdx.x];
                     w[0 * kTraceBlock] = org.x; w[1 * kTraceBlock] = org.y; w[2 * kTraceBlock] = org.z;
@@ -362,6 +359,22 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             }
 #endif
             activeMask = __ballot(active);
+#ifndef NX_NO_STALL_GUARD
+            {
+                const int nowBusy = __popcll(activeMask);
+                stalled = nowBusy < busy ? 0u : stalled + 1u;
+                busy = nowBusy;
+                if (stalled > kStallLimit) {
+                    // no ray has finished for a million iterations: not a tree.  The wave abandons its rays (closest hit: they end
+                    // with what they found so far; any hit: as occluded), takes no more, and tells the host.
+                    if (lane == 0) atomicOr(&S->frame->errorWord, kErrTraversalStalled);
+                    if (active) { active = false; resultPending = !ANY_HIT; }
+                    activeMask = 0ull;
+                    exhausted = true;
+                    rngCur = rngEnd = 0;
+                }
+            }
+#endif
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
     }
 

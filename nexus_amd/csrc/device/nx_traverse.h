@@ -51,9 +51,59 @@ NXD uint2 stack_pop(lds_u64* lds, const uint2* spill, int& sp)
     return make_uint2(0u, 0u);
 }
 
+// Entering an instance whose inverse transform is exactly the identity (InstTrav::flags & kInstIdentity, set where the record
+// is written) leaves a ray as it is, bit for bit — unless one of its components is a zero (the transform's `+ 0 * y` terms
+// can flip the sign of a zero, and 1 / dir follows the sign), an infinity or a NaN (0 * inf), or a denormal.  Such rays are
+// rare (axis-parallel ones) and take the general path, which computes what the reference computes (BVH8Traversal.cuh:259-264);
+// all others skip the two matrix products, the six comparisons of the old "did anything change" test and the LDS parking.
+NXD bool ray_is_ordinary(f3 o, f3 d)
+{
+    constexpr int kSpecial = 0x003 | 0x004 | 0x200 | 0x020 | 0x040 | 0x010 | 0x080;  // NaN, +-inf, +-0, +-denormal
+    // (bitwise |: six v_cmp_class and five scalar ORs; the short-circuit form compiles to a chain of branches)
+    return !((int)__builtin_amdgcn_classf(o.x, kSpecial) | (int)__builtin_amdgcn_classf(o.y, kSpecial) | (int)__builtin_amdgcn_classf(o.z, kSpecial) |
+             (int)__builtin_amdgcn_classf(d.x, kSpecial) | (int)__builtin_amdgcn_classf(d.y, kSpecial) | (int)__builtin_amdgcn_classf(d.z, kSpecial));
+}
+
 NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
 NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
 NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
+
+// The part of an instance record in front of its BLAS root copy.  In a scene whose instances all carry the identity (a uniform
+// flag of the device state, DeviceState::sceneFlags) the three transform rows are not even loaded.
+struct InstFetch {
+    uint4 rows[3];
+    uint4 ptrs;
+    uint2 idFlags;  // instance id, InstTrav::flags
+    NXD GU4 nodes() const { return (GU4)(((unsigned long long)ptrs.y << 32) | ptrs.x); }
+    NXD GF4 isect() const { return (GF4)(((unsigned long long)ptrs.w << 32) | ptrs.z); }
+};
+NXD void fetch_instance(unsigned long long recAddr, bool sceneIdentity, InstFetch& f)
+{
+    GU4 p = (GU4)recAddr;
+    if (!sceneIdentity) { f.rows[0] = p[0]; f.rows[1] = p[1]; f.rows[2] = p[2]; }
+    f.ptrs = p[3];
+    f.idFlags = *(const NX_G uint2*)(p + 4);
+}
+// The ray in the instance's frame (BVH8Traversal.cuh:259-264: origin and direction through the inverse transform, not
+// renormalised).  Returns whether it differs from the incoming ray; false leaves o2 / d2 unset and the caller's ray, 1 / dir
+// and (on exit) the restore untouched.  The comparison is on bit patterns: a zero whose sign the transform flips counts.
+NXD bool enter_instance(const InstFetch& f, bool sceneIdentity, f3 org, f3 dir, f3& o2, f3& d2)
+{
+#ifndef NX_NO_IDENTITY_FLAG
+    const bool identity = sceneIdentity || (f.idFlags.y & kInstIdentity) != 0u;
+    if (identity && ray_is_ordinary(org, dir)) return false;
+#endif
+    float4 r0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (!sceneIdentity) {
+        r0 = make_float4(__uint_as_float(f.rows[0].x), __uint_as_float(f.rows[0].y), __uint_as_float(f.rows[0].z), __uint_as_float(f.rows[0].w));
+        r1 = make_float4(__uint_as_float(f.rows[1].x), __uint_as_float(f.rows[1].y), __uint_as_float(f.rows[1].z), __uint_as_float(f.rows[1].w));
+        r2 = make_float4(__uint_as_float(f.rows[2].x), __uint_as_float(f.rows[2].y), __uint_as_float(f.rows[2].z), __uint_as_float(f.rows[2].w));
+    }
+    o2 = mat_point(r0, r1, r2, org);
+    d2 = mat_vec(r0, r1, r2, dir);
+    return ((__float_as_uint(o2.x) ^ __float_as_uint(org.x)) | (__float_as_uint(o2.y) ^ __float_as_uint(org.y)) | (__float_as_uint(o2.z) ^ __float_as_uint(org.z)) |
+            (__float_as_uint(d2.x) ^ __float_as_uint(dir.x)) | (__float_as_uint(d2.y) ^ __float_as_uint(dir.y)) | (__float_as_uint(d2.z) ^ __float_as_uint(dir.z))) != 0u;
+}
 
 // ChildTrace — BVH8Traversal.cuh:55-146
 NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t invOct4, float tmaxRay, uint2& ng, uint2& tg)
@@ -113,6 +163,7 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
 {
     GU4 tlasNodes = S->tlasNodes;
     const NX_G InstTrav* instTrav = S->instTrav;
+    const bool sceneIdentity = (S->sceneFlags & kSceneAllIdentity) != 0u;
     const f3 worldOrg = org, worldDir = dir;
     uint2 stackSpill[kSpillDepth];
     int sp = 0;
@@ -129,7 +180,17 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
     uint32_t instIdx = 0;
     GU4 nodes = tlasNodes;
     GF4 isect = nullptr;
-    while (__ballot(active) != 0ull) {
+    uint32_t stalled = 0u;  // iterations since a ray of this wave last finished (see kStallLimit)
+    int busy = 64;
+    for (;;) {
+        const int nowBusy = __popcll(__ballot(active));
+        if (nowBusy == 0) break;
+        stalled = nowBusy < busy ? 0u : stalled + 1u;
+        busy = nowBusy;
+        if (stalled > kStallLimit) {
+            if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(&S->frame->errorWord, kErrTraversalStalled);
+            break;
+        }
         if (active && tg.y == 0u && (ng.y & 0xff000000u) == 0u) {
             if (sp == 0) {
                 active = false;
@@ -172,25 +233,15 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
             recAddr = (unsigned long long)(isect + (size_t)(tg.x + (uint32_t)off) * (unsigned)kTriStride);
         }
         uint4 rc[5];
-        uint4 ri[4];
-        uint32_t riInst = 0u;
-        if (wantInst) {
-            GU4 p = (GU4)recAddr;
-            ri[0] = p[0]; ri[1] = p[1]; ri[2] = p[2]; ri[3] = p[3];
-            riInst = *(const NX_G uint32_t*)(p + 4);
-        }
+        InstFetch fi;
+        if (wantInst) fetch_instance(recAddr, sceneIdentity, fi);
         fetch_record(wantNode || wantInst, wantTri, recAddr + (wantInst ? 80ull : 0ull), rc);
         if (wantInst) {
-            const float4 r0 = make_float4(__uint_as_float(ri[0].x), __uint_as_float(ri[0].y), __uint_as_float(ri[0].z), __uint_as_float(ri[0].w));
-            const float4 r1 = make_float4(__uint_as_float(ri[1].x), __uint_as_float(ri[1].y), __uint_as_float(ri[1].z), __uint_as_float(ri[1].w));
-            const float4 r2 = make_float4(__uint_as_float(ri[2].x), __uint_as_float(ri[2].y), __uint_as_float(ri[2].z), __uint_as_float(ri[2].w));
-            nodes = (GU4)(((unsigned long long)ri[3].y << 32) | ri[3].x);
-            isect = (GF4)(((unsigned long long)ri[3].w << 32) | ri[3].z);
-            instIdx = riInst;
-            const f3 o2 = mat_point(r0, r1, r2, org);
-            const f3 d2 = mat_vec(r0, r1, r2, dir);
-            xformed = ((__float_as_uint(o2.x) ^ __float_as_uint(org.x)) | (__float_as_uint(o2.y) ^ __float_as_uint(org.y)) | (__float_as_uint(o2.z) ^ __float_as_uint(org.z)) |
-                       (__float_as_uint(d2.x) ^ __float_as_uint(dir.x)) | (__float_as_uint(d2.y) ^ __float_as_uint(dir.y)) | (__float_as_uint(d2.z) ^ __float_as_uint(dir.z))) != 0u;
+            nodes = fi.nodes();
+            isect = fi.isect();
+            instIdx = fi.idFlags.x;
+            f3 o2, d2;
+            xformed = enter_instance(fi, sceneIdentity, org, dir, o2, d2);
             if (xformed) {
                 org = o2;
                 dir = d2;

@@ -118,12 +118,12 @@ static void invalidate_graph(nxhip_ctx* c)
     // under it is not allowed.  Not a hot path: settings / mode / timing changes only.
     for (uint32_t k = 0; k < slot_count(c); k++) {
         PassSlot* s = slot_at(c, k);
-        if (s->graphExec && s->stream) (void)hipStreamSynchronize(s->stream);
-        if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
-        if (s->graph) (void)hipGraphDestroy(s->graph);
-        s->graphExec = nullptr;
-        s->graph = nullptr;
-        s->graphValid = false;
+        if (!s->graphs.empty() && s->stream) (void)hipStreamSynchronize(s->stream);
+        for (auto& g : s->graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        s->graphs.clear();
     }
     for (auto& t : c->graphTimers) {
         if (t.start) (void)hipEventDestroy(t.start);
@@ -221,6 +221,7 @@ static int alloc_paths(nxhip_ctx* c, uint32_t localCount)
     NX_HIP(hipMemsetAsync(c->accumulation.p, 0, full * 16, c->stream));
     NX_HIP(hipMemsetAsync(c->rgba8.p, 0, full * 4, c->stream));
     c->localCount = localCount;
+    c->pixelSetGeneration++;
     c->pathCount = localCount * c->framesPerPass;
     DeviceState& h = c->h;
     h.localCount = localCount;
@@ -383,11 +384,34 @@ void nxhip_destroy(nxhip_ctx* c)
     delete c;
 }
 
+// After a synchronisation: did a trace kernel abandon rays (FrameState::errorWord, nx_device.h kStallLimit)?  Read and cleared,
+// slot by slot; 4 bytes each.
+static int check_device_errors(nxhip_ctx* c)
+{
+    uint32_t any = 0u;
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        uint32_t* word = &slot_at(c, k)->frame.as<FrameState>()->errorWord;
+        uint32_t w = 0u;
+        NX_HIP(hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost));
+        if (w) {
+            const uint32_t zero = 0u;
+            NX_HIP(hipMemcpy(word, &zero, 4, hipMemcpyHostToDevice));
+        }
+        any |= w;
+    }
+    if (any & kErrTraversalStalled) {
+        set_error("a trace kernel abandoned rays that made no progress for millions of iterations: the uploaded or device-built BVH is not a tree");
+        return NXHIP_ERR_TRAVERSAL;
+    }
+    return NXHIP_OK;
+}
+
 int nxhip_sync(nxhip_ctx* c)
 {
     NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
-    return NXHIP_OK;
+    return check_device_errors(c);
 }
 
 int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
@@ -446,6 +470,7 @@ static int refresh_inst_trav(nxhip_ctx* c)
     const size_t n = c->hostInstIdx.size();
     std::vector<InstTrav> trav(std::max<size_t>(1, n));
     std::memset(trav.data(), 0, trav.size() * sizeof(InstTrav));
+    bool allIdentity = n > 0;
     for (size_t k = 0; k < n; k++) {
         const uint32_t i = c->hostInstIdx[k];
         const nx_bvh_instance& inst = c->hostInstances[i];
@@ -462,12 +487,15 @@ static int refresh_inst_trav(nxhip_ctx* c)
         trav[k].nodes = b.nodes.as<uint4>();
         trav[k].isect = b.isect.as<float4>();
         trav[k].instIdx = i;
+        trav[k].flags = rows_are_identity(m) ? kInstIdentity : 0u;
+        allIdentity = allIdentity && trav[k].flags != 0u;
         for (int q = 0; q < 5; q++) trav[k].root[q] = b.root[q];
     }
     NX_SYNC_ALL(c);
     NX_ALLOC(c->instTrav, trav.size() * sizeof(InstTrav));
     NX_HIP(hipMemcpy(c->instTrav.p, trav.data(), trav.size() * sizeof(InstTrav), hipMemcpyHostToDevice));
     c->h.instTrav = c->instTrav.as<InstTrav>();
+    c->h.sceneFlags = allIdentity ? kSceneAllIdentity : 0u;
     c->stateDirty = true;
     return NXHIP_OK;
 }
@@ -492,6 +520,9 @@ try {
             }
         }
         if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_upload_blas: child index out of range");
+        // children behind their parent in the array (what every builder here and the reference's emit): the node graph then
+        // cannot contain a cycle, which the traversal would follow forever
+        if (inner && n.childBaseIdx <= i) return fail_invalid("nxhip_upload_blas: child nodes must follow their parent");
         if (prims && (uint64_t)n.triangleBaseIdx + prims > triCount) return fail_invalid("nxhip_upload_blas: leaf range out of range");
     }
     BlasHost b;
@@ -564,6 +595,30 @@ int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t 
     NX_SYNC_ALL(c);
     if (nodes) NX_HIP(hipMemcpy(nodes, b.nodes.p, (size_t)b.nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
     if (primIdx) NX_HIP(hipMemcpy(primIdx, b.triIdx.p, (size_t)b.triCount * 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node* node)
+{
+    NX_CHECK_CTX(c);
+    if (!node || blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_debug_write_blas_node: no such BLAS");
+    BlasHost& b = c->blas[(size_t)blasId];
+    if (nodeIdx >= b.nodeCount) return fail_invalid("nxhip_debug_write_blas_node: no such node");
+    int inner = 0, prims = 0;
+    for (int s = 0; s < 8; s++) {
+        if (node->imask & (1u << s)) inner++;
+        else if (node->meta[s]) prims = std::max(prims, (node->meta[s] & 0x1f) + __builtin_popcount(node->meta[s] >> 5));
+    }
+    if ((inner && (uint64_t)node->childBaseIdx + inner > b.nodeCount) || (prims && (uint64_t)node->triangleBaseIdx + prims > b.triCount))
+        return fail_invalid("nxhip_debug_write_blas_node: child or leaf range outside the BLAS");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    NX_HIP(hipMemcpy(b.nodes.as<uint4>() + (size_t)nodeIdx * kNodeStride, node, sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
+    if (nodeIdx == 0) {  // the root is also embedded in the instance records
+        std::memcpy(b.root, node, sizeof b.root);
+        b.rootKnown = true;
+        if (!c->hostInstIdx.empty()) return refresh_inst_trav(c);
+    }
     return NXHIP_OK;
 }
 
@@ -697,6 +752,20 @@ try {
     // documented guarantee — wait, the call is not on the per-frame path
     NX_SYNC_ALL(c);
     for (uint32_t i = 0; i < count; i++) std::memcpy(c->hostInstances[instanceIds[i]].transform.cell, transforms16 + 16 * (size_t)i, 64);
+    // The kernel has set each moved record's identity flag from the inverse it computed.  The scene-wide "no instance transforms
+    // a ray" flag is the host's to keep: it survives only if every new matrix is the identity itself (whose inverse, by the
+    // cofactor formula, is the identity bit for bit).
+    if (c->h.sceneFlags & kSceneAllIdentity) {
+        bool still = true;
+        for (uint32_t i = 0; i < count && still; i++) {
+            const float* m = transforms16 + 16 * (size_t)i;
+            still = rows_are_identity(m) && m[12] == 0.0f && m[13] == 0.0f && m[14] == 0.0f && m[15] == 1.0f;
+        }
+        if (!still) {
+            c->h.sceneFlags &= ~kSceneAllIdentity;
+            c->stateDirty = true;
+        }
+    }
     return NXHIP_OK;
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_set_instance_transforms: ") + e.what());
@@ -1191,21 +1260,40 @@ int launch_now(nxhip_ctx* c, Launch& l)
 
 }  // namespace
 
-// The pass graph of one slot.  Timing nodes (event records around every kernel) exist only in slot 0: kernel timing runs
-// one pass at a time.
-static int build_graph(nxhip_ctx* c, PassSlot* q)
+// The pass graph of one slot for the shape the context asks for right now, built on first use and kept (a handful of shapes
+// exist: small / large pass, passes in flight, tail kernel on or off).  Timing nodes (event records around every kernel) exist
+// only in slot 0, and only one such instance at a time: kernel timing runs one pass at a time and the events are the context's.
+constexpr size_t kMaxGraphInstances = 6;
+
+static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
 {
+    const bool serial = serial_shade(c);
+    const int blocks = trace_blocks(c, c->traceBlocks), tail = tail_bounce(c);
+    for (auto& g : q->graphs)
+        if (g.serialShade == serial && g.traceBlocks == blocks && g.tailBounce == tail) {
+            *execOut = g.exec;
+            return NXHIP_OK;
+        }
     const bool isMain = q == static_cast<PassSlot*>(c);
-    if (isMain) invalidate_graph(c);  // also drops the graphs of the other slots: they are rebuilt on their next use
-    else if (q->graphExec) {
-        (void)hipStreamSynchronize(q->stream);
-        (void)hipGraphExecDestroy(q->graphExec);
-        (void)hipGraphDestroy(q->graph);
-        q->graphExec = nullptr;
-        q->graph = nullptr;
-    }
-    NX_HIP(hipGraphCreate(&q->graph, 0));
     const bool timed = isMain && c->timingMode >= 2;  // event-record nodes around every kernel node; the DAG (and its overlap) is unchanged
+    if (timed) invalidate_graph(c);  // the timing events belong to ONE instance
+    if (q->graphs.size() >= kMaxGraphInstances) {  // (not reached by the shapes above; a bound all the same)
+        (void)hipStreamSynchronize(q->stream);
+        PassSlot::GraphInstance& old = q->graphs.front();
+        (void)hipGraphExecDestroy(old.exec);
+        (void)hipGraphDestroy(old.graph);
+        q->graphs.erase(q->graphs.begin());
+    }
+    PassSlot::GraphInstance inst;
+    inst.serialShade = serial;
+    inst.traceBlocks = blocks;
+    inst.tailBounce = tail;
+    NX_HIP(hipGraphCreate(&inst.graph, 0));
+    auto fail = [&](int rc) {
+        if (inst.exec) (void)hipGraphExecDestroy(inst.exec);
+        if (inst.graph) (void)hipGraphDestroy(inst.graph);
+        return rc;
+    };
     auto levels = frame_levels(c, q);
     std::vector<hipGraphNode_t> prev;
     for (auto& level : levels) {
@@ -1226,25 +1314,22 @@ static int build_graph(nxhip_ctx* c, PassSlot* q)
                 c->graphTimers.emplace_back();
                 KernelTimer& t = c->graphTimers.back();
                 c->graphTimerClass.push_back(l.klass);
-                NX_HIP(hipEventCreate(&t.start));
-                NX_HIP(hipEventCreate(&t.stop));
+                if (!hip_ok(hipEventCreate(&t.start), "hipEventCreate", __FILE__, __LINE__) || !hip_ok(hipEventCreate(&t.stop), "hipEventCreate", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
                 hipGraphNode_t before, after;
-                NX_HIP(hipGraphAddEventRecordNode(&before, q->graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start));
-                NX_HIP(hipGraphAddKernelNode(&node, q->graph, &before, 1, &p));
-                NX_HIP(hipGraphAddEventRecordNode(&after, q->graph, &node, 1, t.stop));
+                if (!hip_ok(hipGraphAddEventRecordNode(&before, inst.graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start), "hipGraphAddEventRecordNode", __FILE__, __LINE__) ||
+                    !hip_ok(hipGraphAddKernelNode(&node, inst.graph, &before, 1, &p), "hipGraphAddKernelNode", __FILE__, __LINE__) ||
+                    !hip_ok(hipGraphAddEventRecordNode(&after, inst.graph, &node, 1, t.stop), "hipGraphAddEventRecordNode", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
                 cur.push_back(after);
             } else {
-                NX_HIP(hipGraphAddKernelNode(&node, q->graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p));
+                if (!hip_ok(hipGraphAddKernelNode(&node, inst.graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p), "hipGraphAddKernelNode", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
                 cur.push_back(node);
             }
         }
         prev.swap(cur);
     }
-    NX_HIP(hipGraphInstantiate(&q->graphExec, q->graph, nullptr, nullptr, 0));
-    q->graphValid = true;
-    q->graphSerialShade = serial_shade(c);
-    q->graphTraceBlocks = trace_blocks(c, c->traceBlocks);
-    q->graphTailBounce = tail_bounce(c);
+    if (!hip_ok(hipGraphInstantiate(&inst.exec, inst.graph, nullptr, nullptr, 0), "hipGraphInstantiate", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
+    q->graphs.push_back(inst);
+    *execOut = inst.exec;
     return NXHIP_OK;
 }
 
@@ -1303,13 +1388,12 @@ try {
                 if (c->timerPool.size() > before) c->timerClass.push_back(l.klass);
             }
     } else {
-        // (rebuilt when the pass size crossed the small-pass threshold or the number of passes in flight changed)
-        if (!q->graphValid || q->graphSerialShade != serial_shade(c) || q->graphTraceBlocks != trace_blocks(c, c->traceBlocks) ||
-            q->graphTailBounce != tail_bounce(c)) {
-            rc = build_graph(c, q);
-            if (rc != NXHIP_OK) return rc;
-        }
-        NX_HIP(hipGraphLaunch(q->graphExec, q->stream));
+        // (one instance per shape: a pass that crosses the small-pass threshold, or a change of the passes in flight, replays
+        //  the instance of its shape — built once)
+        hipGraphExec_t exec = nullptr;
+        rc = pass_graph(c, q, &exec);
+        if (rc != NXHIP_OK) return rc;
+        NX_HIP(hipGraphLaunch(exec, q->stream));
         if (c->timingMode == 3) c->graphTimersPending = true;  // read at nxhip_read_kernel_times: the last replay only
         if (c->timingMode == 2) {
             // the graph's events are re-recorded by the next replay: read them now (timing mode is not the fast path)

@@ -40,14 +40,25 @@ Rccl& rccl()
 {
     static Rccl r;
     if (r.handle || !r.error.empty()) return r;
-    const char* names[] = {std::getenv("NX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        if (!n || !*n) continue;
+    // NX_RCCL_LIB, when set, is the only candidate (a caller that names a library does not want another one picked silently)
+    const char* forced = std::getenv("NX_RCCL_LIB");
+    const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
+    auto attempt = [&](const char* n) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
-    }
+        if (!r.handle) {
+            const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+            if (why.empty()) why = e ? e : "not found";
+        }
+    };
+    if (forced && *forced) attempt(forced);
+    else
+        for (const char* n : defaults) {
+            attempt(n);
+            if (r.handle) break;
+        }
     if (!r.handle) {
-        r.error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found") + "; set NX_RCCL_LIB";
+        r.error = std::string("cannot load RCCL (") + (forced && *forced ? forced : "librccl.so.1") + "): " + (why.empty() ? "not found" : why) + "; set NX_RCCL_LIB";
         return r;
     }
     auto sym = [&](const char* s) { return dlsym(r.handle, s); };
@@ -139,18 +150,15 @@ try {
     if (rc != NXHIP_OK) return rc;
     rc = nxhip_set_pixel_map(c, map.data(), n);
     if (rc != NXHIP_OK) return rc;
-    c->mgpuWorld = worldSize;
-    c->mgpuRank = rank;
-    c->mgpuComm = comm;
-    c->mgpuOwnsComm = ownsComm;
-    c->mgpuTileRows = tileRows;
+    // (the context is marked as split only when everything below has succeeded: a failed setup leaves no half-initialised state)
+    DevBuf gathered, maps, fullAccum, fullRgba8;
     if (rank == 0) {
         // root: the gather lands in [world][n] float4; every rank's map, so that the tiles can be scattered into the full image
         const size_t full = (size_t)c->width * c->height;
-        if (!c->mgpuGathered.alloc((size_t)worldSize * n * sizeof(float4)) || !c->mgpuMaps.alloc((size_t)worldSize * n * 4) ||
-            !c->mgpuFullAccum.alloc(full * sizeof(float4)) || !c->mgpuFullRgba8.alloc(full * 4)) return NXHIP_ERR_HIP;
-        NX_HIP(hipMemset(c->mgpuFullAccum.p, 0, full * sizeof(float4)));
-        NX_HIP(hipMemset(c->mgpuFullRgba8.p, 0, full * 4));
+        if (!gathered.alloc((size_t)worldSize * n * sizeof(float4)) || !maps.alloc((size_t)worldSize * n * 4) ||
+            !fullAccum.alloc(full * sizeof(float4)) || !fullRgba8.alloc(full * 4)) return NXHIP_ERR_HIP;
+        NX_HIP(hipMemset(fullAccum.p, 0, full * sizeof(float4)));
+        NX_HIP(hipMemset(fullRgba8.p, 0, full * 4));
         std::vector<uint32_t> all((size_t)worldSize * n);
         for (int r = 0; r < worldSize; r++) {
             uint32_t m = 0;
@@ -158,8 +166,18 @@ try {
             if (rc != NXHIP_OK) return rc;
             if (m != n) return fail(NXHIP_ERR_INVALID, "nxhip_mgpu: ranks have unequal tile sizes");
         }
-        NX_HIP(hipMemcpy(c->mgpuMaps.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        NX_HIP(hipMemcpy(maps.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
+    c->mgpuGathered = std::move(gathered);
+    c->mgpuMaps = std::move(maps);
+    c->mgpuFullAccum = std::move(fullAccum);
+    c->mgpuFullRgba8 = std::move(fullRgba8);
+    c->mgpuWorld = worldSize;
+    c->mgpuRank = rank;
+    c->mgpuComm = comm;
+    c->mgpuOwnsComm = ownsComm;
+    c->mgpuTileRows = tileRows;
+    c->mgpuPixelSet = c->pixelSetGeneration;  // the pixel set (viewport + map) the gather buffers and maps were built for
     return NXHIP_OK;
 } catch (const std::exception& e) {
     return fail(NXHIP_ERR_INVALID, std::string("nxhip_mgpu: ") + e.what());
@@ -201,6 +219,10 @@ int nxhip_mgpu_gather(nxhip_ctx* c)
 {
     if (!c) return fail(NXHIP_ERR_INVALID, "null context");
     if (!c->mgpuComm) return fail(NXHIP_ERR_INVALID, "nxhip_mgpu_gather: call nxhip_mgpu_init first");
+    // nxhip_resize / nxhip_set_pixel_map after the split was set up change localCount and drop the map: the gather buffers,
+    // the compose maps and (across ranks) the collective's element count would no longer fit
+    if (c->mgpuPixelSet != c->pixelSetGeneration)
+        return fail(NXHIP_ERR_INVALID, "nxhip_mgpu_gather: the viewport or pixel map changed after the tile split was set up (nxhip_mgpu_shutdown, then nxhip_mgpu_init again)");
     Rccl& r = rccl();
     NX_HIP(hipSetDevice(c->device));
     const uint32_t n = c->localCount;

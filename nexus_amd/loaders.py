@@ -418,3 +418,30 @@ def load_obj(path):
     out.material_diffuse_texture, out.material_emissive_texture = [-1], [-1]
     out.instances = [dict(mesh=0, material=0, position=np.zeros(3, np.float32), rotation=np.zeros(3, np.float32), scale=np.ones(3, np.float32), name=path)]
     return out
+
+
+def write_obj(path, tris):
+    """TRI_DT triangles as an indexed Wavefront .obj (v / vn / vt / f with all three indices; equal corners share one index).
+    Floats are written with 9 significant digits, which a float32 survives exactly; vt carries 1 - v because readers
+    (Assimp's aiProcess_FlipUVs in the reference, OBJLoader.cpp:213-239; `load_obj` above; the C++ reader) flip it back."""
+    t = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
+    n = len(t)
+    corners = np.zeros((n, 3, 8), np.float32)
+    for k in range(3):
+        corners[:, k, 0:3] = t["pos%d" % k]
+        corners[:, k, 3:6] = t["normal%d" % k]
+        corners[:, k, 6:8] = t["texCoord%d" % k]
+    flat = corners.reshape(n * 3, 8)
+    keys = np.ascontiguousarray(flat).view(np.dtype((np.void, 32))).reshape(-1)
+    _, first, inverse = np.unique(keys, return_index=True, return_inverse=True)
+    verts = flat[first]
+    idx = inverse.reshape(n, 3) + 1
+    with open(path, "w") as f:
+        f.write("# %d triangles, %d vertices\n" % (n, len(verts)))
+        f.write("".join("v %.9g %.9g %.9g\n" % (a, b, c) for a, b, c in verts[:, 0:3].tolist()))
+        f.write("".join("vn %.9g %.9g %.9g\n" % (a, b, c) for a, b, c in verts[:, 3:6].tolist()))
+        uv = verts[:, 6:8].copy()
+        uv[:, 1] = np.float32(1.0) - uv[:, 1]
+        f.write("".join("vt %.9g %.9g\n" % (a, b) for a, b in uv.tolist()))
+        f.write("".join("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, b, b, b, c, c, c) for a, b, c in idx.tolist()))
+    return len(verts)

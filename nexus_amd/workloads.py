@@ -209,3 +209,39 @@ def config5(width=3840, height=2160, path_length=16, field=2200, prop_nu=512, pr
              diffuse_maps=[checker_texture(256, 256, 11)], emissive_maps=[checker_texture(64, 64, 12)], build_threads=0)
     sc.lights = mesh_lights(sc.instances, sc.materials)
     return sc
+
+
+def check_obj_round_trip(sc, mesh_index=0):
+    """configs[1] speaks of a "single 1M-triangle .obj mesh": write the workload's mesh as a Wavefront .obj, read it back with
+    the product's reader (nexus::OBJLoader through nxh_load_scene_file: the route of the reference's OBJLoader::LoadOBJ,
+    Assets/OBJLoader.cpp:213-239) and require the triangles it yields to equal the in-memory ones the BVH was built from —
+    positions and normals bit for bit, texture coordinates too when the 1 - v flip is exact in float32.  Untimed."""
+    import os
+    import tempfile
+    import time
+
+    from . import loaders
+
+    mesh = sc.meshes[mesh_index]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "mesh.obj")
+        t0 = time.time()
+        n_verts = loaders.write_obj(path, mesh)
+        t_write = time.time() - t0
+        size = os.path.getsize(path)
+        t0 = time.time()
+        meshes, _mats, _insts = capi.load_scene_file(path)
+        t_read = time.time() - t0
+    if len(meshes) != 1 or len(meshes[0]) != len(mesh):
+        raise RuntimeError("obj round trip: %d meshes / %d triangles read, %d written" % (len(meshes), len(meshes[0]) if meshes else 0, len(mesh)))
+    got = meshes[0]
+    for f in ("pos0", "pos1", "pos2", "normal0", "normal1", "normal2"):
+        if not np.array_equal(got[f].view(np.uint32), mesh[f].view(np.uint32)):
+            raise RuntimeError("obj round trip: field %s differs from the in-memory mesh" % f)
+    uv_exact = all(np.array_equal(got[f].view(np.uint32), mesh[f].view(np.uint32)) for f in ("texCoord0", "texCoord1", "texCoord2"))
+    if not uv_exact:
+        worst = max(float(np.abs(got[f] - mesh[f]).max()) for f in ("texCoord0", "texCoord1", "texCoord2"))
+        if worst > 1e-6:
+            raise RuntimeError("obj round trip: texture coordinates differ by %g" % worst)
+    return {"triangles": int(len(mesh)), "vertices": int(n_verts), "file_MB": round(size / 1e6, 1), "write_s": round(t_write, 2), "read_s": round(t_read, 2),
+            "positions_normals_bit_exact": True, "texcoords_bit_exact": bool(uv_exact), "reader": "nexus::OBJLoader (nxh_load_scene_file)"}

@@ -19,6 +19,10 @@
 #include <pthread.h>
 #include "orc_shade.h"
 
+/* what one shaded path asks for: the shadow ray of its light sample, its continuation ray */
+struct sh_out { int valid; f3 origin, direction, radiance; float distance; uint32_t pixel; };
+struct tr_out { int valid; f3 origin, direction; uint32_t pixel; };
+
 struct orc_wavefront {
     const orc_scene *scene;
     uint32_t n; /* local pixel count */
@@ -44,6 +48,11 @@ struct orc_wavefront {
     uint32_t *rgba8;
     orc_trace_stats closestStats, shadowStats;
     uint32_t frameNumber;
+    /* threaded logic / shade (orc_wavefront_render with nthreads > 1): what item k of a queue produces is parked in slot k of
+     * these and appended to the output queues afterwards, in item order — the serial slot order exactly */
+    struct sh_out *tmpShadow;
+    struct tr_out *tmpTrace;
+    int8_t *tmpType;
 };
 
 static int32_t *mat_queue_size(orc_queue_sizes *q, int type)
@@ -93,6 +102,7 @@ void orc_wavefront_destroy(orc_wavefront *w)
     free(w->shOrigin); free(w->shDirection); free(w->shRadiance); free(w->shDistance); free(w->shPixel);
     for (int m = 0; m < 4; m++) { free(w->mqDirection[m]); free(w->mqHit[m]); free(w->mqPixel[m]); }
     free(w->accumulation); free(w->rgba8);
+    free(w->tmpShadow); free(w->tmpTrace); free(w->tmpType);
     free(w);
 }
 
@@ -284,42 +294,85 @@ static uint32_t seed_for(const orc_wavefront *w, uint32_t slot, uint32_t pixelId
     return orc_rng_init_index(slot, w->scene->camera.resolution[0], w->frameNumber);
 }
 
-/* LogicKernel — PathTracer.cu:136-210 */
-static void logic(orc_wavefront *w, uint32_t bounce)
+/* Ranges of a queue on worker threads (pthread per range, as trace_pass).  fn(ctx, begin, end). */
+typedef struct { void (*fn)(void *, uint32_t, uint32_t); void *ctx; uint32_t begin, end; } range_job;
+static void *range_worker(void *a) { range_job *j = (range_job *)a; j->fn(j->ctx, j->begin, j->end); return NULL; }
+static void parallel_ranges(uint32_t count, int nthreads, void (*fn)(void *, uint32_t, uint32_t), void *ctx)
+{
+    if (nthreads <= 1 || count < 4096) { fn(ctx, 0, count); return; }
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    range_job jobs[256];
+    const uint32_t chunk = (count + (uint32_t)nthreads - 1) / (uint32_t)nthreads;
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        const uint32_t b = (uint32_t)t * chunk;
+        if (b >= count) break;
+        jobs[t].fn = fn; jobs[t].ctx = ctx; jobs[t].begin = b; jobs[t].end = (b + chunk < count) ? b + chunk : count;
+        pthread_create(&th[t], NULL, range_worker, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
+/* LogicKernel — PathTracer.cu:136-210: one thread (queue item).  Returns the material queue the path goes to, -1: none. */
+static int logic_item(orc_wavefront *w, uint32_t bounce, uint32_t index)
 {
     const orc_scene *s = w->scene;
-    const uint32_t count = (uint32_t)w->q.traceSize[bounce - 1];
-    for (uint32_t index = 0; index < count; index++) {
-        const nx_hit hit = w->trHit[index];
-        const f3 dir = w->trDirection[index];
-        const uint32_t pixelIdx = w->trPixel[index];
-        uint32_t rng = seed_for(w, index, pixelIdx, bounce, 0);
-        const f3 throughput = bounce == 1 ? mk3s(1.0f) : w->throughput[pixelIdx];
+    const nx_hit hit = w->trHit[index];
+    const f3 dir = w->trDirection[index];
+    const uint32_t pixelIdx = w->trPixel[index];
+    uint32_t rng = seed_for(w, index, pixelIdx, bounce, 0);
+    const f3 throughput = bounce == 1 ? mk3s(1.0f) : w->throughput[pixelIdx];
 
-        if (hit.hitDistance == 1e30f) {
-            f3 bg = mul3(throughput, sample_background(s, dir));
-            if (s->envSampling && s->hdrMap && bounce > 1 && s->settings.useMIS) {
-                /* the NEE samples the environment too: weight the BSDF-sampled miss against it (extension) */
-                const float envPdf = env_pdf(s, dir) / (float)nee_light_count(s);
-                if (orc_pdf_valid(envPdf)) bg = scale3(bg, orc_power_heuristic(w->lastPdf[pixelIdx], envPdf));
-            }
-            if (bounce == 1) w->radiance[pixelIdx] = bg;
-            else w->radiance[pixelIdx] = add3(w->radiance[pixelIdx], bg);
-            continue;
+    if (hit.hitDistance == 1e30f) {
+        f3 bg = mul3(throughput, sample_background(s, dir));
+        if (s->envSampling && s->hdrMap && bounce > 1 && s->settings.useMIS) {
+            /* the NEE samples the environment too: weight the BSDF-sampled miss against it (extension) */
+            const float envPdf = env_pdf(s, dir) / (float)nee_light_count(s);
+            if (orc_pdf_valid(envPdf)) bg = scale3(bg, orc_power_heuristic(w->lastPdf[pixelIdx], envPdf));
         }
-        /* Russian roulette */
-        const float probability = maxcomp3(throughput);
-        if (orc_rand(&rng) < probability) w->throughput[pixelIdx] = div3s(throughput, probability);
-        else continue;
+        if (bounce == 1) w->radiance[pixelIdx] = bg;
+        else w->radiance[pixelIdx] = add3(w->radiance[pixelIdx], bg);
+        return -1;
+    }
+    /* Russian roulette */
+    const float probability = maxcomp3(throughput);
+    if (orc_rand(&rng) < probability) w->throughput[pixelIdx] = div3s(throughput, probability);
+    else return -1;
 
-        const nx_bvh_instance *inst = &s->instances[hit.instanceIdx];
-        const int type = s->materials[inst->materialId].type;
-        if (type < 0 || type > 3) continue;
+    const nx_bvh_instance *inst = &s->instances[hit.instanceIdx];
+    const int type = s->materials[inst->materialId].type;
+    if (type < 0 || type > 3) return -1;
+    return type;
+}
+
+typedef struct { orc_wavefront *w; uint32_t bounce; int type; } item_ctx;
+static void logic_range(void *a, uint32_t begin, uint32_t end)
+{
+    item_ctx *c = (item_ctx *)a;
+    for (uint32_t i = begin; i < end; i++) c->w->tmpType[i] = (int8_t)logic_item(c->w, c->bounce, i);
+}
+
+/* The kernel: items in ascending order claim their queue slots (serial semantics).  With threads the per-item work — which
+ * touches only the item's own pixel — runs on ranges first and the slots are handed out afterwards, in the same order. */
+static void logic(orc_wavefront *w, uint32_t bounce, int nthreads)
+{
+    const uint32_t count = (uint32_t)w->q.traceSize[bounce - 1];
+    const int threaded = nthreads > 1 && count >= 4096;
+    if (threaded) {
+        if (!w->tmpType) w->tmpType = (int8_t *)malloc(w->n);
+        item_ctx c = {w, bounce, 0};
+        parallel_ranges(count, nthreads, logic_range, &c);
+    }
+    for (uint32_t index = 0; index < count; index++) {
+        const int type = threaded ? w->tmpType[index] : logic_item(w, bounce, index);
+        if (type < 0) continue;
         int32_t *size = mat_queue_size(&w->q, type);
         const int32_t slot = size[bounce]++;
-        w->mqHit[type][slot] = hit;
-        w->mqDirection[type][slot] = dir;
-        w->mqPixel[type][slot] = pixelIdx;
+        w->mqHit[type][slot] = w->trHit[index];
+        w->mqDirection[type][slot] = w->trDirection[index];
+        w->mqPixel[type][slot] = w->trPixel[index];
     }
 }
 
@@ -327,8 +380,8 @@ static float tri_area(f3 p0, f3 p1, f3 p2) { return 0.5f * length3(cross3(sub3(p
 static f3 tri_normal(const nx_triangle *t) { return cross3(sub3(ld3(t->pos1), ld3(t->pos0)), sub3(ld3(t->pos2), ld3(t->pos0))); }
 
 /* NextEventEstimation — PathTracer.cu:213-308 */
-static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *material, f3 hitPoint, f3 normal,
-                f3 hitGNormal, f3 throughput, uint32_t pixelIdx, uint32_t *rng)
+static void nee(orc_wavefront *w, f3 wi, const nx_material *material, f3 hitPoint, f3 normal,
+                f3 hitGNormal, f3 throughput, uint32_t pixelIdx, uint32_t *rng, struct sh_out *out)
 {
     const orc_scene *s = w->scene;
     /* no lights: the reference indexes an empty array here (undefined); defined as "no light sample, no random numbers
@@ -349,12 +402,12 @@ static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *mat
         if (!orc_bsdf_eval_f3(material, wi, wo, &sampleThroughput, &bsdfPdf)) return;
         const float weight = orc_power_heuristic(lightPdf, bsdfPdf);
         const f3 radiance = div3s(mul3(mul3(scale3(throughput, weight), sampleThroughput), sample_background(s, shDir)), lightPdf);
-        const int32_t slot = w->q.traceShadowSize[bounce]++;
-        w->shDistance[slot] = 1e30f;
-        w->shRadiance[slot] = radiance;
-        w->shOrigin[slot] = offset_ray(hitPoint, scale3(hitGNormal, sgnE(dot3(shDir, normal))));
-        w->shDirection[slot] = shDir;
-        w->shPixel[slot] = pixelIdx;
+        out->valid = 1;
+        out->distance = 1e30f;
+        out->radiance = radiance;
+        out->origin = offset_ray(hitPoint, scale3(hitGNormal, sgnE(dot3(shDir, normal))));
+        out->direction = shDir;
+        out->pixel = pixelIdx;
         return;
     }
     const nx_light light = s->lights[pick];
@@ -406,20 +459,21 @@ static void nee(orc_wavefront *w, uint32_t bounce, f3 wi, const nx_material *mat
     } else emissive = ld3(lightMaterial->emissive);
 
     const f3 radiance = div3s(scale3(mul3(mul3(scale3(throughput, weight), sampleThroughput), emissive), lightMaterial->intensity), lightPdf);
-    const int32_t slot = w->q.traceShadowSize[bounce]++;
-    w->shDistance[slot] = distance;
-    w->shRadiance[slot] = radiance;
-    w->shOrigin[slot] = shOrigin;
-    w->shDirection[slot] = shDir;
-    w->shPixel[slot] = pixelIdx;
+    out->valid = 1;
+    out->distance = distance;
+    out->radiance = radiance;
+    out->origin = shOrigin;
+    out->direction = shDir;
+    out->pixel = pixelIdx;
 }
 
 /* Shade<BSDF> — PathTracer.cu:311-458.  `type` selects the queue and the BSDF. */
-static void shade(orc_wavefront *w, uint32_t bounce, int type)
+static void shade_item(orc_wavefront *w, uint32_t bounce, int type, int32_t requestIdx, struct sh_out *shOut, struct tr_out *trOut)
 {
     const orc_scene *s = w->scene;
-    const int32_t size = mat_queue_size(&w->q, type)[bounce];
-    for (int32_t requestIdx = 0; requestIdx < size; requestIdx++) {
+    shOut->valid = 0;
+    trOut->valid = 0;
+    {
         const nx_hit hit = w->mqHit[type][requestIdx];
         const f3 rayDirection = w->mqDirection[type][requestIdx];
         const uint32_t pixelIdx = w->mqPixel[type][requestIdx];
@@ -464,7 +518,7 @@ static void shade(orc_wavefront *w, uint32_t bounce, int type)
         if (bounce == 1) w->radiance[pixelIdx] = radiance;
         else w->radiance[pixelIdx] = add3(w->radiance[pixelIdx], radiance);
 
-        if (bounce == s->settings.pathLength) continue;
+        if (bounce == s->settings.pathLength) return;
 
         f4 color = {1.0f, 1.0f, 1.0f, 1.0f};
         if (material.diffuseMapId != -1) {
@@ -481,26 +535,67 @@ static void shade(orc_wavefront *w, uint32_t bounce, int type)
             wo = normalize3(rotate_point(invert_rotation(q), neg3(wi)));
             const float od = sgnE(dot3(wo, normal));
             const f3 origin = offset_ray(p, scale3(gNormal, od));
-            const int32_t slot = w->q.traceSize[bounce]++;
-            w->trOrigin[slot] = origin;
-            w->trDirection[slot] = wo;
-            w->trPixel[slot] = pixelIdx;
+            trOut->valid = 1;
+            trOut->origin = origin;
+            trOut->direction = wo;
+            trOut->pixel = pixelIdx;
         } else {
-            if (s->settings.useMIS) nee(w, bounce, wi, &material, p, normal, gNormal, throughput, pixelIdx, &rng);
+            if (s->settings.useMIS) nee(w, wi, &material, p, normal, gNormal, throughput, pixelIdx, &rng, shOut);
             float pdf;
             f3 sampleThroughput;
-            if (!orc_bsdf_sample_f3(&material, wi, &rng, &wo, &sampleThroughput, &pdf)) continue;
+            if (!orc_bsdf_sample_f3(&material, wi, &rng, &wo, &sampleThroughput, &pdf)) return;
             wo = normalize3(rotate_point(invert_rotation(q), wo));
             const float od = sgnE(dot3(wo, normal));
             const f3 origin = offset_ray(p, scale3(gNormal, od));
             throughput = mul3(throughput, sampleThroughput);
-            const int32_t slot = w->q.traceSize[bounce]++;
-            w->trOrigin[slot] = origin;
-            w->trDirection[slot] = wo;
-            w->trPixel[slot] = pixelIdx;
+            trOut->valid = 1;
+            trOut->origin = origin;
+            trOut->direction = wo;
+            trOut->pixel = pixelIdx;
             w->rayOrigin[pixelIdx] = origin;
             w->throughput[pixelIdx] = throughput;
             w->lastPdf[pixelIdx] = pdf;
+        }
+    }
+}
+
+static void shade_range(void *a, uint32_t begin, uint32_t end)
+{
+    item_ctx *c = (item_ctx *)a;
+    for (uint32_t i = begin; i < end; i++) shade_item(c->w, c->bounce, c->type, (int32_t)i, &c->w->tmpShadow[i], &c->w->tmpTrace[i]);
+}
+
+/* The kernel: a path's shadow request is appended before its continuation ray, paths in ascending order (see logic) */
+static void shade(orc_wavefront *w, uint32_t bounce, int type, int nthreads)
+{
+    const int32_t size = mat_queue_size(&w->q, type)[bounce];
+    const int threaded = nthreads > 1 && size >= 4096;
+    if (threaded) {
+        if (!w->tmpShadow) w->tmpShadow = (struct sh_out *)malloc((size_t)w->n * sizeof(struct sh_out));
+        if (!w->tmpTrace) w->tmpTrace = (struct tr_out *)malloc((size_t)w->n * sizeof(struct tr_out));
+        item_ctx c = {w, bounce, type};
+        parallel_ranges((uint32_t)size, nthreads, shade_range, &c);
+    }
+    for (int32_t requestIdx = 0; requestIdx < size; requestIdx++) {
+        struct sh_out shLocal;
+        struct tr_out trLocal;
+        const struct sh_out *sh = &shLocal;
+        const struct tr_out *tr = &trLocal;
+        if (threaded) { sh = &w->tmpShadow[requestIdx]; tr = &w->tmpTrace[requestIdx]; }
+        else shade_item(w, bounce, type, requestIdx, &shLocal, &trLocal);
+        if (sh->valid) {
+            const int32_t slot = w->q.traceShadowSize[bounce]++;
+            w->shDistance[slot] = sh->distance;
+            w->shRadiance[slot] = sh->radiance;
+            w->shOrigin[slot] = sh->origin;
+            w->shDirection[slot] = sh->direction;
+            w->shPixel[slot] = sh->pixel;
+        }
+        if (tr->valid) {
+            const int32_t slot = w->q.traceSize[bounce]++;
+            w->trOrigin[slot] = tr->origin;
+            w->trDirection[slot] = tr->direction;
+            w->trPixel[slot] = tr->pixel;
         }
     }
 }
@@ -513,12 +608,12 @@ void orc_wavefront_render(orc_wavefront *w, uint32_t frameNumber, int nthreads)
     generate(w);
     trace_pass(w, (uint32_t)w->q.traceSize[0], 0, nthreads);
     for (uint32_t bounce = 1; bounce <= pathLength && bounce < NX_PATH_MAX_LENGTH; bounce++) {
-        logic(w, bounce);
+        logic(w, bounce, nthreads);
         /* graph insertion order: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120) */
-        shade(w, bounce, NX_MAT_DIFFUSE);
-        shade(w, bounce, NX_MAT_PLASTIC);
-        shade(w, bounce, NX_MAT_DIELECTRIC);
-        if (w->conductorMode == NX_CONDUCTOR_EXTENDED) shade(w, bounce, NX_MAT_CONDUCTOR);
+        shade(w, bounce, NX_MAT_DIFFUSE, nthreads);
+        shade(w, bounce, NX_MAT_PLASTIC, nthreads);
+        shade(w, bounce, NX_MAT_DIELECTRIC, nthreads);
+        if (w->conductorMode == NX_CONDUCTOR_EXTENDED) shade(w, bounce, NX_MAT_CONDUCTOR, nthreads);
         trace_pass(w, (uint32_t)w->q.traceSize[bounce], 0, nthreads);
         trace_pass(w, (uint32_t)w->q.traceShadowSize[bounce], 1, nthreads);
     }

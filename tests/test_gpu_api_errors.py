@@ -173,3 +173,41 @@ def test_a_failed_queue_growth_leaves_the_context_usable(gpu_ctx_factory):
     ctx.accumulate()
     after = ctx.read_accumulation()
     assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
+
+
+def test_a_bvh_that_is_not_a_tree_ends_in_an_error_status_not_in_a_hang(gpu_ctx_factory):
+    """A node whose child range points back at itself passes no upload (nxhip_upload_blas and nxhip_set_tlas insist on
+    children behind their parent), so it is planted with the debug hook.  The trace kernels abandon the rays that go round in
+    circles after kStallLimit iterations without a retirement, nxhip_sync reports NXHIP_ERR_TRAVERSAL once, and the context
+    works again after the node is repaired."""
+    import time
+
+    import numpy as np
+    from nexus_amd import pod, scenegen
+    from tests import scene_helpers as SH
+
+    scene = SH.soup_scene(n=800, seed=3)
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    rays = np.concatenate([scenegen.random_rays(1024, seed=5, radius=5.0, target_extent=2.0), scenegen.interior_rays(1024, seed=6, extent=2.0)])
+    want = scene.oracle().trace_closest(rays)
+    assert SH.hit_records_equal(ctx.trace_batch(rays), want)
+    ctx.sync()
+    nodes, _ = ctx.read_blas(0, len(scene.blas[0][1]))
+    assert nodes["imask"][0] != 0
+    # upload refuses the cycle ...
+    bad_nodes = nodes.copy()
+    bad_nodes["childBaseIdx"][0] = 0
+    with pytest.raises(capi.NexusError):
+        ctx.upload_blas(bad_nodes, scene.blas[0][1], scene.blas[0][2])
+    # ... the hook plants it: the root's first inner child is now the root itself
+    ctx.debug_write_blas_node(0, 0, bad_nodes[0])
+    t0 = time.time()
+    ctx.trace_batch(rays)
+    with pytest.raises(capi.NexusError, match="not a tree"):
+        ctx.sync()
+    assert time.time() - t0 < 60.0
+    ctx.sync()  # reported once
+    ctx.debug_write_blas_node(0, 0, nodes[0])
+    assert SH.hit_records_equal(ctx.trace_batch(rays), want)
+    ctx.sync()

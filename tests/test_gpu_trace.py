@@ -92,7 +92,17 @@ def test_empty_and_single_ray(gpu_ctx_factory):
     assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
 
 
-@pytest.mark.parametrize("make_scene", [SH.soup_scene, SH.instanced_scene])
+def mixed_identity_scene():
+    """Identity-placed and rotated / scaled instances side by side: the per-record identity flag is set for some records
+    only, so the scene-wide flag is off and the kernel decides per lane."""
+    from nexus_amd import capi
+
+    meshes = [scenegen.random_soup(1200, seed=12, extent=0.7, size=0.09), scenegen.displaced_torus(40, 20, seed=12, major=0.6, minor=0.2)]
+    return SH.BuiltScene(meshes, [(0, 0, SH.IDENTITY), (1, 0, SH.IDENTITY), (1, 0, capi.mat4_from_trs((0.9, 0.2, -0.4), (25, 50, 75), (0.8, 1.2, 1.0))),
+                                  (0, 0, capi.mat4_from_trs((-0.7, -0.3, 0.5), (0, 90, 0))), (0, 0, capi.mat4_from_trs((0.5, 0.0, 0.0)))])
+
+
+@pytest.mark.parametrize("make_scene", [SH.soup_scene, SH.instanced_scene, mixed_identity_scene])
 def test_axis_aligned_rays_with_signed_zero_components(gpu_ctx_factory, make_scene):
     """Directions with exact +0 / -0 components (1/dir = +inf / -inf) through identity and rotated instances: the
     instance-entry shortcut for rays a transform leaves unchanged must not alter a single bit."""
@@ -126,6 +136,29 @@ def test_axis_aligned_rays_with_signed_zero_components(gpu_ctx_factory, make_sce
     # nearly-aligned half is expected to hit anything
     assert (want["hitDistance"][n:] < 1e29).mean() > 0.02
     assert SH.hit_records_equal(got, want)
+    # the any-hit variant shares the instance entry: same rays, tmax just beyond / just short of the closest hit
+    tmax = np.where(want["hitDistance"] < 1e29, want["hitDistance"] * rng.choice([0.999, 1.001], len(rays)), 10.0).astype(np.float32)
+    assert np.array_equal(ctx.trace_shadow_batch(rays, tmax), scene.oracle().trace_any(rays, tmax))
+
+
+def test_identity_instances_in_a_mixed_scene_trace_like_the_oracle(gpu_ctx_factory):
+    """Ordinary rays through a scene whose instances are partly identity-placed (flagged records skip the transform) and
+    partly rotated: hit records and visit counts equal the oracle's."""
+    scene = mixed_identity_scene()
+    ctx = gpu_ctx_factory(128, 128)
+    scene.upload(ctx)
+    rays = _rays_for(scene, 30000, seed=91)
+    ctx.enable_trace_stats(True)
+    ctx.read_trace_stats(reset=True)
+    got = ctx.trace_batch(rays)
+    closest, _ = ctx.read_trace_stats(reset=True)
+    ctx.enable_trace_stats(False)
+    st = O.TraceStats()
+    want = scene.oracle().trace_closest(rays, st)
+    assert (want["hitDistance"] < 1e29).mean() > 0.05
+    assert SH.hit_records_equal(got, want)
+    for k in ("nodes", "tris", "instances"):
+        assert closest[k] == st.as_dict()[k], k
 
 
 def test_degenerate_geometry_planar_meshes_and_zero_area_triangles(gpu_ctx_factory):

@@ -110,3 +110,36 @@ def test_device_side_refit_equals_the_host_refit_and_traces_like_the_oracle(gpu_
     assert not SH.hit_records_equal(ctx.trace_batch(_rays(2000, 3)), before) or n_inst == 1
     with pytest.raises(capi.NexusError):
         ctx.set_instance_transforms(np.array([n_inst], np.uint32), xfs[:1])
+
+
+@pytest.mark.gpu
+def test_device_side_transforms_keep_the_identity_shortcut_honest(gpu_ctx_factory):
+    """A scene placed with identity transforms only (the trace kernels then skip the transform rows altogether), one instance
+    rotated on the device and later put back: after each step the GPU traces what the oracle traces for that placement."""
+    meshes = [scenegen.random_soup(900, seed=21, extent=0.6, size=0.1), scenegen.displaced_torus(32, 16, seed=21, major=0.5, minor=0.2)]
+    scene = SH.BuiltScene(meshes, [(0, 0, SH.IDENTITY), (1, 0, SH.IDENTITY), (0, 0, SH.IDENTITY)])
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    rays = _rays(12000, 51)
+    # signed zeros in the directions as well: the shortcut must leave those rays to the general path
+    rays["direction"][:200, 0] = np.float32(-0.0)
+    rays["direction"][200:400, 2] = np.float32(0.0)
+    assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
+
+    def place(xf):
+        ctx.set_instance_transforms(np.array([1], np.uint32), np.array([xf], dtype=np.float32))
+        old = scene.instances[1]
+        inst = scene.instances.copy()
+        inst[1] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), xf, scene.blas[int(old["bvhIdx"])][0][0])
+        moved = SH.BuiltScene.__new__(SH.BuiltScene)
+        moved.__dict__.update(scene.__dict__)
+        moved.instances, moved.tlas_nodes = inst, capi.tlas_refit(scene.tlas_nodes, scene.tlas_idx, inst)
+        return moved
+
+    rotated = place(capi.mat4_from_trs((0.3, -0.2, 0.1), (30, 60, 10), (1.2, 0.9, 1.0)))
+    got = ctx.trace_batch(rays)
+    assert SH.hit_records_equal(got, rotated.oracle().trace_closest(rays))
+    back = place(SH.IDENTITY)
+    got = ctx.trace_batch(rays)
+    assert SH.hit_records_equal(got, back.oracle().trace_closest(rays))
+    assert SH.hit_records_equal(got, scene.oracle().trace_closest(rays))
