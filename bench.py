@@ -400,7 +400,8 @@ def main():
         pm = tile_pixel_map(W, H, 0, N)
         if args.pixel_order == "tiles":
             pm = multigpu.tiled_order(pm, W)
-        capN = max(1, min((args.frames_per_pass or (16 if big else 64)) * N, 512))
+        # (an explicit --frames-per-pass is taken as the rank's pass size itself, for sweeps)
+        capN = max(1, min(args.frames_per_pass if explicit_fpp else (16 if big else 64) * N, 512))
         S_full, R_full = S, R
         S, R, _ = plan_schedule(args.steps, capN, args.passes_in_flight, explicit_fpp, 1.0 / N)
         sync()

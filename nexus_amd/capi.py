@@ -393,6 +393,11 @@ def decode_png(data):
     return out, int(ch.value)
 
 
+def decode_image(data):
+    """IMGLoader::LoadIMG on an image file in memory — PNG, JPEG or Radiance .hdr by its signature: (HxWx4 uint8, channels)."""
+    return decode_png(data)
+
+
 class Context:
     """One ``nxhip_ctx`` (one GPU).  Thin 1:1 wrapper of the C-ABI; raises NexusError on any failure."""
 

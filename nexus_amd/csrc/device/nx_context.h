@@ -77,7 +77,7 @@ struct PassSlot {
     DevBuf shRayO, shRayD, shRadiance;
     DevBuf mqHit[4], mqDirInst[4];
     DevBuf counters, frame, dState;
-    size_t pathCapacity = 0;  // paths the queue buffers hold (grow-only across nxhip_set_frames_per_pass)
+    size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
     // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in
     // nxhip_api.hip: a small pass, a large pass and a pass among several in flight are different graphs).  A pass of another
     // size class replays the instance built for that class instead of re-instantiating one inside the frame loop.
@@ -111,6 +111,10 @@ struct nxhip_ctx : nxd::PassSlot {
 
     uint32_t width = 0, height = 0, localCount = 0;
     uint32_t framesPerPass = 1, pathCount = 0;
+    // Nominal queue capacity in paths (grow-only across nxhip_set_frames_per_pass).  A slot allocates its ~0.28 KB per path when
+    // it is about to be used (ensure_slot_queues) and gives it back when the context stops using it: the slots beyond the
+    // passes in flight, and slot 0 while the passes render in the extra slots.
+    size_t queueCapacity = 0;
     size_t radianceBoundCapacity = 0;  // float4 capacity of an externally bound radiance buffer, 0 = own buffer
 
     nxd::DeviceState h{};  // host mirror (scene + slot 0's queues), uploaded to every slot's dState when dirty

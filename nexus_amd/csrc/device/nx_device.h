@@ -71,14 +71,17 @@ static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
 // Traversal record of one TLAS leaf, stored in TLAS *leaf order* (entry k belongs to tlasInstIdx[k]) so that entering an
 // instance is one fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id, the BLAS root.
 struct __attribute__((aligned(16))) InstTrav {
-    float4 r0, r1, r2;  // rows 0..2 of invTransform
-    const NX_G uint4* nodes;
-    const NX_G float4* isect;
+    // (first chunk = what entering the instance needs at once: a lane waits for this load only before it decides whether
+    //  the transform has to be applied; the pointers and the id are needed an iteration later at the earliest)
     uint32_t instIdx;
     uint32_t flags;     // kInstIdentity: the inverse transform's first three rows are exactly those of the identity matrix
     uint32_t pad_[2];
+    const NX_G uint4* nodes;
+    const NX_G float4* isect;
+    float4 r0, r1, r2;  // rows 0..2 of invTransform
     uint4 root[5];      // a copy of the BLAS's root node: entering the instance and testing its root are one loop iteration
 };
+static_assert(sizeof(InstTrav) == 160, "InstTrav layout");
 constexpr uint32_t kInstIdentity = 1u;
 constexpr uint32_t kSceneAllIdentity = 1u;  // DeviceState::sceneFlags
 // rows 0..2 of a row-major 4x4 matrix equal the identity's bit for bit (+0.0 and 1.0 exactly; -0.0 does not count)
@@ -92,7 +95,6 @@ inline __host__ __device__ bool rows_are_identity(const float* m)
     }
     return same;
 }
-static_assert(sizeof(InstTrav) == 160, "InstTrav layout");
 
 struct TextureDev {
     const NX_G uint32_t* texels;  // RGBA8, row 0 first
@@ -136,7 +138,8 @@ struct FrameState {
     uint32_t errorWord;          // kErrTraversalStalled: set by a trace kernel that abandoned rays (see kStallLimit), read and cleared by nxhip_sync
 };
 constexpr uint32_t kErrTraversalStalled = 1u;
-// A wave of a trace kernel that has run this many loop iterations (about a second) without a single one of its rays finishing gives up on them:
+// A wave of a trace kernel that has stayed in its traversal loop for this many iterations (about a second) without coming
+// through its refill point — i.e. with rays that do not finish — gives up on them:
 // the rays end as misses / unoccluded, the error word is set and nxhip_sync reports NXHIP_ERR_TRAVERSAL.  A ray of a well-formed
 // tree visits every record at most once, so the bound is far above anything legitimate (the longest rays of the 10 M-triangle
 // scene take a few thousand iterations); it exists so that a BVH that is not a tree — which the upload checks reject, but a

@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
         unsigned long long activeMask = __ballot(active);
         NX_STAMP(0);
         if (activeMask == 0ull) break;
-        uint32_t stalled = 0u;           // iterations since a ray of this wave last finished (wave-uniform: scalar registers)
-        int busy = __popcll(activeMask);
+        uint32_t spins = 0u;  // iterations since the wave last came through its refill point (wave-uniform: a scalar register)
 
         // ---- traverse until too many lanes have run out of work
         do {
@@ -291,7 +290,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             if (wantInst) {
                 nodes = fi.nodes();
                 isect = fi.isect();
-                instIdx = fi.idFlags.x;
+                instIdx = fi.head.x;
                 // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
                 // A transform that maps this ray onto itself bit for bit leaves 1/dir as it is, so the three divisions here and
                 // the reload + three divisions on exit are skipped; an instance flagged as carrying the identity does not even
@@ -360,19 +359,15 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 #endif
             activeMask = __ballot(active);
 #ifndef NX_NO_STALL_GUARD
-            {
-                const int nowBusy = __popcll(activeMask);
-                stalled = nowBusy < busy ? 0u : stalled + 1u;
-                busy = nowBusy;
-                if (stalled > kStallLimit) {
-                    // no ray has finished for a million iterations: not a tree.  The wave abandons its rays (closest hit: they end
-                    // with what they found so far; any hit: as occluded), takes no more, and tells the host.
-                    if (lane == 0) atomicOr(&S->frame->errorWord, kErrTraversalStalled);
-                    if (active) { active = false; resultPending = !ANY_HIT; }
-                    activeMask = 0ull;
-                    exhausted = true;
-                    rngCur = rngEnd = 0;
-                }
+            // A wave leaves this loop when enough of its rays have finished, or — once the queue is dry — when all have.  One that
+            // is still here after kStallLimit iterations holds rays that go round in circles: not a tree.  It abandons them
+            // (closest hit: they end with what they found so far; any hit: as occluded), takes no more, and tells the host.
+            if (++spins > kStallLimit) {
+                if (lane == 0) atomicOr(&S->frame->errorWord, kErrTraversalStalled);
+                if (active) { active = false; resultPending = !ANY_HIT; }
+                activeMask = 0ull;
+                exhausted = true;
+                rngCur = rngEnd = 0;
             }
 #endif
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));

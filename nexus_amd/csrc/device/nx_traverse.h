@@ -68,33 +68,39 @@ NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }
 NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
 NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
 
-// The part of an instance record in front of its BLAS root copy.  In a scene whose instances all carry the identity (a uniform
-// flag of the device state, DeviceState::sceneFlags) the three transform rows are not even loaded.
+// The part of an instance record in front of its BLAS root copy, loaded in record order: id + flags, pointers, transform rows.
+// In a scene whose instances all carry the identity (a uniform flag of the device state, DeviceState::sceneFlags) the three
+// transform rows are not even loaded.
 struct InstFetch {
-    uint4 rows[3];
+    uint4 head;     // instance id, InstTrav::flags, -, -
     uint4 ptrs;
-    uint2 idFlags;  // instance id, InstTrav::flags
+    uint4 rows[3];
     NXD GU4 nodes() const { return (GU4)(((unsigned long long)ptrs.y << 32) | ptrs.x); }
     NXD GF4 isect() const { return (GF4)(((unsigned long long)ptrs.w << 32) | ptrs.z); }
 };
 NXD void fetch_instance(unsigned long long recAddr, bool sceneIdentity, InstFetch& f)
 {
     GU4 p = (GU4)recAddr;
-    if (!sceneIdentity) { f.rows[0] = p[0]; f.rows[1] = p[1]; f.rows[2] = p[2]; }
-    f.ptrs = p[3];
-    f.idFlags = *(const NX_G uint2*)(p + 4);
+    f.head = p[0];
+    f.ptrs = p[1];
+    if (!sceneIdentity) { f.rows[0] = p[2]; f.rows[1] = p[3]; f.rows[2] = p[4]; }
 }
 // The ray in the instance's frame (BVH8Traversal.cuh:259-264: origin and direction through the inverse transform, not
 // renormalised).  Returns whether it differs from the incoming ray; false leaves o2 / d2 unset and the caller's ray, 1 / dir
 // and (on exit) the restore untouched.  The comparison is on bit patterns: a zero whose sign the transform flips counts.
 NXD bool enter_instance(const InstFetch& f, bool sceneIdentity, f3 org, f3 dir, f3& o2, f3& d2)
 {
-#ifndef NX_NO_IDENTITY_FLAG
-    const bool identity = sceneIdentity || (f.idFlags.y & kInstIdentity) != 0u;
-    if (identity && ray_is_ordinary(org, dir)) return false;
-#endif
     float4 r0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-    if (!sceneIdentity) {
+#ifndef NX_NO_IDENTITY_FLAG
+    const bool ordinary = ray_is_ordinary(org, dir);
+    if (sceneIdentity) {
+        // (decided from registers alone: nothing of the record has to have arrived yet)
+        if (ordinary) return false;
+    } else {
+        if (ordinary && (f.head.y & kInstIdentity) != 0u) return false;  // waits for the record's first chunk only
+#else
+    {
+#endif
         r0 = make_float4(__uint_as_float(f.rows[0].x), __uint_as_float(f.rows[0].y), __uint_as_float(f.rows[0].z), __uint_as_float(f.rows[0].w));
         r1 = make_float4(__uint_as_float(f.rows[1].x), __uint_as_float(f.rows[1].y), __uint_as_float(f.rows[1].z), __uint_as_float(f.rows[1].w));
         r2 = make_float4(__uint_as_float(f.rows[2].x), __uint_as_float(f.rows[2].y), __uint_as_float(f.rows[2].z), __uint_as_float(f.rows[2].w));
@@ -180,14 +186,9 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
     uint32_t instIdx = 0;
     GU4 nodes = tlasNodes;
     GF4 isect = nullptr;
-    uint32_t stalled = 0u;  // iterations since a ray of this wave last finished (see kStallLimit)
-    int busy = 64;
-    for (;;) {
-        const int nowBusy = __popcll(__ballot(active));
-        if (nowBusy == 0) break;
-        stalled = nowBusy < busy ? 0u : stalled + 1u;
-        busy = nowBusy;
-        if (stalled > kStallLimit) {
+    uint32_t spins = 0u;  // iterations of this call: 64 rays, none of which legitimately takes anywhere near kStallLimit
+    while (__ballot(active) != 0ull) {
+        if (++spins > kStallLimit) {
             if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(&S->frame->errorWord, kErrTraversalStalled);
             break;
         }
@@ -239,7 +240,7 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
         if (wantInst) {
             nodes = fi.nodes();
             isect = fi.isect();
-            instIdx = fi.idFlags.x;
+            instIdx = fi.head.x;
             f3 o2, d2;
             xformed = enter_instance(fi, sceneIdentity, org, dir, o2, d2);
             if (xformed) {

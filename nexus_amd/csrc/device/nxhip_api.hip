@@ -179,6 +179,7 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     for (int i = 0; i < kCount; i++)
         if (!fresh[i].alloc(n * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
     NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // radiance
+    NX_HIP(hipMemset(fresh[2].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
     q->pathCapacity = n;
@@ -196,14 +197,49 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     return NXHIP_OK;
 }
 
-// the same capacity in every slot (slot 0 last, so that a failure in an extra slot leaves slot 0 untouched)
+// Give a slot's queue buffers back (nothing of it may be in flight: the caller has synchronised).
+static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
+{
+    DevBuf* const bufs[] = {&q->throughputPdf, &q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->shRayO, &q->shRayD, &q->shRadiance,
+                            &q->mqHit[0], &q->mqDirInst[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqHit[2], &q->mqDirInst[2], &q->mqHit[3], &q->mqDirInst[3]};
+    for (DevBuf* b : bufs) b->release();
+    q->pathCapacity = 0;
+    if (q == static_cast<PassSlot*>(c)) {
+        DeviceState& h = c->h;
+        h.throughputPdf = h.radiance = h.rayOrigin = nullptr;
+        h.trace = TraceQueue{};
+        h.shadow = ShadowQueue{};
+        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{};
+    }
+    c->stateDirty = true;
+}
+
+// A new nominal capacity: every slot that holds buffers is re-allocated (slot 0 last, so that a failure in an extra slot leaves
+// slot 0 untouched); released slots allocate when they are next used.
 static int alloc_queues(nxhip_ctx* c, size_t n)
 {
     for (uint32_t k = slot_count(c); k-- > 0;) {
-        const int rc = alloc_slot_queues(c, slot_at(c, k), n);
+        PassSlot* q = slot_at(c, k);
+        if (k != 0 && q->pathCapacity == 0) continue;
+        const int rc = alloc_slot_queues(c, q, n);
         if (rc != NXHIP_OK) return rc;
     }
+    c->queueCapacity = n;
     return NXHIP_OK;
+}
+
+// Before a slot is used: its queues exist at the nominal capacity.
+static int ensure_slot_queues(nxhip_ctx* c, PassSlot* q)
+{
+    if (q->pathCapacity >= c->queueCapacity && q->pathCapacity > 0) return NXHIP_OK;
+    float4* const boundPtr = c->h.radiance;
+    const size_t boundCap = c->radianceBoundCapacity;
+    const int rc = alloc_slot_queues(c, q, std::max<size_t>(c->queueCapacity, 1));
+    if (rc == NXHIP_OK && boundCap != 0 && q == static_cast<PassSlot*>(c)) {  // an external radiance binding survives
+        c->h.radiance = boundPtr;
+        c->radianceBoundCapacity = boundCap;
+    }
+    return rc;
 }
 
 // Everything sized by the pixel set of this context: queues for localCount * framesPerPass paths and a zeroed image.
@@ -422,14 +458,21 @@ int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
         return fail_invalid("nxhip_resize: more than 2^31 paths (pixels x frames per pass): lower nxhip_set_frames_per_pass first");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
-    c->width = width;
+    // the new size is committed only when its buffers exist: a failed allocation leaves viewport, pixel map and image as they were
+    const uint32_t oldW = c->width, oldH = c->height;
+    c->width = width;  // (alloc_paths sizes the image from these)
     c->height = height;
+    const int rc = alloc_paths(c, width * height);
+    if (rc != NXHIP_OK) {
+        c->width = oldW;
+        c->height = oldH;
+        return rc;
+    }
     c->h.camera.resolution[0] = width;
     c->h.camera.resolution[1] = height;
     c->pixelMap.release();
     c->h.pixelMap = nullptr;
-    const int rc = alloc_paths(c, width * height);
-    if (rc != NXHIP_OK) return rc;
+    c->stateDirty = true;
     return set_frame_number_device(c, 0);
 }
 
@@ -657,6 +700,8 @@ try {
         }
         if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_set_tlas: child index out of range");
         if (prims && (uint64_t)n.triangleBaseIdx + prims > instanceCount) return fail_invalid("nxhip_set_tlas: leaf range out of range");
+        // (checked here, before the context is touched: a failure must leave the previous TLAS and its traversal records in place)
+        if (inner && n.childBaseIdx <= i) return fail_invalid("nxhip_set_tlas: child nodes must follow their parent");
     }
     NX_SYNC_ALL(c);
     std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
@@ -681,7 +726,6 @@ try {
             const nx_bvh8_node& n = nodes[i];
             const uint32_t inner = (uint32_t)__builtin_popcount(n.imask);
             for (uint32_t k = 0; k < inner; k++) {
-                if (n.childBaseIdx + k <= i) return fail_invalid("nxhip_set_tlas: child nodes must follow their parent");
                 depth[n.childBaseIdx + k] = depth[i] + 1;
                 maxDepth = std::max(maxDepth, depth[i] + 1);
             }
@@ -800,8 +844,10 @@ try {
     // (nx_wavefront.hip keep_previous_vertex).  The logic kernel reads type and flag with the one load it already does.
     std::vector<nx_material> dev(materials, materials + count);
     for (nx_material& m : dev) {
+        // "can emit" exactly as shade_path tests it: maxcomp3(emissive * intensity) > 0 (a negative intensity with a negative
+        // component emits too)
         const bool flag = m.emissiveMapId != -1 || m.diffuseMapId != -1 || m.opacity < 1.0f ||
-                          std::max(std::max(m.emissive[0], m.emissive[1]), m.emissive[2]) * m.intensity > 0.0f;
+                          std::max(std::max(m.emissive[0] * m.intensity, m.emissive[1] * m.intensity), m.emissive[2] * m.intensity) > 0.0f;
         reinterpret_cast<unsigned char*>(&m)[kMaterialFlagOffset] = flag ? 1u : 0u;
     }
     NX_HIP(hipMemcpy(c->materials.p, dev.data(), (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
@@ -1361,6 +1407,19 @@ try {
     if (c->nextSlot >= R) c->nextSlot = 0;
     PassSlot* q = render_slot(c, R, c->nextSlot);
     c->nextSlot = (c->nextSlot + 1) % R;
+    if (q->pathCapacity < c->queueCapacity || q->pathCapacity == 0) {
+        rc = ensure_slot_queues(c, q);
+        if (rc != NXHIP_OK) return rc;
+        rc = upload_state(c);
+        if (rc != NXHIP_OK) return rc;
+    }
+    if (R > 1 && c->pathCapacity != 0 && !c->awaitingAccumulate) {
+        // the passes render in the extra slots: slot 0's queue set (as large as any of theirs) would sit idle
+        NX_SYNC_ALL(c);
+        release_slot_queues(c, c);
+        rc = upload_state(c);
+        if (rc != NXHIP_OK) return rc;
+    }
     const uint32_t frames = c->framesPerPass, frameLast = c->frameNumber + frames;
     if (R > 1) {
         rc = ensure_slot_events(q);
@@ -1496,13 +1555,11 @@ try {
         NX_HIP(hipMemset(q->counters.p, 0, sizeof(Counters)));
         FrameState fs{0u, -1, -1, 0u};
         NX_HIP(hipMemcpy(q->frame.p, &fs, sizeof fs, hipMemcpyHostToDevice));
-        const int rc = alloc_slot_queues(c, q.get(), std::max<size_t>(c->pathCapacity, 1));
-        if (rc != NXHIP_OK) {
-            (void)hipStreamDestroy(q->stream);
-            return rc;
-        }
-        c->extra.push_back(std::move(q));
+        c->extra.push_back(std::move(q));  // (its queues are allocated when it first renders: ensure_slot_queues)
     }
+    // slots beyond the passes in flight give their queues back (a context that once ran 8 passes in flight does not keep 8 queue sets)
+    for (size_t k = passes > 1 ? passes : 0; k < c->extra.size(); k++)
+        if (c->extra[k]->pathCapacity) release_slot_queues(c, c->extra[k].get());
     for (uint32_t k = 0; k < slot_count(c); k++) {
         const int rc = ensure_slot_events(slot_at(c, k));
         if (rc != NXHIP_OK) return rc;
@@ -1524,7 +1581,7 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
     const size_t n = (size_t)std::max<uint32_t>(c->localCount, 1u) * frames;
     if (c->radianceBoundCapacity != 0 && n > c->radianceBoundCapacity)
         return fail_invalid("nxhip_set_frames_per_pass: the bound radiance buffer is too small for this many frames; rebind first");
-    if (n > c->pathCapacity) {
+    if (n > c->queueCapacity) {
         // grow only: a later, smaller pass (e.g. the remainder of a frame budget) reuses the buffers.  The frame counter
         // and the accumulation are left alone: a pass size is a scheduling choice, not a new image.
         NX_HIP(hipSetDevice(c->device));
@@ -1557,7 +1614,7 @@ int nxhip_bind_radiance(nxhip_ctx* c, void* radianceDevice, uint32_t capacity)
         c->h.radiance = static_cast<float4*>(radianceDevice);
         c->radianceBoundCapacity = capacity;
     } else {
-        c->h.radiance = c->radiance.as<float4>();
+        c->h.radiance = c->radiance.as<float4>();  // (null while slot 0's queues are released: they come back with its next use)
         c->radianceBoundCapacity = 0;
     }
     c->stateDirty = true;
@@ -1683,6 +1740,8 @@ int nxhip_read_rgba8(nxhip_ctx* c, uint32_t* dst)
     return NXHIP_OK;
 }
 
+// Slot 0's radiance buffer (or the bound one).  Passes in flight > 1 render in other slots and slot 0's queues are released:
+// NULL then — use nxhip_bind_radiance or nxhip_read_radiance.
 void* nxhip_radiance_device_ptr(nxhip_ctx* c) { return c ? (void*)c->h.radiance : nullptr; }
 void* nxhip_accumulation_device_ptr(nxhip_ctx* c) { return c ? c->accumulation.p : nullptr; }
 
@@ -1750,7 +1809,9 @@ try {
     if (!rays || !hits) return fail_invalid("nxhip_trace_batch: null buffer");
     NX_HIP(hipSetDevice(c->device));
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
-    int rc = upload_state(c);
+    int rc = ensure_slot_queues(c, c);
+    if (rc != NXHIP_OK) return rc;
+    rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
     const uint32_t cap = c->pathCount;
     std::vector<float4> o(std::min(cap, count)), d(std::min(cap, count)), h(std::min(cap, count));
@@ -1793,7 +1854,9 @@ try {
     if (!rays || !tmax || !occluded) return fail_invalid("nxhip_trace_shadow_batch: null buffer");
     NX_HIP(hipSetDevice(c->device));
     if (!c->h.tlasNodes) return fail_invalid("no TLAS has been set");
-    int rc = upload_state(c);
+    int rc = ensure_slot_queues(c, c);
+    if (rc != NXHIP_OK) return rc;
+    rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
     const uint32_t cap = c->pathCount;
     const uint32_t m = std::min(cap, count);

@@ -1,4 +1,5 @@
-// IMGLoader.cpp — PNG decoder behind nexus/IMGLoader.h (the reference's IMGLoader.cpp:17-41 calls stbi_load with 4 channels).
+// IMGLoader.cpp — image decoders behind nexus/IMGLoader.h: PNG (all colour types and bit depths, Adam7 interlacing), Radiance
+// .hdr and — JPEGDecoder.cpp — JPEG, each reduced to RGBA8 exactly as stbi_load(…, 4) does (the reference's IMGLoader.cpp:17-41).
 #include "nexus/IMGLoader.h"
 
 #include <zlib.h>
@@ -13,6 +14,10 @@
 #include <vector>
 
 namespace nexus {
+
+namespace jpeg {
+Texture decode(const unsigned char* data, size_t size);  // JPEGDecoder.cpp
+}
 
 namespace {
 
@@ -108,10 +113,11 @@ Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
 {
     if (size >= 2 && data[0] == '#' && data[1] == '?') return load_radiance_hdr(data, size);
     static const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (size >= 3 && data[0] == 0xff && data[1] == 0xd8) fail("JPEG images are not supported (PNG only)");
+    if (size >= 3 && data[0] == 0xff && data[1] == 0xd8) return jpeg::decode(data, size);
     if (size < 8 || std::memcmp(data, kSig, 8) != 0) fail("not a PNG file");
     uint32_t width = 0, height = 0;
     int depth = 0, colour = -1;
+    bool interlaced = false;
     std::vector<unsigned char> idat, palette, trns;
     bool seenHeader = false, seenEnd = false;
     for (size_t off = 8; off + 12 <= size && !seenEnd;) {
@@ -126,15 +132,18 @@ Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
             depth = body[8];
             colour = body[9];
             if (body[10] != 0 || body[11] != 0) fail("unknown compression / filter method");
-            if (body[12] != 0) fail("interlaced PNG files are not supported");
+            if (body[12] > 1) fail("unknown interlace method");
+            interlaced = body[12] == 1;
             seenHeader = true;
         } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
         else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!std::memcmp(type, "IEND", 4)) seenEnd = true;
+        else if (!(type[0] & 0x20)) fail("unknown critical chunk");  // (ancillary chunks — lower-case first letter — are skipped)
         off += 12 + static_cast<size_t>(len);
     }
     if (!seenHeader || idat.empty()) fail("no IHDR / IDAT chunk");
+    if (!seenEnd) fail("the file ends before its IEND chunk");
     if (width == 0 || height == 0 || width > (1u << 15) || height > (1u << 15)) fail("unreasonable image size");
     const int samples = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
     if (!samples) fail("unknown colour type");
@@ -145,33 +154,54 @@ Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
     if (colour == 3 && (palette.size() < 3 || palette.size() % 3)) fail("palette image without a valid PLTE chunk");
 
     const size_t bitsPerPixel = static_cast<size_t>(samples) * depth;
-    const size_t stride = (static_cast<size_t>(width) * bitsPerPixel + 7) / 8;
     const size_t bpp = std::max<size_t>(1, bitsPerPixel / 8);  // filter distance in bytes
-    std::vector<unsigned char> raw((stride + 1) * height);
+    auto stride_of = [&](uint32_t w) { return (static_cast<size_t>(w) * bitsPerPixel + 7) / 8; };
+    // the sub-images the data stream carries one after the other: the image itself, or the seven Adam7 passes
+    // (pass p holds the pixels (x0 + i * dx, y0 + j * dy); empty passes carry no bytes)
+    struct Pass { uint32_t x0, y0, dx, dy, w, h; };
+    std::vector<Pass> passes;
+    if (!interlaced) passes.push_back(Pass{0, 0, 1, 1, width, height});
+    else {
+        static const uint32_t kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1}, kDx[7] = {8, 8, 4, 4, 2, 2, 1}, kDy[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int p = 0; p < 7; p++) {
+            const uint32_t w = (width + kDx[p] - 1 - kX0[p]) / kDx[p], h = (height + kDy[p] - 1 - kY0[p]) / kDy[p];
+            if (width > kX0[p] && height > kY0[p] && w && h) passes.push_back(Pass{kX0[p], kY0[p], kDx[p], kDy[p], w, h});
+        }
+    }
+    size_t rawSize = 0;
+    for (const Pass& p : passes) rawSize += (stride_of(p.w) + 1) * p.h;
+    std::vector<unsigned char> raw(rawSize);
     uLongf rawLen = static_cast<uLongf>(raw.size());
     const int zrc = uncompress(raw.data(), &rawLen, idat.data(), static_cast<uLong>(idat.size()));
     if (zrc != Z_OK || rawLen != raw.size()) fail("corrupt image data (zlib)");
 
-    // undo the scanline filters in place (filter byte first on every line)
-    std::vector<unsigned char> prev(stride, 0);
-    for (uint32_t y = 0; y < height; y++) {
-        unsigned char* line = raw.data() + (stride + 1) * y;
-        const int filter = line[0];
-        unsigned char* cur = line + 1;
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = cur[i];
-            switch (filter) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) / 2; break;
-            case 4: v += paeth(a, b, c); break;
-            default: fail("unknown scanline filter");
+    // undo the scanline filters in place (filter byte first on every line; every pass starts with a zero line above it)
+    {
+        size_t off = 0;
+        for (const Pass& p : passes) {
+            const size_t stride = stride_of(p.w);
+            std::vector<unsigned char> prev(stride, 0);
+            for (uint32_t y = 0; y < p.h; y++) {
+                unsigned char* line = raw.data() + off + (stride + 1) * y;
+                const int filter = line[0];
+                unsigned char* cur = line + 1;
+                for (size_t i = 0; i < stride; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                    int v = cur[i];
+                    switch (filter) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) / 2; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: fail("unknown scanline filter");
+                    }
+                    cur[i] = static_cast<unsigned char>(v);
+                }
+                std::memcpy(prev.data(), cur, stride);
             }
-            cur[i] = static_cast<unsigned char>(v);
+            off += (stride + 1) * p.h;
         }
-        std::memcpy(prev.data(), cur, stride);
     }
 
     Texture tex;
@@ -194,10 +224,13 @@ Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
     const bool haveKey = (colour == 0 && trns.size() >= 2) || (colour == 2 && trns.size() >= 6);
     if (haveKey)
         for (int k = 0; k < (colour == 0 ? 1 : 3); k++) key[k] = (uint32_t(trns[2 * k]) << 8) | trns[2 * k + 1];
-    for (uint32_t y = 0; y < height; y++) {
-        const unsigned char* row = raw.data() + (stride + 1) * y + 1;
-        unsigned char* out = tex.pixels.data() + static_cast<size_t>(y) * width * 4;
-        for (uint32_t x = 0; x < width; x++, out += 4) {
+    size_t passOff = 0;
+    for (const Pass& ps : passes) {
+      const size_t stride = stride_of(ps.w);
+      for (uint32_t py = 0; py < ps.h; py++) {
+        const unsigned char* row = raw.data() + passOff + (stride + 1) * py + 1;
+        for (uint32_t x = 0; x < ps.w; x++) {
+            unsigned char* out = tex.pixels.data() + (static_cast<size_t>(ps.y0 + py * ps.dy) * width + (ps.x0 + x * ps.dx)) * 4;
             switch (colour) {
             case 0: {
                 const uint32_t g = sample(row, x);
@@ -226,6 +259,8 @@ Texture IMGLoader::LoadIMG(const unsigned char* data, size_t size)
                 for (int k = 0; k < 4; k++) out[k] = to8(sample(row, 4 * x + k));
             }
         }
+      }
+      passOff += (stride + 1) * ps.h;
     }
     return tex;
 }

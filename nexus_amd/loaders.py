@@ -134,18 +134,36 @@ def decode_hdr(data):
     return out, 3
 
 
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))  # x0, y0, dx, dy per pass
+
+
+def decode_image(data):
+    """An image file in memory -> (HxWx4 uint8, channels), as the reference's IMGLoader gets it from stbi_load(..., 4).
+    PNG and Radiance .hdr are decoded here (Python twins of the C++ decoders, compared with them byte for byte by the
+    tests); JPEG goes through the product's C++ decoder (nexus::jpeg, checked against stb_image by
+    tests/test_image_decoders.py) — there is no Python twin of that one."""
+    data = bytes(data)
+    if data[:2] == b"\xff\xd8":
+        from . import capi
+
+        return capi.decode_image(data)
+    if data[:2] == b"#?":
+        return decode_hdr(data), 3
+    return decode_png(data)
+
+
 def decode_png(data):
     """PNG (ISO/IEC 15948) -> (HxWx4 uint8, channels of the file), what stbi_load(..., 4) returns and the reference's
     IMGLoader hands to Texture (Assets/IMGLoader.cpp:17-41): all colour types, 1-16 bits, palette / colour-key
-    transparency, 16-bit samples reduced to their high byte; no Adam7 interlacing."""
+    transparency, 16-bit samples reduced to their high byte, Adam7 interlacing."""
     data = bytes(data)
-    if data[:2] == b"\xff\xd8":
-        raise ValueError("JPEG images are not supported (PNG only)")
     if data[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("not a PNG file")
-    off, idat, palette, trns, hdr = 8, b"", b"", b"", None
+    off, idat, palette, trns, hdr, ended = 8, b"", b"", b"", None, False
     while off + 12 <= len(data):
         (n,), typ = struct.unpack_from(">I", data, off), data[off + 4: off + 8]
+        if n > len(data) - off - 12:
+            raise ValueError("chunk runs past the end of the file")
         body = data[off + 8: off + 8 + n]
         if typ == b"IHDR":
             hdr = struct.unpack(">IIBBBBB", body)
@@ -156,58 +174,78 @@ def decode_png(data):
         elif typ == b"IDAT":
             idat += body
         elif typ == b"IEND":
+            ended = True
             break
+        elif not typ[0] & 0x20:
+            raise ValueError("unknown critical chunk")
         off += 12 + n
     if hdr is None or not idat:
         raise ValueError("no IHDR / IDAT chunk")
+    if not ended:
+        raise ValueError("the file ends before its IEND chunk")
     w, h, depth, colour, _comp, _filt, interlace = hdr
-    if interlace:
-        raise ValueError("interlaced PNG files are not supported")
+    if interlace > 1:
+        raise ValueError("unknown interlace method")
     samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
     bits = samples * depth
-    stride = (w * bits + 7) // 8
     bpp = max(1, bits // 8)
     raw = zlib.decompress(idat)
-    if len(raw) != (stride + 1) * h:
+    passes = [(0, 0, 1, 1, w, h)]
+    if interlace:
+        passes = [(x0, y0, dx, dy, (w + dx - 1 - x0) // dx, (h + dy - 1 - y0) // dy) for (x0, y0, dx, dy) in ADAM7 if w > x0 and h > y0]
+    if len(raw) != sum(((pw * bits + 7) // 8 + 1) * ph for (_x0, _y0, _dx, _dy, pw, ph) in passes):
         raise ValueError("corrupt image data")
-    rows = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        f = raw[(stride + 1) * y]
-        cur = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=(stride + 1) * y + 1).astype(np.int32)
-        if f == 0:
-            pass
-        elif f == 2:
-            cur = (cur + prev) & 255
-        else:  # 1, 3, 4 depend on the already reconstructed byte bpp to the left: a scan
-            out = cur.copy()
-            for i in range(stride):
-                a = out[i - bpp] if i >= bpp else 0
-                b = prev[i]
-                c = prev[i - bpp] if i >= bpp else 0
-                if f == 1:
-                    out[i] = (out[i] + a) & 255
-                elif f == 3:
-                    out[i] = (out[i] + (a + b) // 2) & 255
-                elif f == 4:
-                    pp = a + b - c
-                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
-                    out[i] = (out[i] + (a if (pa <= pb and pa <= pc) else (b if pb <= pc else c))) & 255
-                else:
-                    raise ValueError("unknown scanline filter")
-            cur = out
-        rows[y] = cur
-        prev = cur
-    if depth == 8:
-        smp = rows[:, : w * samples].astype(np.uint32)
-    elif depth == 16:
-        smp = (rows[:, : 2 * w * samples: 2].astype(np.uint32) << 8) | rows[:, 1: 2 * w * samples: 2]
-    else:
-        bitsarr = np.unpackbits(rows, axis=1)[:, : w * samples * depth].reshape(h, w * samples, depth)
-        smp = np.zeros((h, w * samples), dtype=np.uint32)
-        for k in range(depth):
-            smp = (smp << 1) | bitsarr[:, :, k]
-    smp = smp.reshape(h, w, samples)
+
+    def sub_image(offset, pw, ph):
+        """one filtered sub-image of the stream -> [ph][pw][samples] at full bit depth"""
+        stride = (pw * bits + 7) // 8
+        rows = np.zeros((ph, stride), dtype=np.uint8)
+        prev = np.zeros(stride, dtype=np.int32)
+        for y in range(ph):
+            f = raw[offset + (stride + 1) * y]
+            cur = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=offset + (stride + 1) * y + 1).astype(np.int32)
+            if f == 0:
+                pass
+            elif f == 2:
+                cur = (cur + prev) & 255
+            else:  # 1, 3, 4 depend on the already reconstructed byte bpp to the left: a scan
+                out = cur.copy()
+                for i in range(stride):
+                    a = out[i - bpp] if i >= bpp else 0
+                    b = prev[i]
+                    c = prev[i - bpp] if i >= bpp else 0
+                    if f == 1:
+                        out[i] = (out[i] + a) & 255
+                    elif f == 3:
+                        out[i] = (out[i] + (a + b) // 2) & 255
+                    elif f == 4:
+                        pp = a + b - c
+                        pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                        out[i] = (out[i] + (a if (pa <= pb and pa <= pc) else (b if pb <= pc else c))) & 255
+                    else:
+                        raise ValueError("unknown scanline filter")
+                cur = out
+            rows[y] = cur
+            prev = cur
+        if depth == 8:
+            sm = rows[:, : pw * samples].astype(np.uint32)
+        elif depth == 16:
+            sm = (rows[:, : 2 * pw * samples: 2].astype(np.uint32) << 8) | rows[:, 1: 2 * pw * samples: 2]
+        else:
+            bitsarr = np.unpackbits(rows, axis=1)[:, : pw * samples * depth].reshape(ph, pw * samples, depth)
+            sm = np.zeros((ph, pw * samples), dtype=np.uint32)
+            for k in range(depth):
+                sm = (sm << 1) | bitsarr[:, :, k]
+        return sm.reshape(ph, pw, samples), (stride + 1) * ph
+
+    smp = np.zeros((h, w, samples), dtype=np.uint32)
+    offset = 0
+    for (x0, y0, dx, dy, pw, ph) in passes:
+        if pw == 0 or ph == 0:
+            continue
+        sub, used = sub_image(offset, pw, ph)
+        smp[y0::dy, x0::dx] = sub
+        offset += used
 
     def to8(v):
         if depth == 16:
@@ -314,7 +352,7 @@ def load_glb(path):
                 raw = open(os.path.join(os.path.dirname(path), img["uri"]), "rb").read()
             else:
                 raise ValueError("image without bufferView or file uri")
-            px, _ch = decode_png(raw)
+            px, _ch = decode_image(raw)
             result = len(out.textures)
             out.textures.append((kind, px))
         except Exception as e:  # the reference prints and carries on (IMGLoader.cpp:24-25)

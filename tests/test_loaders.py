@@ -250,13 +250,18 @@ def test_png_decoders_agree_with_the_encoded_samples():
         capi.decode_png(bytes(bad))
 
 
-def _textured_glb(path, rng):
-    """A two-triangle quad with UVs, a base-colour texture and an emissive texture (PNG, embedded through bufferViews)."""
+def _textured_glb(path, rng, images=None):
+    """A two-triangle quad with UVs, a base-colour texture and an emissive texture (PNG unless `images` gives the two files'
+    bytes, embedded through bufferViews)."""
     import json
     import struct
 
-    base_png, _ = _png(16, 8, 6, 8, 4, rng)
-    emis_png, _ = _png(4, 4, 2, 8, 3, rng)
+    if images:
+        base_png, emis_png = images
+    else:
+        base_png, _ = _png(16, 8, 6, 8, 4, rng)
+        emis_png, _ = _png(4, 4, 2, 8, 3, rng)
+    mime = ["image/jpeg" if b[:2] == b"\xff\xd8" else "image/png" for b in (base_png, emis_png)]
     pos = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
     nrm = np.tile(np.array([0, 1, 0], np.float32), (4, 1))
     uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
@@ -272,7 +277,7 @@ def _textured_glb(path, rng):
         "meshes": [{"name": "quad", "primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]}],
         "materials": [{"name": "tex", "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "baseColorTexture": {"index": 0}},
                        "emissiveTexture": {"index": 1}, "emissiveFactor": [1, 1, 1]}],
-        "textures": [{"source": 0}, {"source": 1}], "images": [{"bufferView": 4, "mimeType": "image/png"}, {"bufferView": 5, "mimeType": "image/png"}],
+        "textures": [{"source": 0}, {"source": 1}], "images": [{"bufferView": 4, "mimeType": mime[0]}, {"bufferView": 5, "mimeType": mime[1]}],
         "buffers": [{"byteLength": len(blob)}], "bufferViews": views,
         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3", "min": [-1, 0, -1], "max": [1, 0, 1]},
                       {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
@@ -305,7 +310,7 @@ def test_glb_textures_cpp_equals_python_and_reach_the_asset_manager(tmp_path):
     sc.load_file(str(tmp_path) + os.sep, "textured.glb")
     sc.update()
     assert sc.light_count() == 1
-    # a JPEG (or anything that is not a PNG) is dropped with a warning, the scene still loads
+    # an image that cannot be decoded (here: a JPEG signature in front of PNG bytes) is dropped with a warning, the scene still loads
     raw = bytearray(open(path, "rb").read())
     at = raw.find(base_png[:8])
     raw[at: at + 4] = b"\xff\xd8\xff\xe0"
@@ -316,6 +321,48 @@ def test_glb_textures_cpp_equals_python_and_reach_the_asset_manager(tmp_path):
     assert loaders.load_glb(broken).material_diffuse_texture == [-1]
 
 
+def test_glb_with_jpeg_images_loads_like_through_stb_image(tmp_path):
+    """glTF's most common image encoding: a baseline 4:2:0 and a progressive JPEG as base-colour and emissive textures.  Both
+    readers decode them, to the pixels stb_image produces (tests/golden/images_golden.npz: the reference's decoder on the same
+    files), and the scene built from the file has its light."""
+    from nexus_amd import capi
+
+    img_dir = os.path.join(SH.GOLDEN, "images")
+    names = ("base_420_q75_37x29", "prog_444_q85_37x29")
+    files = [open(os.path.join(img_dir, n + ".jpg"), "rb").read() for n in names]
+    gold = np.load(os.path.join(SH.GOLDEN, "images_golden.npz"))
+    path = str(tmp_path / "jpeg_textures.glb")
+    _textured_glb(path, None, images=files)
+    texs, dt, et, warns = capi.load_scene_textures(path)
+    assert warns == [] and list(dt) == [0] and list(et) == [1]
+    py = loaders.load_glb(path)
+    assert py.warnings == []
+    for (kind, px), (kind_py, px_py), n in zip(texs, py.textures, names):
+        assert kind == kind_py and np.array_equal(px, px_py)
+        assert np.array_equal(px, gold[n])
+    sc = capi.Scene(32, 32)
+    sc.load_file(str(tmp_path) + os.sep, "jpeg_textures.glb")
+    sc.update()
+    assert sc.light_count() == 1
+
+
+def test_interlaced_png_python_twin_equals_cpp():
+    from nexus_amd import capi
+    from tests.test_image_decoders import make_png
+
+    rng = np.random.RandomState(31)
+    for colour, depth, n, (w, h) in ((0, 1, 1, (9, 5)), (2, 8, 3, (13, 11)), (3, 4, 1, (7, 9)), (4, 16, 2, (3, 2)), (6, 8, 4, (17, 8)), (2, 16, 3, (1, 1))):
+        palette = rng.randint(0, 256, 48).astype(np.uint8) if colour == 3 else None
+        maxv = 15 if colour == 3 else (1 << depth) - 1
+        smp = rng.randint(0, maxv + 1, size=(h, w, n)).astype(np.uint32)
+        data = make_png(smp, colour, depth, interlace=True, palette=palette)
+        a, ca = capi.decode_image(data)
+        b, cb = loaders.decode_png(data)
+        assert ca == cb and np.array_equal(a, b)
+        plain, _ = capi.decode_image(make_png(smp, colour, depth, interlace=False, palette=palette))
+        assert np.array_equal(a, plain)
+
+
 def test_cpp_decoders_survive_mutated_files(tmp_path):
     """Byte-level mutations of valid files: the C++ PNG decoder and .glb reader must either decode or raise NexusError,
     never read out of bounds (this test is also part of the AddressSanitizer run, tools/run_sanitized_cpu_tests.sh)."""
@@ -324,6 +371,11 @@ def test_cpp_decoders_survive_mutated_files(tmp_path):
     rng = np.random.RandomState(11)
     pngs = [_png(9, 7, 6, 8, 4, rng)[0], _png(5, 6, 0, 1, 1, rng)[0], _png(6, 4, 2, 16, 3, rng)[0],
             _png(7, 5, 3, 4, 1, rng, palette=bytes(rng.randint(0, 256, size=48).astype(np.uint8)))[0]]
+    # JPEG files (baseline with restart markers, progressive) and an interlaced PNG go through the same mill
+    from tests.test_image_decoders import make_png
+    for n in ("base_420_q80_restart_70x40", "prog_420_q70_45x31", "base_cmyk_q80_24x18"):
+        pngs.append(open(os.path.join(SH.GOLDEN, "images", n + ".jpg"), "rb").read())
+    pngs.append(make_png(rng.randint(0, 256, size=(9, 11, 3)).astype(np.uint32), 2, 8, interlace=True))
     outcomes = {"ok": 0, "refused": 0}
     for data in pngs:
         for _ in range(60):
@@ -355,4 +407,4 @@ def test_cpp_decoders_survive_mutated_files(tmp_path):
             outcomes["ok"] += 1
         except capi.NexusError:
             outcomes["refused"] += 1
-    assert outcomes["refused"] > 20 and outcomes["ok"] + outcomes["refused"] == 4 * 60 + 40
+    assert outcomes["refused"] > 20 and outcomes["ok"] > 20 and outcomes["ok"] + outcomes["refused"] == len(pngs) * 60 + 40
