@@ -98,6 +98,34 @@ def tile_pixel_map(width, height, rank, world):
     return multigpu.tile_pixel_map(width, height, rank, world, multigpu.tile_rows_for(height, world, (TILE_ROWS, 8, 4, 6, 3, 2, 1)))
 
 
+KERNEL_SOURCES = {"trace": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"),
+                  "wavefront": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h")}
+
+
+def kernel_source_hash(which):
+    """sha256 (16 hex digits) over the device sources a kernel class is compiled from: the committed per-ray / per-item counter
+    constants (profiles/trace_counters.json, tools/pmc_to_json.py) carry the hash of the code they were measured on, and a
+    figure derived from them is only reported while the code is still that code."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[which]:
+        h.update(open(os.path.join(ROOT, "nexus_amd", "csrc", "device", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters_for(config, key, which):
+    """the committed counter constants of one kernel class, or (None, reason)"""
+    if not os.path.exists(COUNTERS_JSON):
+        return None, "no profiles/trace_counters.json"
+    ck = json.load(open(COUNTERS_JSON)).get("config%d" % config, {}).get(key)
+    if not ck:
+        return None, "no counter pass committed for this workload and kernel class (tools/profile_round.sh)"
+    if ck.get("source_sha16") != kernel_source_hash(which):
+        return None, "the committed counters were measured on other kernel code (source hash %s, now %s): re-run tools/profile_round.sh" % (ck.get("source_sha16"), kernel_source_hash(which))
+    return ck, None
+
+
 def trace_algorithmic_bytes(st):
     """SURVEY.md section 8d, closest-hit kernel: 44 B per ray (24 in + 20 out), 80 B per node visited, 40 B per triangle
     tested (4 index + 36 positions), 104 B per instance entered."""
@@ -145,14 +173,16 @@ def stamp(phase):
 
 def plan_schedule(steps, cap, passes_in_flight, explicit_pass_size, share):
     """Pass size S and passes in flight R for a timed region of `steps` frames.  `cap`: the largest pass (frames), `share`: the
-    fraction of the image this process renders (1 / ranks).  A region shorter than a few full passes is cut into enough
-    passes to have several in flight — their drains overlap — instead of collapsing to one (the driver's 20-frame region:
-    one 20-frame pass 1 530, five 4-frame passes 1 590 Msamples/s before this round's kernel changes)."""
-    split_into = 5
+    fraction of the image this process renders (1 / ranks).  Measured on the 20-frame region the driver times (gpurun_out
+    r3_01 / r3_05): a pass has a latency floor — nine trace levels, each as long as its slowest ray —
+    of about 5.7 ms however little it carries, so work is only worth cutting into passes in flight while every piece keeps
+    about four 1080p frames' worth of paths: the full frame runs five 4-frame passes (1 590 Msamples/s against 1 530 for one
+    20-frame pass), a rank of an 8-way split its 2.5 frames' worth as ONE pass (5.8 ms; cut five ways: 6.6 ms)."""
     if explicit_pass_size:
         S = max(1, min(cap, steps))
     else:
-        S = max(1, min(cap, -(-steps // split_into)))
+        pieces = max(1, min(5, int(steps * share / 4.0)))
+        S = cap if steps > cap else max(1, -(-steps // pieces))  # (a budget of more than one full pass keeps full passes)
     n_passes = -(-steps // S)
     small = S * share <= 4.0
     R = passes_in_flight if passes_in_flight else (6 if small else 4)
@@ -259,6 +289,7 @@ def main():
         sc.env_sampling = False
         workload_name += " [environment sampling off: experiment]"
 
+    frames_rendered = [0]  # by step(): what a profiler run of this command has seen of every kernel (tools/pmc_to_json.py)
     dist = None
     torch = None
     if dist_mode:
@@ -319,6 +350,7 @@ def main():
             assert seen.all()
 
         def step(n):
+            frames_rendered[0] += n
             # every rank path-traces and accumulates its own tiles (the exact per-frame running mean of the 1-GPU path) ...
             if ctx.frames_per_pass != n:
                 ctx.set_frames_per_pass(n)  # within the allocated capacity: no synchronisation, the size travels as a kernel argument
@@ -351,6 +383,7 @@ def main():
             ctx.set_passes_in_flight(R)
 
         def step(n):
+            frames_rendered[0] += n
             if ctx.frames_per_pass != n:
                 ctx.set_frames_per_pass(n)  # within the allocated capacity: no synchronisation, the size travels as a kernel argument
             ctx.render_frame()
@@ -442,7 +475,7 @@ def main():
             "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order,
             "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
-            "pass_sizes": schedule(args.steps),
+            "pass_sizes": schedule(args.steps), "frames_rendered_by_the_timed_loop": frames_rendered[0],
             "host_scene_build_s": round(t_build, 2), "blas_builder": "device LBVH (nxhip_build_blas)" if args.device_bvh else "host binned-SAH + SAH-DP collapse (the reference's algorithm)",
         },
     }
@@ -489,9 +522,7 @@ def main():
         # HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE), VALU wave-instructions and the clock under the profiler.  Per ray they
         # do not depend on the pass size (measured equal within 4 % at 1 and 20 frames per pass), so the driver's pass size
         # gets the same figures as the profiled one.
-        ck = None
-        if os.path.exists(COUNTERS_JSON):
-            ck = json.load(open(COUNTERS_JSON)).get("config%d" % args.config, {}).get("trace_closest")
+        ck, ck_reason = counters_for(args.config, "trace_closest", "trace")
         ceilings = {}
         traffic = None
         if ck:
@@ -507,7 +538,7 @@ def main():
             # The any-hit launch of a bounce runs concurrently with the closest-hit one on the same SIMDs, and a wave64 VALU
             # instruction measures 2.42 cycles, not 2 (tools/micro/half_wave.hip): the SIMDs' issue slots are fuller than
             # `frac` says.  Reported beside it, not as the fraction.
-            cks = json.load(open(COUNTERS_JSON)).get("config%d" % args.config, {}).get("trace_shadow")
+            cks, _ = counters_for(args.config, "trace_shadow", "trace")
             if cks and kt["shadow"]["launches"]:
                 shadow_rays_per_launch = shadow["rays"] / (kt["shadow"]["launches"] * passes)
                 both = ginst + shadow_rays_per_launch * cks["valu_insts_per_ray"] / dur_s / 1e9
@@ -523,7 +554,7 @@ def main():
             "bound": bound, "kernel": "trace_kernel<closest>", "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": traffic,
             "traffic_source": ("rays per launch of this run x bytes per ray from %s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; reads x2 per the gfx950 note of "
-                               "MI355X_MICROARCH.md)" % os.path.relpath(COUNTERS_JSON, ROOT)) if ck else None,
+                               "MI355X_MICROARCH.md)" % os.path.relpath(COUNTERS_JSON, ROOT)) if ck else ck_reason,
             "ceilings": ceilings,
             # the algorithmic bytes of SURVEY.md section 8d: mostly served by L1 / L2 / Infinity Cache when the scene fits them
             "algorithmic": {"bytes_per_launch": int(alg_bytes_per_launch), "GBs": round(alg_gbs, 1), "bytes_per_ray": round(alg_bytes_per_launch / max(1.0, rays_per_launch), 1),
@@ -544,8 +575,46 @@ def main():
             "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
                        "algorithmic_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"] * passes)) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
             "kernel_ms_per_frame": {k: round(v["ms"] / frames_timed[k], 4) for k, v in kt.items()},
+            "items_per_frame": {"logic": int(sum(int(x) for x in q["traceSize"][: args.path_length]) // S),
+                                "shade": int(sum(int(sum(q[m][1: args.path_length + 1])) for m in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize")) // S)},
             "live_rays_by_bounce": [int(x) for x in q["traceSize"][: args.path_length + 1]],
         }
+
+    # ---- the second kernel class: logic and the material (shade) kernels, per queue item
+    if "roofline" in out:
+        rf = out["roofline"]
+        classes = {}
+        # SURVEY.md section 8d, algorithmic bytes per item.  Logic: 60 in + 48 out, + 164 gathered (instance 160 + material 4)
+        # for a hit.  Shade: 36 request + 12 throughput + 348 gathered (instance 160, BVH descriptor 32, triangle 96, material
+        # 60) + 360 for the light sample, out 28 + 44 + 28 + 24.
+        alg = {"logic": 60 + 48 + 164, "shade": 36 + 12 + 348 + 360 + 28 + 44 + 28 + 24}
+        for klass in ("logic", "shade"):
+            items = rf["items_per_frame"][klass]
+            ms = rf["kernel_ms_per_frame"].get(klass)
+            if not items or not ms:
+                continue
+            sec = ms * 1e-3
+            e = {"items_per_frame": items, "ms_per_frame": ms, "Mitems_per_s": round(items / sec / 1e6, 1), "algorithmic_bytes_per_item": alg[klass],
+                 "algorithmic_GBs": round(items * alg[klass] / sec / 1e9, 1)}
+            ck2, why = counters_for(args.config, klass, "wavefront")
+            if ck2:
+                bytes_item = ck2.get("hbm_read_bytes_per_ray", 0.0) + ck2.get("hbm_write_bytes_per_ray", 0.0)
+                gbs = items * bytes_item / sec / 1e9
+                e["hbm"] = {"bytes_per_item": round(bytes_item, 1), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "frac_of_achievable_6290": round(gbs / 6290.0, 4)}
+                if "valu_insts_per_ray" in ck2:
+                    ginst = items * ck2["valu_insts_per_ray"] / sec / 1e9
+                    peak_ginst = SIMDS * ck2.get("clock_GHz", 2.3) / VALU_ISSUE_CYCLES
+                    e["valu-issue"] = {"valu_insts_per_item": ck2["valu_insts_per_ray"], "achieved": round(ginst, 1), "peak": round(peak_ginst, 1), "unit": "G wave-instructions/s",
+                                       "frac": round(ginst / peak_ginst, 4)}
+                for k in ("l1_hit_rate", "l2_hit_rate", "valu_active_lanes_per_inst", "vmem_rd_insts_per_ray"):
+                    if k in ck2:
+                        e[k] = ck2[k]
+                e["bound"] = max((k for k in ("hbm", "valu-issue") if k in e), key=lambda k: e[k]["frac"])
+            else:
+                e["counters"] = why
+            classes[klass] = e
+        rf["classes"] = classes
 
     if rank == 0 and not dist_mode and not args.no_cpu_baseline:
         # a 1-GPU box's CPU share is 16 hardware threads

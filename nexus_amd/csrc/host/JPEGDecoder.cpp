@@ -81,7 +81,7 @@ struct HuffTable {
             const int run = sym >> 4, mag = sym & 15;
             if (!mag || len + mag > 9) continue;
             int v = ((w << len) & 511) >> (9 - mag);
-            if (v < (1 << (mag - 1))) v += (-1 << mag) + 1;
+            if (v < (1 << (mag - 1))) v -= (1 << mag) - 1;
             if (v >= -128 && v <= 127) shortcut[w] = static_cast<int16_t>(v * 256 + run * 16 + len + mag);
         }
     }

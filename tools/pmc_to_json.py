@@ -18,12 +18,38 @@ ap.add_argument("--out", required=True)
 ap.add_argument("passes", nargs="+")
 a = ap.parse_args()
 
-KERNELS = {"trace_closest": "trace_kernel<false, false", "trace_shadow": "trace_kernel<true, false"}
+# kernel classes: name pattern -> the unit its counters are divided by (rays traced; queue items processed)
+KERNELS = {"trace_closest": "trace_kernel<false, false", "trace_shadow": "trace_kernel<true, false", "logic": "logic_kernel<", "shade": "shade_kernel<"}
 bench = json.load(open(a.bench))
-rays = {"trace_closest": bench["roofline"]["rays_per_frame"] * a.frames, "trace_shadow": bench["roofline"]["shadow"]["rays_per_frame"] * a.frames}
+rf = bench["roofline"]
+rays = {"trace_closest": rf["rays_per_frame"] * a.frames, "trace_shadow": rf["shadow"]["rays_per_frame"] * a.frames,
+        "logic": rf.get("items_per_frame", {}).get("logic", 0) * a.frames, "shade": rf.get("items_per_frame", {}).get("shade", 0) * a.frames}
+
+
+def source_hash(files):
+    """sha256 over the kernel sources a class is compiled from: bench.py refuses counter constants measured on other code"""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in files:
+        h.update(open(os.path.join(root, "nexus_amd", "csrc", "device", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+SOURCES = {"trace_closest": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"), "trace_shadow": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"),
+           "logic": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h"),
+           "shade": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h")}
 
 sums = {k: collections.defaultdict(float) for k in KERNELS}
+frames_of = {}  # counter name -> frames the run that collected it rendered
 for d in a.passes:
+    frames_d = a.frames
+    line = os.path.normpath(d) + ".json"  # tools/profile_round.sh keeps the bench line of every counter run beside its directory
+    if os.path.exists(line):
+        try:
+            frames_d = json.load(open(line))["config"].get("frames_rendered_by_the_timed_loop", a.frames)
+        except Exception:
+            pass
     dur = {}
     for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -43,13 +69,22 @@ for d in a.passes:
         t = sum(dur[i][1] for i in seen[k] if i in dur)
         for n in names:
             sums[k]["_ns_with_" + n] = t
+            frames_of[n] = frames_d
 
 out = json.load(open(a.out)) if os.path.exists(a.out) else {}
 cfg = out.setdefault("config%d" % a.config, {})
 cfg["profile"] = {"tag": a.tag, "command": a.command, "frames": a.frames, "pass_dirs": [os.path.basename(os.path.normpath(p)) for p in a.passes]}
+per_frame = {"trace_closest": rf["rays_per_frame"], "trace_shadow": rf["shadow"]["rays_per_frame"],
+             "logic": rf.get("items_per_frame", {}).get("logic", 0), "shade": rf.get("items_per_frame", {}).get("shade", 0)}
 for k in KERNELS:
-    s, n = sums[k], max(1, rays[k])
-    e = {"rays_profiled": int(rays[k])}
+    s, n = dict(sums[k]), max(1, rays[k])
+    if not s:
+        continue
+    # every counter divided by the units of ITS run: normalise the sums to the nominal frame count first
+    for c in list(s):
+        if not c.startswith("_") and frames_of.get(c, a.frames) != a.frames:
+            s[c] = s[c] * a.frames / frames_of[c]
+    e = {"rays_profiled": int(rays[k]), "unit": "ray" if k.startswith("trace") else "queue item", "source_sha16": source_hash(SOURCES[k])}
     if "FETCH_SIZE" in s:
         e["hbm_read_bytes_per_ray"] = round(2.0 * s["FETCH_SIZE"] * 1024.0 / n, 2)
     if "WRITE_SIZE" in s:
@@ -81,4 +116,4 @@ for k in KERNELS:
     e["raw_sums"] = {c: v for c, v in sorted(s.items()) if not c.startswith("_")}
     cfg[k] = e
 json.dump(out, open(a.out, "w"), indent=1, sort_keys=True)
-print(json.dumps({k: {x: y for x, y in cfg[k].items() if x != "raw_sums"} for k in KERNELS}, indent=1))
+print(json.dumps({k: {x: y for x, y in cfg[k].items() if x != "raw_sums"} for k in KERNELS if k in cfg}, indent=1))
