@@ -40,6 +40,12 @@ public:
     // Extension, off by default: when only existing instances changed, refit the TLAS (O(n)) in Update() instead of the
     // reference's full agglomerative rebuild (Scene.cpp:29-55).
     void SetTlasRefit(bool enable) { m_TlasRefit = enable; }
+    // Extension, off by default: leave the TLAS to the device.  Update() then builds no tree on the host when instances were
+    // added or removed — PathTracer::UpdateDeviceScene has the device build it from the instances' world boxes
+    // (nxhip_rebuild_tlas: linear BVH, a millisecond where the reference's agglomerative clustering takes seconds) — and
+    // moved instances are refitted on the device as with SetTlasRefit.  GetTLAS() holds no tree in this mode.
+    void SetDeviceTlasBuild(bool enable) { m_DeviceTlas = enable; tlasDirty = true; }
+    bool UsesDeviceTlasBuild() const { return m_DeviceTlas; }
 
     // ---- per frame -----------------------------------------------------------------------------------------------
     bool IsInvalid() const { return m_Invalid || !m_InvalidMeshInstances.empty() || m_Camera->IsInvalid() || m_AssetManager.IsInvalid(); }
@@ -83,6 +89,7 @@ private:
     std::set<uint32_t> m_InvalidMeshInstances;
     bool m_Invalid = true;
     bool m_TlasRefit = false;
+    bool m_DeviceTlas = false;
     size_t m_TlasBuiltFor = 0;  // instance count of the last full TLAS build
 };
 

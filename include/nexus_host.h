@@ -100,6 +100,9 @@ int nxs_scene_set_instance_transform(nxs_scene *s, uint32_t instanceId, const fl
 /* Extension (off by default): refit the TLAS in nxs_scene_update when only existing instances changed, instead of the
  * reference's full rebuild. */
 int nxs_scene_set_tlas_refit(nxs_scene *s, int enable);
+/* Extension (off by default): the TLAS is built and refitted on the device (Scene::SetDeviceTlasBuild -> nxhip_rebuild_tlas /
+ * nxhip_set_instance_transforms); nxs_scene_update then runs no TLAS builder on the host. */
+int nxs_scene_set_device_tlas(nxs_scene *s, int enable);
 /* Scene::CreateMeshInstanceFromFile — Scene.cpp:83-91: adds the file's materials, meshes (one BVH8 each) and instances. */
 int nxs_scene_load_file(nxs_scene *s, const char *path, const char *fileName);
 int nxs_scene_set_camera(nxs_scene *s, const float pos[3], const float forward[3], float horizontalFovDeg, float focusDist,

@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node",
+    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
@@ -38,7 +38,7 @@ HOST_SYMBOLS = [
     "nxs_renderer_save_screenshot", "nxs_renderer_save_exr", "nxs_renderer_frame_number", "nxs_renderer_megasamples_per_second", "nxs_renderer_device_context",
     "nxs_renderer_set_modes",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
-    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit",
+    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit", "nxs_scene_set_device_tlas",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
     "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes", "nxs_pathtracer_set_frames_per_pass", "nxs_pathtracer_set_passes_in_flight",
@@ -501,6 +501,18 @@ class Context:
         check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
         return nodes, idx
 
+    def rebuild_tlas(self, instances):
+        """build the TLAS on the device (LBVH over the instances' world boxes) and install it; returns (nodes, instance index list)"""
+        instances = np.ascontiguousarray(instances, dtype=pod.INST_DT)
+        self.L.nxhip_rebuild_tlas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        check(self.L.nxhip_rebuild_tlas(self.h, _ptr(instances), len(instances)), "nxhip_rebuild_tlas")
+        self.L.nxhip_read_tlas_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        n = C.c_uint32(0)
+        idx = np.zeros(len(instances), dtype=np.uint32)
+        check(self.L.nxhip_read_tlas_index(self.h, _ptr(idx), len(idx), C.byref(n)), "nxhip_read_tlas_index")
+        nodes, _ = self.read_tlas(n.value, len(instances))
+        return nodes, idx
+
     def debug_write_blas_node(self, blas_id, node_idx, node):
         """test hook: overwrite one node of an uploaded BLAS without the upload checks"""
         node = np.ascontiguousarray(node, dtype=pod.NODE_DT).reshape(1)
@@ -780,6 +792,11 @@ class Scene:
 
     def set_tlas_refit(self, enable=True):
         _scheck(self.L.nxs_scene_set_tlas_refit(self.h, 1 if enable else 0), "nxs_scene_set_tlas_refit")
+
+    def set_device_tlas(self, enable=True):
+        """the TLAS is built (nxhip_rebuild_tlas) and refitted on the device; update() runs no host TLAS builder"""
+        self.L.nxs_scene_set_device_tlas.argtypes = [C.c_void_p, C.c_int]
+        _scheck(self.L.nxs_scene_set_device_tlas(self.h, 1 if enable else 0), "nxs_scene_set_device_tlas")
 
     def load_file(self, path, file_name):
         """Scene::CreateMeshInstanceFromFile: materials, meshes (one BVH8 each) and instances of a .glb / .obj"""

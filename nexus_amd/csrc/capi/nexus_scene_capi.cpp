@@ -210,6 +210,11 @@ int nxs_scene_set_tlas_refit(nxs_scene* s, int enable)
     return guarded([&] { s->scene.SetTlasRefit(enable != 0); });
 }
 
+int nxs_scene_set_device_tlas(nxs_scene* s, int enable)
+{
+    return guarded([&] { s->scene.SetDeviceTlasBuild(enable != 0); });
+}
+
 int nxs_scene_load_file(nxs_scene* s, const char* path, const char* fileName)
 {
     return guarded([&] {

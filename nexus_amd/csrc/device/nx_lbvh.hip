@@ -70,6 +70,33 @@ __global__ void __launch_bounds__(kBlock) tri_bounds_kernel(const nx_triangle* _
     }
 }
 
+// the same for a TLAS: the primitives are the instances' world-space boxes (BVHInstance::SetTransform computed them)
+__global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_instance* __restrict__ inst, const uint32_t n, Box3* __restrict__ box, uint32_t* __restrict__ sceneBounds)
+{
+    float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Box3 b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = inst[i].boundsMin[a];
+            b.hi[a] = inst[i].boundsMax[a];
+            const float c = 0.5f * (b.lo[a] + b.hi[a]);
+            cl[a] = fminf(cl[a], c);
+            ch[a] = fmaxf(ch[a], c);
+        }
+        box[i] = b;
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            cl[a] = fminf(cl[a], __shfl_down(cl[a], o));
+            ch[a] = fmaxf(ch[a], __shfl_down(ch[a], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&sceneBounds[a], float_ordered(cl[a]));
+            atomicMax(&sceneBounds[3 + a], float_ordered(ch[a]));
+        }
+    }
+}
+
 // ---- 2. 63-bit Morton codes of the box centres --------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long spread21(uint32_t v)  // 21 bits -> every third bit
 {
@@ -367,24 +394,15 @@ int grid_for(uint32_t n, int cus) { return (int)std::min<uint32_t>((n + kBlock -
 
 }  // namespace
 
-// Builds nodes / primIdx / isect for the `n` triangles at dTris (device).  All device buffers come back through the
-// arguments; *nodeCount = nodes used.
-int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount)
+// The build from primitive boxes on: Morton codes, sort, radix tree, bounds, collapse.  `triBox` / `bounds` (centroid bounds,
+// ordered-uint encoded) are on the device and filled by a kernel already queued on the stream.  primIdx: n entries.
+static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bounds, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
-    DevBuf triBox, bounds;
-    if (!triBox.alloc((size_t)n * sizeof(Box3)) || !bounds.alloc(6 * 4) || !primIdx.alloc((size_t)n * 4) || !isect.alloc((size_t)n * kTriStride * sizeof(float4))) return NXHIP_ERR_HIP;
-    {
-        const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-        NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
-        tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
-    }
     if (n <= 8) {
         if (!nodes.alloc(sizeof(nx_bvh8_node))) return NXHIP_ERR_HIP;
         small_mesh_kernel<<<1, 64, 0, st>>>(triBox.as<Box3>(), (int)n, nodes.as<nx_bvh8_node>(), primIdx.as<uint32_t>());
-        isect_kernel<<<1, kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
-        NX_HIP(hipStreamSynchronize(st));
         *nodeCount = 1;
         return NXHIP_OK;
     }
@@ -441,7 +459,41 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes
         NX_HIP(hipMemcpyAsync(counters.as<uint32_t>() + 2, &zero, 4, hipMemcpyHostToDevice, st));
         std::swap(cur, nxt);
     }
+    return NXHIP_OK;
+}
+
+// Builds nodes / primIdx / isect for the `n` triangles at dTris (device).  All device buffers come back through the
+// arguments; *nodeCount = nodes used.
+int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    DevBuf triBox, bounds;
+    if (!triBox.alloc((size_t)n * sizeof(Box3)) || !bounds.alloc(6 * 4) || !primIdx.alloc((size_t)n * 4) || !isect.alloc((size_t)n * kTriStride * sizeof(float4))) return NXHIP_ERR_HIP;
+    const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
+    tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
+    const int rc = lbvh_from_boxes(c, triBox, bounds, n, nodes, primIdx, nodeCount);
+    if (rc != NXHIP_OK) return rc;
     isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
+    NX_HIP(hipStreamSynchronize(st));
+    NX_HIP(hipGetLastError());
+    return NXHIP_OK;
+}
+
+// The same builder over instance boxes: a TLAS for `n` instances (device array, world bounds filled in).  nodes / primIdx
+// (the TLAS's instance index list, leaf order) stay on the device; *nodeCount = nodes used.
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    DevBuf box, bounds;
+    if (!box.alloc((size_t)n * sizeof(Box3)) || !bounds.alloc(6 * 4) || !primIdx.alloc((size_t)n * 4)) return NXHIP_ERR_HIP;
+    const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
+    instance_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dInstances, n, box.as<Box3>(), bounds.as<uint32_t>());
+    const int rc = lbvh_from_boxes(c, box, bounds, n, nodes, primIdx, nodeCount);
+    if (rc != NXHIP_OK) return rc;
     NX_HIP(hipStreamSynchronize(st));
     NX_HIP(hipGetLastError());
     return NXHIP_OK;

@@ -94,6 +94,12 @@ struct SlotAllocator {
                 sRun[threadIdx.x] += total;
             } else {
                 sBase[threadIdx.x] = total ? atomicAdd(counters[threadIdx.x], total) : 0;
+#ifdef NX_EXTRA_ATOMICS
+                // experiment: are the logic / material kernels bound by the returning atomics on their queue
+                // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
+                for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
+                    if (total && atomicAdd(counters[threadIdx.x], 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
+#endif
             }
         }
         __syncthreads();

@@ -27,6 +27,7 @@ const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
 int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount);
 
 static thread_local std::string g_lastError;
 
@@ -751,6 +752,45 @@ try {
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_set_tlas: ") + e.what());
     return NXHIP_ERR_INVALID;
+}
+
+int nxhip_rebuild_tlas(nxhip_ctx* c, const nx_bvh_instance* instances, uint32_t instanceCount)
+try {
+    NX_CHECK_CTX(c);
+    if (!instances || instanceCount == 0) return fail_invalid("nxhip_rebuild_tlas: empty input");
+    if (kNodeStride != 5) return fail_invalid("nxhip_rebuild_tlas: built with padded node records");
+    for (uint32_t i = 0; i < instanceCount; i++)
+        if (instances[i].bvhIdx >= c->blas.size()) return fail_invalid("nxhip_rebuild_tlas: instance refers to a BLAS id that has not been uploaded");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    DevBuf dInst, wide, primIdx;
+    NX_ALLOC(dInst, (size_t)instanceCount * sizeof(nx_bvh_instance));
+    NX_HIP(hipMemcpy(dInst.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
+    uint32_t nodeCount = 0;
+    int rc = lbvh_build_tlas(c, dInst.as<nx_bvh_instance>(), instanceCount, wide, primIdx, &nodeCount);
+    if (rc != NXHIP_OK) return rc;
+    // The tree is a few hundred nodes per thousand instances: it comes back once so that nxhip_set_tlas — range checks, the
+    // traversal records in leaf order, the schedule of the device-side refit — installs it like any other TLAS.
+    std::vector<nx_bvh8_node> nodes(nodeCount);
+    std::vector<uint32_t> idx(instanceCount);
+    NX_HIP(hipMemcpy(nodes.data(), wide.p, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+    NX_HIP(hipMemcpy(idx.data(), primIdx.p, (size_t)instanceCount * 4, hipMemcpyDeviceToHost));
+    return nxhip_set_tlas(c, nodes.data(), nodeCount, idx.data(), instances, instanceCount);
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_rebuild_tlas: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
+int nxhip_read_tlas_index(nxhip_ctx* c, uint32_t* instanceIdx, uint32_t capacity, uint32_t* nodeCount)
+{
+    NX_CHECK_CTX(c);
+    if (!c->h.tlasNodes) return fail_invalid("nxhip_read_tlas_index: no TLAS has been set");
+    if (nodeCount) *nodeCount = c->tlasNodeCount;
+    if (instanceIdx) {
+        if (capacity < c->hostInstIdx.size()) return fail_invalid("nxhip_read_tlas_index: destination too small");
+        std::memcpy(instanceIdx, c->hostInstIdx.data(), c->hostInstIdx.size() * 4);
+    }
+    return NXHIP_OK;
 }
 
 int nxhip_set_instance_transforms(nxhip_ctx* c, const uint32_t* instanceIds, const float* transforms16, uint32_t count)

@@ -76,7 +76,16 @@ void PathTracer::UpdateDeviceScene(const Scene& scene)
         Check(nxhip_set_materials(m_Ctx, assets.GetMaterials().data(), static_cast<uint32_t>(assets.GetMaterials().size())), "nxhip_set_materials");
         mutableAssets.materialsDirty = false;
     }
-    if (scene.tlasDirty && scene.GetTLAS() && !scene.GetTLAS()->bvh8.nodes.empty()) {
+    if (scene.tlasDirty && scene.UsesDeviceTlasBuild() && !scene.GetBVHInstances().empty()) {
+        // the TLAS is built where it is used: instances (with the world bounds SetTransform gave them) go up, the tree never
+        // exists on the host
+        const std::vector<BVHInstance>& placed = scene.GetBVHInstances();
+        std::vector<nx_bvh_instance> inst(placed.size());
+        for (size_t i = 0; i < inst.size(); i++) inst[i] = BVHInstance::ToDevice(placed[i]);
+        Check(nxhip_rebuild_tlas(m_Ctx, inst.data(), static_cast<uint32_t>(inst.size())), "nxhip_rebuild_tlas");
+        scene.tlasDirty = false;
+        scene.movedInstances.clear();
+    } else if (scene.tlasDirty && scene.GetTLAS() && !scene.GetTLAS()->bvh8.nodes.empty()) {
         const TLAS& tlas = *scene.GetTLAS();
         std::vector<nx_bvh_instance> inst(tlas.bvhInstances.size());
         for (size_t i = 0; i < inst.size(); i++) inst[i] = BVHInstance::ToDevice(tlas.bvhInstances[i]);

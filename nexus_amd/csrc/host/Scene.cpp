@@ -55,9 +55,20 @@ void Scene::Update()
     }
     m_InvalidMeshInstances.clear();
 
+    const bool sameInstances = m_TlasBuiltFor == m_BVHInstances.size();
+    if (m_DeviceTlas) {
+        // the tree lives on the device only: same instances moved -> refit there; anything else -> rebuilt there
+        if (sameInstances && onlyTransforms && !tlasDirty) movedInstances.insert(movedInstances.end(), moved.begin(), moved.end());
+        else {
+            tlasDirty = true;
+            movedInstances.clear();
+        }
+        m_TlasBuiltFor = m_BVHInstances.size();
+        m_Invalid = false;
+        return;
+    }
     if (!m_Tlas) m_Tlas = std::make_shared<TLAS>(m_BVHInstances);
     m_Tlas->SetBVHInstances(m_BVHInstances);
-    const bool sameInstances = m_TlasBuiltFor == m_BVHInstances.size();
     if (m_TlasRefit && sameInstances && m_Tlas->Refit()) {
         // the host copy of the tree is refitted too (O(n)), so that it stays what the device holds; the device is told
         // only which instances moved, unless it has yet to see this tree at all

@@ -147,6 +147,41 @@ def test_moving_instances_with_tlas_refit_renders_like_a_rebuild():
 
 
 @pytest.mark.gpu
+def test_scene_with_the_tlas_left_to_the_device_renders_like_the_host_built_one():
+    """Scene::SetDeviceTlasBuild: no TLAS builder runs on the host — the device builds the tree from the instances when the
+    scene is first sent and when an instance is added, and refits it when instances move.  Same image as the reference's
+    host rebuild at every stage (pixel-keyed RNG; hits are those of a correct TLAS either way)."""
+    W = H = 64
+    imgs = {False: [], True: []}
+    for device_tlas in (False, True):
+        sc = _cornell_facade(W, H, 3)
+        sc.set_device_tlas(device_tlas)
+        sc.update()
+        pt = capi.PathTracer(W, H)
+        pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+
+        def frame():
+            pt.update_device_scene(sc)
+            pt.reset_frame_number()
+            pt.render(sc)
+            imgs[device_tlas].append(pt.read_radiance())
+
+        frame()
+        sc.set_instance_transform(5, (0.35, 0.05, 0.25), (90.0, 10.0, 0.0), (1.0, 1.0, 1.0))  # moved: device-side refit
+        sc.update()
+        frame()
+        sc.create_instance(6, 1, position=(0.0, 1.2, 0.0), rotation_deg=(90.0, 45.0, 0.0), scale=(0.5, 0.5, 0.5))  # added: rebuild
+        sc.update()
+        frame()
+        assert sc.instance_count() == 9
+        pt.close()
+    for a, b in zip(imgs[False], imgs[True]):
+        assert np.isfinite(a).all() and a.max() > 0
+        assert SH.image_agreement(b, a, 1e-6) >= 0.999
+    assert SH.image_agreement(imgs[True][2], imgs[True][0], 1e-6) < 0.999  # the edits are visible
+
+
+@pytest.mark.gpu
 def test_cpp_example_program_renders_the_same_image(tmp_path):
     """examples/nexus_render.cpp (the reference's render loop through the kept C++ API, no Python in the process) against
     the same scene driven through the ctypes facade."""
