@@ -117,14 +117,36 @@ struct MaterialQueue {
     NX_G float4* dirInst;  // (ray direction, instance)
 };
 
-// Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize
-// (PathTracer.cuh:61-73) with traceCount/traceShadowCount widened to one fetch head per XCD.
-struct Counters {
+// Every queue is kept in kQueueShards REGIONS of its buffer (region k = slots [k * cap, (k + 1) * cap), cap =
+// DeviceState::queueShardCap) with one size word per region: a producer workgroup appends to region blockIdx % 8, so the
+// returning atomics that hand out slots are spread over eight words — a single word sustains only ~90 of them per microsecond,
+// which is what bound the logic and material kernels (one extra zero-adding atomic per tile: material kernels x4.2, DESIGN.md
+// section 6) — and the trace kernels' eight fetch heads (one per XCD group) walk one region each.  Grid-stride tiles make the
+// regions balanced and bound their fill: a kernel of M items in tiles of T gives each region at most M / 8 + 2 T outputs.
+// DeviceState::queueShards == 1 (ordered compaction: one workgroup, the reference's serial slot order) keeps everything in
+// region 0, whose capacity is then the whole buffer.
+constexpr int kQueueShards = 8;
+static_assert(kQueueShards == kXcds, "one queue region per fetch head");
+constexpr int kQueueShardSlack = 4096;  // slots a region may exceed its even share by (see above; tiles are at most 1 024 items)
+
+// Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize (PathTracer.cuh:61-73) with every
+// size word and traceCount / traceShadowCount widened to one per region / XCD group — and each region's words on 4 KiB of
+// their own: the returning atomics on them are device-scope and execute at the memory side, where what serialises them is the
+// channel an address maps to; eight words in one cache line are one channel (measured: no gain at all over a single word),
+// eight words 4 KiB apart are not.
+struct RegionCounters {
     int32_t traceSize[kMaxBounceSlots];
     int32_t traceShadowSize[kMaxBounceSlots];
     int32_t materialSize[4][kMaxBounceSlots];  // enum order DIFFUSE, DIELECTRIC, PLASTIC, CONDUCTOR
-    int32_t traceHead[kMaxBounceSlots][kXcds];
-    int32_t shadowHead[kMaxBounceSlots][kXcds];
+    int32_t traceHead[kMaxBounceSlots];        // rays of this region handed out by the closest-hit / any-hit trace launch
+    int32_t shadowHead[kMaxBounceSlots];
+    int32_t pad_[1024 - 8 * kMaxBounceSlots];
+};
+static_assert(sizeof(RegionCounters) == 4096, "one region's counters per 4 KiB");
+constexpr int kRegionStride = (int)(sizeof(RegionCounters) / sizeof(int32_t));  // distance between the same word of two regions
+
+struct Counters {
+    RegionCounters region[kQueueShards];
     // ordered-compaction running bases (single-workgroup mode)
     int32_t orderedBase[8];
     int32_t tailHead;      // paths of the tail kernel's queue handed out so far
@@ -191,6 +213,8 @@ struct DeviceState {
     uint32_t localCount;       // pixels rendered by this context
     uint32_t framesPerPass;    // S >= 1
     uint32_t pathCount;        // localCount * framesPerPass
+    uint32_t queueShards;      // regions in use: kQueueShards, or 1 with ordered compaction
+    uint32_t queueShardCap;    // slots per region
     const NX_G uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
     NX_G float4* throughputPdf;     // rgb throughput, w = lastPdf
     NX_G float4* radiance;

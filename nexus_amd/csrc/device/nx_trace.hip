@@ -29,6 +29,7 @@
 //     parked in LDS instead of being kept in 9 VGPRs.
 // No MFMA: this is pointer chasing, bounded by memory latency / bandwidth.
 #define NX_KERNEL_TU 1
+#include "nx_queue.h"
 #include "nx_traverse.h"
 
 namespace nxd {
@@ -59,9 +60,16 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     __shared__ float ldsWorld[9 * kTraceBlock];
 
     NX_G Counters* C = S->counters;
-    const int size = ANY_HIT ? C->traceShadowSize[bounce] : C->traceSize[bounce];
+    // the queue's eight regions (nx_device.h): region k = slots [k * cap, k * cap + regionRays[k]), fetch head k counts the
+    // rays handed out of it
+    // (word k of either: [k * kRegionStride])
+    const NX_G int32_t* regionRays = ANY_HIT ? &C->region[0].traceShadowSize[bounce] : &C->region[0].traceSize[bounce];
+    const int cap = (int)S->queueShardCap;
+    int size = 0;
+#pragma unroll
+    for (int k = 0; k < kXcds; k++) size += regionRays[k * kRegionStride];
     if (size <= 0) return;
-    NX_G int* heads = ANY_HIT ? C->shadowHead[bounce] : C->traceHead[bounce];
+    NX_G int* heads = ANY_HIT ? &C->region[0].shadowHead[bounce] : &C->region[0].traceHead[bounce];
     GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
     GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
     GU4 tlasNodes = S->tlasNodes;
@@ -74,11 +82,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
-    // shard geometry: 8 contiguous, 64-aligned pieces of the queue
-    const int chunk = ((size + kXcds * kWave - 1) / (kXcds * kWave)) * kWave;
     const int homeShard = blockIdx.x & (kXcds - 1);
-    const int homeBegin = homeShard * chunk;
-    const int homeRays = max(0, min(size, homeBegin + chunk) - homeBegin);
+    const int homeRays = regionRays[homeShard * kRegionStride];
     // this wave's rank among the waves that call this shard home
     const int rankInShard = (int)(blockIdx.x >> 3) * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
     // A wave the queue does not need leaves without touching a fetch head.  The grid is sized for the largest queue; on a
@@ -157,10 +162,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     if (exhausted) break;
                     // one returning atomic reserves kReserve rays of `shard` (the head counts rays handed out)
                     const int leader = __ffsll((long long)needMask) - 1;
-                    const int shardBegin = shard * chunk;
-                    const int shardEnd = min(size, shardBegin + chunk);
+                    const int shardBegin = shard * cap;
+                    const int shardEnd = shardBegin + regionRays[shard * kRegionStride];
                     int base = 0;
-                    if (lane == leader) base = atomicAdd(&heads[shard], reserve);
+                    if (lane == leader) base = atomicAdd(&heads[shard * kRegionStride], reserve);
                     base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
                     rngCur = shardBegin + base;
                     rngEnd = min(shardEnd, rngCur + reserve);
@@ -170,9 +175,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         rngCur = rngEnd = 0;
                         int left = 0;
                         if (lane < kXcds) {
-                            const int b2 = lane * chunk, e2 = min(size, b2 + chunk);
-                            const int taken = __hip_atomic_load(&heads[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            left = max(0, (e2 - b2) - taken);
+                            const int taken = __hip_atomic_load(&heads[lane * kRegionStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            left = max(0, regionRays[lane * kRegionStride] - taken);
                         }
                         int best = 0, bestLeft = 0;
 #pragma unroll

@@ -18,6 +18,7 @@
 #include "nx_bsdf.h"
 #include "nx_device.h"
 #include "nx_math.h"
+#include "nx_queue.h"
 #include "nx_texture.h"
 #include "nx_traverse.h"
 
@@ -148,8 +149,12 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __
     if (threadIdx.x == 0) {
         S->framesPerPass = frames;
         S->pathCount = S->localCount * frames;
-        S->counters->traceSize[0] = (int)(S->localCount * frames);
         S->frame->frameNumber = frameLast;
+    }
+    if (threadIdx.x < kQueueShards) {
+        // the primary rays: path i goes to region i / piece (generate_kernel)
+        const uint32_t n = S->localCount * frames, piece = dense_piece(n, S->queueShards), k = threadIdx.x;
+        S->counters->region[k].traceSize[0] = k < S->queueShards ? (int)min(piece, n - min(n, k * piece)) : 0;
     }
 }
 
@@ -164,6 +169,7 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
     const f3 camPos = ld3(S->camera.position), camRight = ld3(S->camera.right), camUp = ld3(S->camera.up);
     const f3 llc = ld3(S->camera.lowerLeftCorner), vpX = ld3(S->camera.viewportX), vpY = ld3(S->camera.viewportY);
     const float lensRadius = S->camera.lensRadius;
+    const uint32_t piece = dense_piece(n, S->queueShards), cap = S->queueShardCap;
     for (uint32_t index = blockIdx.x * blockDim.x + threadIdx.x; index < n; index += gridDim.x * blockDim.x) {
         const PathId id = path_id(S, index, frameLast);
         const uint32_t g = global_pixel(S, id.pixel);
@@ -182,8 +188,9 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         S->radiance[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
         // reading them back, and the logic kernel stores them for every path that survives its first hit
-        S->trace.rayO[index] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-        S->trace.rayD[index] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
+        const uint32_t region = index / piece, slot = region * cap + (index - region * piece);
+        S->trace.rayO[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+        S->trace.rayD[slot] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
     }
 }
 
@@ -323,13 +330,16 @@ template <bool ORDERED>
 __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGIC_WAVES) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
-    const int size = C->traceSize[bounce - 1];
+    const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
+    const int size = in.total;
     // the grid is sized for the largest queue: a workgroup with no tile to process leaves before the allocator's
     // barriers (late bounces carry a few thousand items; an all-empty launch used to cost 30 us)
     if ((int)(blockIdx.x * blockDim.x) >= size) return;
     const uint32_t frame = S->frame->frameNumber;
     SlotAllocator<ORDERED, 4> slots;
-    int* const ctr[4] = {&C->materialSize[0][bounce], &C->materialSize[1][bounce], &C->materialSize[2][bounce], &C->materialSize[3][bounce]};
+    const int region = producer_region(S), regionBase = region * (int)S->queueShardCap;
+    RegionCounters* const rc = &C->region[region];
+    int* const ctr[4] = {&rc->materialSize[0][bounce], &rc->materialSize[1][bounce], &rc->materialSize[2][bounce], &rc->materialSize[3][bounce]};
     slots.init(ctr);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
@@ -338,15 +348,16 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
         float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0);
         uint32_t inst = 0, pixelIdx = 0;
         if (index < size) {
-            hit = S->trace.hit[index];
-            dirPix = S->trace.rayD[index];
+            const int at = in.slot(index);  // where item `index` of the trace queue lives
+            hit = S->trace.hit[at];
+            dirPix = S->trace.rayD[at];
             pixelIdx = __float_as_uint(dirPix.w);
             const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
             bool miss, survived, needsPrevVertex;
             f3 bg = mk3(0.0f), t = mk3(0.0f);
-            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[index]; }, miss, bg, survived, t, inst,
+            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[at]; }, miss, bg, survived, t, inst,
                               needsPrevVertex);
-            if (needsPrevVertex) keep_previous_vertex(S, pixelIdx, S->trace.rayO[index]);
+            if (needsPrevVertex) keep_previous_vertex(S, pixelIdx, S->trace.rayO[at]);
             if (miss) {
                 float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
                 r.x += bg.x; r.y += bg.y; r.z += bg.z;
@@ -363,7 +374,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
         slots.alloc(want, slot);
         if (type >= 0) {
             const MaterialQueue mq = S->material[type];
-            const int sl = type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3]));
+            const int sl = regionBase + (type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3])));
             // the hit distance is of no use to the material kernels (they work from u, v): its slot carries the path index,
             // which saves a third array (4 B written and read per path, one load and one store instruction each)
             mq.hit[sl] = make_float4(__uint_as_float(pixelIdx), hit.y, hit.z, hit.w);
@@ -577,12 +588,14 @@ template <int TYPE, bool ORDERED>
 __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
-    const int size = C->materialSize[TYPE][bounce];
+    const QueueView in = queue_view(&C->region[0].materialSize[TYPE][bounce], S->queueShardCap);
+    const int size = in.total;
     if ((int)(blockIdx.x * blockDim.x) >= size) return;  // no tile for this workgroup (see logic_kernel)
     const uint32_t frame = S->frame->frameNumber;
     const MaterialQueue mq = S->material[TYPE];
     SlotAllocator<ORDERED, 2> slots;  // 0: shadow requests, 1: continuation rays
-    int* const ctr[2] = {&C->traceShadowSize[bounce], &C->traceSize[bounce]};
+    const int region = producer_region(S), regionBase = region * (int)S->queueShardCap;
+    int* const ctr[2] = {&C->region[region].traceShadowSize[bounce], &C->region[region].traceSize[bounce]};
     slots.init(ctr);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
@@ -594,8 +607,9 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         uint32_t pixelIdx = 0;
 
         if (requestIdx < size) {
-            const float4 hit = mq.hit[requestIdx];
-            const float4 dirInst = mq.dirInst[requestIdx];
+            const int at = in.slot(requestIdx);
+            const float4 hit = mq.hit[at];
+            const float4 dirInst = mq.dirInst[at];
             pixelIdx = __float_as_uint(hit.x);
             const uint32_t instanceIdx = __float_as_uint(dirInst.w);
             const float4 tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
@@ -616,7 +630,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         const bool want[2] = {wantShadow, wantTrace};
         int slot[2];
         slots.alloc(want, slot);
-        const int shadowSlot = slot[0], traceSlot = slot[1];
+        const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
             S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
@@ -651,7 +665,8 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
 {
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
     Counters* C = S->counters;
-    const int size = C->traceSize[firstBounce - 1];
+    const QueueView in = queue_view(&C->region[0].traceSize[firstBounce - 1], S->queueShardCap);
+    const int size = in.total;
     if (size <= 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -681,16 +696,17 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
             const int mine = base + (int)__popcll(needMask & laneLt);
             if (!alive && mine < size) {
                 index = mine;
-                const float4 hit = S->trace.hit[index];
-                const float4 dirPix = S->trace.rayD[index];
-                inst = S->trace.hitInst[index];
+                const int at = in.slot(mine);
+                const float4 hit = S->trace.hit[at];
+                const float4 dirPix = S->trace.rayD[at];
+                inst = S->trace.hitInst[at];
                 pixelIdx = __float_as_uint(dirPix.w);
                 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
                 hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
                 tp = S->throughputPdf[pixelIdx];
                 // the path's previous vertex: the origin of the ray that produced this hit, or, after a pass-through, what
                 // the logic step of the pass-through surface kept
-                ro = S->trace.rayO[index];
+                ro = S->trace.rayO[at];
                 if (ro.w != 0.0f) ro = S->rayOrigin[pixelIdx];
                 rad = S->radiance[pixelIdx];
                 bounce = firstBounce;

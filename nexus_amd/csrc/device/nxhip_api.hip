@@ -134,6 +134,11 @@ static void invalidate_graph(nxhip_ctx* c)
     c->graphTimerClass.clear();
 }
 
+// Slots per queue region for a capacity of n paths (nx_device.h, Counters): an even share, 64-aligned, plus the slack a region
+// may run over it; a queue buffer holds kQueueShards regions.
+static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) / (kQueueShards * 64)) * 64 + kQueueShardSlack; }
+static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
+
 // The device-state block of a slot: the scene part of the host mirror plus the slot's own queues, counters and frame words.
 static void compose_view(nxhip_ctx* c, PassSlot* s)
 {
@@ -149,6 +154,10 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     }
     v.counters = s->counters.as<Counters>();
     v.frame = s->frame.as<FrameState>();
+    // queue regions: eight, or one spanning the buffer when a single workgroup hands out slots in the reference's serial order
+    const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
+    v.queueShards = ordered ? 1u : (uint32_t)kQueueShards;
+    v.queueShardCap = (uint32_t)(ordered ? queue_buffer_slots(c->queueCapacity) : queue_region_cap(c->queueCapacity));
 }
 
 static int upload_state(nxhip_ctx* c)
@@ -177,8 +186,8 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
     static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
     DevBuf fresh[kCount];
-    for (int i = 0; i < kCount; i++)
-        if (!fresh[i].alloc(n * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    for (int i = 0; i < kCount; i++)  // the first three are per path, the rest are queues (regions + slack)
+        if (!fresh[i].alloc((i < 3 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
     NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // radiance
     NX_HIP(hipMemset(fresh[2].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
@@ -1289,8 +1298,11 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
-    const int og = ordered ? 1 : c->shadeBlocksPerCU * c->numCUs, ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
-    const int lg = ordered ? 1 : c->logicBlocksPerCU * c->numCUs, lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
+    // (grids of the producer kernels are multiples of the queue regions: workgroup w appends to region w % 8, and the bound on a
+    //  region's fill — nx_device.h — needs the grid-stride tiles to visit the regions evenly)
+    auto whole_regions = [](int g) { return (g + kQueueShards - 1) / kQueueShards * kQueueShards; };
+    const int og = ordered ? 1 : whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
+    const int lg = ordered ? 1 : whole_regions(c->logicBlocksPerCU * c->numCUs), lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
     const int tailFrom = tail_bounce(c);
     for (int bounce = 1; bounce <= pathLength; bounce++) {
         if (bounce == tailFrom) {  // the rest of the pass in one launch
@@ -1793,12 +1805,17 @@ int nxhip_read_queue_sizes(nxhip_ctx* c, nxhip_queue_sizes* out)
     NX_SYNC_ALL(c);
     Counters h;
     NX_HIP(hipMemcpy(&h, (c->lastRendered ? c->lastRendered : static_cast<PassSlot*>(c))->counters.p, sizeof h, hipMemcpyDeviceToHost));
-    std::memcpy(out->traceSize, h.traceSize, sizeof h.traceSize);
-    std::memcpy(out->traceShadowSize, h.traceShadowSize, sizeof h.traceShadowSize);
-    std::memcpy(out->diffuseSize, h.materialSize[NX_MAT_DIFFUSE], sizeof h.traceSize);
-    std::memcpy(out->plasticSize, h.materialSize[NX_MAT_PLASTIC], sizeof h.traceSize);
-    std::memcpy(out->dielectricSize, h.materialSize[NX_MAT_DIELECTRIC], sizeof h.traceSize);
-    std::memcpy(out->conductorSize, h.materialSize[NX_MAT_CONDUCTOR], sizeof h.traceSize);
+    std::memset(out, 0, sizeof *out);
+    for (int k = 0; k < kQueueShards; k++)  // a queue's size = the sum over its regions
+        for (int b = 0; b < kMaxBounceSlots; b++) {
+            const RegionCounters& r = h.region[k];
+            out->traceSize[b] += r.traceSize[b];
+            out->traceShadowSize[b] += r.traceShadowSize[b];
+            out->diffuseSize[b] += r.materialSize[NX_MAT_DIFFUSE][b];
+            out->plasticSize[b] += r.materialSize[NX_MAT_PLASTIC][b];
+            out->dielectricSize[b] += r.materialSize[NX_MAT_DIELECTRIC][b];
+            out->conductorSize[b] += r.materialSize[NX_MAT_CONDUCTOR][b];
+        }
     return NXHIP_OK;
 }
 
@@ -1825,15 +1842,44 @@ int nxhip_get_selected_instance(nxhip_ctx* c, int32_t* instanceIdx)
 
 // ---- kernel-level hooks -----------------------------------------------------------------------------
 
+// The ray-batch hooks number their n rays densely and cut them into one contiguous piece per queue region in use (as
+// generate_kernel does for the primary rays): ray i lives in slot (i / piece) * cap + i % piece.
+struct HookLayout {
+    uint32_t shards, cap, piece;
+    int32_t sizes[kQueueShards];
+};
+static HookLayout hook_layout(const nxhip_ctx* c, uint32_t n)
+{
+    HookLayout l{};
+    l.shards = c->view.queueShards;
+    l.cap = c->view.queueShardCap;
+    l.piece = ((n + l.shards * 64u - 1u) / (l.shards * 64u)) * 64u;
+    for (uint32_t k = 0; k < (uint32_t)kQueueShards; k++) l.sizes[k] = k < l.shards ? (int32_t)std::min(l.piece, n - std::min(n, k * l.piece)) : 0;
+    return l;
+}
+// host array (n elements of `elem` bytes, dense numbering) <-> a queue buffer's regions
+static int hook_copy(nxhip_ctx* c, const HookLayout& l, void* dev, void* host, size_t elem, bool toDevice)
+{
+    for (uint32_t k = 0; k < l.shards; k++) {
+        if (l.sizes[k] <= 0) continue;
+        char* d = static_cast<char*>(dev) + (size_t)k * l.cap * elem;
+        char* h = static_cast<char*>(host) + (size_t)k * l.piece * elem;
+        if (toDevice) NX_HIP(hipMemcpyAsync(d, h, (size_t)l.sizes[k] * elem, hipMemcpyHostToDevice, c->stream));
+        else NX_HIP(hipMemcpyAsync(h, d, (size_t)l.sizes[k] * elem, hipMemcpyDeviceToHost, c->stream));
+    }
+    return NXHIP_OK;
+}
+
 static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
 {
-    // queue size + zeroed fetch heads for the reserved bounce slot
+    // region sizes + zeroed fetch heads for the reserved bounce slot
     Counters* dc = c->counters.as<Counters>();
-    const int32_t size = (int32_t)n;
-    int32_t* sizeWord = anyHit ? &dc->traceShadowSize[kHookBounceSlot] : &dc->traceSize[kHookBounceSlot];
-    int32_t* heads = anyHit ? dc->shadowHead[kHookBounceSlot] : dc->traceHead[kHookBounceSlot];
-    NX_HIP(hipMemcpyAsync(sizeWord, &size, 4, hipMemcpyHostToDevice, c->stream));
-    NX_HIP(hipMemsetAsync(heads, 0, kXcds * 4, c->stream));
+    const HookLayout layout = hook_layout(c, n);
+    for (int k = 0; k < kQueueShards; k++) {
+        RegionCounters* r = &dc->region[k];
+        NX_HIP(hipMemcpyAsync(anyHit ? &r->traceShadowSize[kHookBounceSlot] : &r->traceSize[kHookBounceSlot], &layout.sizes[k], 4, hipMemcpyHostToDevice, c->stream));
+        NX_HIP(hipMemsetAsync(anyHit ? &r->shadowHead[kHookBounceSlot] : &r->traceHead[kHookBounceSlot], 0, 4, c->stream));
+    }
     Launch l = make_launch(trace_kernel_ptr(anyHit, c->statsEnabled), anyHit ? c->shadowBlocks : c->traceBlocks, kTraceBlockThreads,
                            anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot);
     const size_t before = c->timerPool.size();
@@ -1865,12 +1911,13 @@ try {
             o[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], 0.0f);
             d[i] = make_float4(r.direction[0], r.direction[1], r.direction[2], idx);
         }
-        NX_HIP(hipMemcpyAsync(c->trRayO.p, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        NX_HIP(hipMemcpyAsync(c->trRayD.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        const HookLayout l = hook_layout(c, n);
+        if ((rc = hook_copy(c, l, c->trRayO.p, o.data(), 16, true)) != NXHIP_OK) return rc;
+        if ((rc = hook_copy(c, l, c->trRayD.p, d.data(), 16, true)) != NXHIP_OK) return rc;
         rc = run_trace_chunk(c, false, n);
         if (rc != NXHIP_OK) return rc;
-        NX_HIP(hipMemcpyAsync(h.data(), c->trHit.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-        NX_HIP(hipMemcpyAsync(hi.data(), c->trHitInst.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = hook_copy(c, l, c->trHit.p, h.data(), 16, false)) != NXHIP_OK) return rc;
+        if ((rc = hook_copy(c, l, c->trHitInst.p, hi.data(), 4, false)) != NXHIP_OK) return rc;
         NX_SYNC_ALL(c);
         for (uint32_t i = 0; i < n; i++) {
             nx_hit& out = hits[first + i];
@@ -1911,9 +1958,10 @@ try {
             d[i] = make_float4(r.direction[0], r.direction[1], r.direction[2], idx);
         }
         // the kernel's tail adds the request's radiance to the path's pixel when unoccluded: radiance 1 into a zeroed buffer
-        NX_HIP(hipMemcpyAsync(c->shRayO.p, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        NX_HIP(hipMemcpyAsync(c->shRayD.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        NX_HIP(hipMemcpyAsync(c->shRadiance.p, rad.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        const HookLayout l = hook_layout(c, n);
+        if ((rc = hook_copy(c, l, c->shRayO.p, o.data(), 16, true)) != NXHIP_OK) return rc;
+        if ((rc = hook_copy(c, l, c->shRayD.p, d.data(), 16, true)) != NXHIP_OK) return rc;
+        if ((rc = hook_copy(c, l, c->shRadiance.p, rad.data(), 16, true)) != NXHIP_OK) return rc;
         NX_HIP(hipMemsetAsync(c->h.radiance, 0, (size_t)n * 16, c->stream));  // the buffer the kernel adds into (own or bound)
         rc = run_trace_chunk(c, true, n);
         if (rc != NXHIP_OK) return rc;
