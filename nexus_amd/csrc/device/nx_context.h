@@ -170,4 +170,8 @@ struct nxhip_ctx : nxd::PassSlot {
     bool traceGridForced = false;                            // NX_TRACE_BLOCKS_*: use them as they are
     int shadeBlocksPerCU = 10, logicBlocksPerCU = 2;  // grid-stride kernels: workgroups per CU
     bool serialShade = false;  // the four material kernels of a bounce as one graph branch instead of four
+    int parallelShade = -1;    // NX_SHADE_PARALLEL (tuning experiments only): 1 = parallel branches whatever the pass size
+    // material types the scene's materials use (bit NX_MAT_*): a type no material has can never receive a queue item, so its
+    // kernel is left out of the pass graph (a launch on the critical path of every bounce, however empty)
+    uint32_t materialTypeMask = 0xfu;
 };

@@ -394,6 +394,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
         }
         if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
+        if (const char* e = std::getenv("NX_SHADE_PARALLEL")) c->parallelShade = std::atoi(e);    // tuning experiments only
         if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
             const int n = std::atoi(e);
             if (n >= 1 && n <= 65536) { c->traceBlocks = c->shadowBlocks = n; c->traceGridForced = true; }
@@ -902,6 +903,13 @@ try {
     NX_HIP(hipMemcpy(c->materials.p, dev.data(), (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
     c->h.materials = c->materials.as<nx_material>();
     c->stateDirty = true;
+    uint32_t mask = 0u;
+    for (const nx_material& m : dev)
+        if (m.type >= 0 && m.type <= 3) mask |= 1u << m.type;
+    if (mask != c->materialTypeMask) {  // the pass graphs hold one material kernel per type in use
+        c->materialTypeMask = mask;
+        invalidate_graph(c);
+    }
     return NXHIP_OK;
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_set_materials: ") + e.what());
@@ -1236,7 +1244,10 @@ int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t fram
 // fraction of the image, so its 20-frame pass is a small one (8 ranks: 2.5 frames' worth of paths).
 double pass_size_in_frames(const nxhip_ctx* c) { return (double)c->localCount * (double)c->framesPerPass / (1920.0 * 1080.0); }
 
-bool serial_shade(const nxhip_ctx* c) { return c->serialShade || pass_size_in_frames(c) <= 4.0; }
+// (round 3: with only the material kernels of types in use in the graph and the slot counters spread over the queue regions, one
+//  branch is also the faster form for large passes — 64 frames per pass, 4 in flight: 1 988 against 1 974 Msamples/s — so it is
+//  what every pass uses; NX_SHADE_PARALLEL=1 brings the parallel branches back for experiments)
+bool serial_shade(const nxhip_ctx* c) { return c->parallelShade != 1; }
 
 // Passes in flight right now: kernel timing and the counting variant measure one pass at a time, and a caller-bound
 // radiance buffer exists once.
@@ -1311,11 +1322,14 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         }
         levels.push_back({make_launch(logic_kernel_ptr(ordered), lg, lb, NXHIP_K_LOGIC, S, bounce)});
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
+        // (only the types some material of the scene has: a queue no material feeds stays empty)
         std::vector<Launch> shade;
-        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
-        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_PLASTIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
-        shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIELECTRIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
-        if (c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_CONDUCTOR, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        auto in_use = [&](int type) { return (c->materialTypeMask >> type) & 1u; };
+        if (in_use(NX_MAT_DIFFUSE)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (in_use(NX_MAT_PLASTIC)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_PLASTIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (in_use(NX_MAT_DIELECTRIC)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIELECTRIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (in_use(NX_MAT_CONDUCTOR) && c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_CONDUCTOR, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
+        if (shade.empty()) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));  // (a level cannot be empty)
         // serial slot order needs the kernels one after the other; so do several passes in flight, which would otherwise ask
         // for four hardware queues per slot (the material kernels of one bounce serialise on the CUs anyway: each grid fills them)
         if (ordered || serial_shade(c)) for (auto& l : shade) levels.push_back({l});
