@@ -171,18 +171,20 @@ def stamp(phase):
     faulthandler.dump_traceback_later(_WATCHDOG_S, exit=True)
 
 
-def plan_schedule(steps, cap, passes_in_flight, explicit_pass_size, share):
-    """Pass size S and passes in flight R for a timed region of `steps` frames.  `cap`: the largest pass (frames), `share`: the
-    fraction of the image this process renders (1 / ranks).  Measured on the 20-frame region the driver times (gpurun_out
-    r3_01 / r3_05): a pass has a latency floor — nine trace levels, each as long as its slowest ray —
-    of about 5.7 ms however little it carries, so work is only worth cutting into passes in flight while every piece keeps
-    about four 1080p frames' worth of paths: the full frame runs five 4-frame passes (1 590 Msamples/s against 1 530 for one
-    20-frame pass), a rank of an 8-way split its 2.5 frames' worth as ONE pass (5.8 ms; cut five ways: 6.6 ms)."""
+def plan_schedule(steps, cap, passes_in_flight, explicit_pass_size, share, pixels=1920 * 1080):
+    """Pass size S and passes in flight R for a timed region of `steps` frames.  `cap`: the pass size of a long run (frames),
+    `share`: the fraction of the image this process renders (1 / ranks).  Measured (gpurun_out r3_15 / r3_16, DESIGN.md section
+    6): a region that starts and ends with an idle GPU is fastest as ONE pass, whatever its length — 20 / 40 / 64 / 128 frames:
+    1 654 / 1 835 / 1 964 / 1 963 Msamples/s as one pass against 1 622 / 1 803 / 1 877 / 1 907 for the best split into passes in
+    flight (passes that start together reach their drains together, and every pass pays its own nine trace levels' worth of
+    slowest rays) — as long as its paths fit the queues (128 full frames' worth: 72 GB).  A longer budget is a sequence of
+    `cap`-frame passes, four in flight: those do run out of phase, and the drain of one is filled by the bulk of the next
+    (512 frames: 1 990 against 1 905 with one at a time)."""
+    single = int(128 * (1920 * 1080) / (pixels * share))  # frames whose paths fill the queues of 128 full 1080p frames
     if explicit_pass_size:
         S = max(1, min(cap, steps))
     else:
-        pieces = max(1, min(5, int(steps * share / 4.0)))
-        S = cap if steps > cap else max(1, -(-steps // pieces))  # (a budget of more than one full pass keeps full passes)
+        S = steps if steps <= single else cap
     n_passes = -(-steps // S)
     small = S * share <= 4.0
     R = passes_in_flight if passes_in_flight else (6 if small else 4)
@@ -256,7 +258,7 @@ def main():
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
     explicit_fpp = args.frames_per_pass is not None
     cap = max(1, min((args.frames_per_pass or (16 if big else 64)) * world, 512))
-    S, R, n_passes = plan_schedule(args.steps, cap, args.passes_in_flight, explicit_fpp, 1.0 / world)
+    S, R, n_passes = plan_schedule(args.steps, cap, args.passes_in_flight, explicit_fpp, 1.0 / world, args.width * args.height)
     pass_sizes = [int(x) for x in args.pass_sizes.split(",")] if args.pass_sizes else None
     if pass_sizes:
         if sum(pass_sizes) != args.steps or min(pass_sizes) < 1:
@@ -396,11 +398,11 @@ def main():
         """`reps` timed regions of exactly `steps` frames (pass sizes: schedule(steps, size)), after `warmup` untimed frames in
         passes of the same sizes — so that every slot has instantiated the graph the timed passes replay (a pass of another size
         class would be a different graph: nxhip keeps one instance per shape) and touched its queues."""
-        if R > 1:
-            for n in schedule(max(warmup, 1), size)[:1] * R:  # every slot once, at the timed pass size
-                step(n)
-            sync()
-            ctx.reset_frame_number()
+        # every slot once at the timed pass size (one slot: the context itself), then the image starts over
+        for n in schedule(steps, size)[:1] * max(R, 1):
+            step(n)
+        sync()
+        ctx.reset_frame_number()
         for n in schedule(warmup, size):
             step(n)
         sync()
@@ -436,7 +438,7 @@ def main():
         # (an explicit --frames-per-pass is taken as the rank's pass size itself, for sweeps)
         capN = max(1, min(args.frames_per_pass if explicit_fpp else (16 if big else 64) * N, 512))
         S_full, R_full = S, R
-        S, R, _ = plan_schedule(args.steps, capN, args.passes_in_flight, explicit_fpp, 1.0 / N)
+        S, R, _ = plan_schedule(args.steps, capN, args.passes_in_flight, explicit_fpp, 1.0 / N, W * H)
         sync()
         ctx.set_pixel_map(pm)
         ctx.set_frames_per_pass(S)

@@ -19,6 +19,9 @@ public:
     PathTracer& operator=(const PathTracer&) = delete;
 
     void Reset();
+    // the queue / path-state buffers go back to the device allocator (the reference frees them in Reset and on resize,
+    // PathTracer.cpp:31, :300); the next Render() brings them back
+    void FreeDeviceBuffers();
     void ResetFrameNumber();
     void Render(const Scene& scene);  // one frame: generate, trace, pathLength x (logic, shade, trace, shadow), accumulate
     void OnResize(uint32_t width, uint32_t height);

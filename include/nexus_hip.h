@@ -60,6 +60,12 @@ int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCo
  * the SAH builder's (another tree); hit records are the same up to equidistant ties, traversal visits more nodes.  Returns
  * the BLAS id like nxhip_upload_blas. */
 int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount, int32_t *blasId);
+/* Which binary tree the device builders (nxhip_build_blas, nxhip_rebuild_tlas) collapse into 8-wide nodes.
+ * clusteringRadius > 0 (default 16): parallel locally-ordered clustering — the Morton-sorted primitives are merged bottom-up,
+ * every cluster pairing with the neighbour within `radius` places whose union has the smallest surface area; a few dozen
+ * rounds, tree quality close to the host's binned-SAH build.  0: the binary radix tree of the Morton codes (LBVH): one
+ * launch, a tree that visits more nodes per ray on irregular geometry.  Either way the result is a valid conservative CWBVH. */
+int nxhip_set_device_builder(nxhip_ctx *ctx, int clusteringRadius);
 /* Read a BLAS's nodes / primitive index list back (either may be NULL; *nodeCount = nodes it has). */
 int nxhip_read_blas(nxhip_ctx *ctx, int32_t blasId, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *primIdx, uint32_t primCapacity,
                     uint32_t *nodeCount);
@@ -171,6 +177,10 @@ int nxhip_read_rgba8(nxhip_ctx *ctx, uint32_t *dst);
 int nxhip_write_accumulation(nxhip_ctx *ctx, const float *src, uint32_t frameNumber);
 /* Device pointers for zero-copy consumers on the same GPU (e.g. an RCCL gather of radiance tiles):
  * float4 per local pixel (xyz = radiance, w unused).  Valid until the next resize / set_pixel_map. */
+/* PathTracer::FreeDeviceBuffers (Renderer/PathTracer.cpp:35-92): give the path-state and queue buffers of every pass slot back
+ * (about 0.28 KB per path and slot: 36 GB at 1080p x 64 frames per pass).  The accumulated image, the scene and the
+ * configuration stay; the next nxhip_render_frame (or ray-batch hook) allocates what it needs again. */
+int nxhip_release_queues(nxhip_ctx *ctx);
 void *nxhip_radiance_device_ptr(nxhip_ctx *ctx);
 void *nxhip_accumulation_device_ptr(nxhip_ctx *ctx);
 /* Make the context write its per-frame radiance into caller-owned device memory (float4[capacity], capacity >=

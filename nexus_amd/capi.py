@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index",
+    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
@@ -500,6 +500,14 @@ class Context:
         idx = np.zeros(tri_count, dtype=np.uint32)
         check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
         return nodes, idx
+
+    def set_device_builder(self, clustering_radius=16):
+        """device BLAS / TLAS builders: clustering (PLOC) with this search radius, 0 = radix tree (LBVH)"""
+        check(self.L.nxhip_set_device_builder(self.h, int(clustering_radius)), "nxhip_set_device_builder")
+
+    def release_queues(self):
+        """PathTracer::FreeDeviceBuffers: queue / path-state buffers back to the allocator until the next render"""
+        check(self.L.nxhip_release_queues(self.h), "nxhip_release_queues")
 
     def rebuild_tlas(self, instances):
         """build the TLAS on the device (LBVH over the instances' world boxes) and install it; returns (nodes, instance index list)"""

@@ -144,6 +144,7 @@ struct nxhip_ctx : nxd::PassSlot {
     nxd::DevBuf pixelMap, accumulation, rgba8;
     nxd::DevBuf traceStats;
 
+    int deviceBuilderRadius = 16;  // nxhip_build_blas / nxhip_rebuild_tlas: neighbour search radius of the clustering, 0 = radix tree (LBVH)
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
     bool statsEnabled = false;
     bool timingEnabled = false;

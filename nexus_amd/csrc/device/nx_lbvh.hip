@@ -140,8 +140,9 @@ struct Bvh2 {
     int* left;     // [n-1] child node ids (>= n-1: leaf)
     int* right;
     int* parent;   // [2n-1]
-    int* first;    // [n-1] range of sorted positions covered by the internal node
+    int* first;    // [n-1] range of sorted positions covered by the internal node (radix tree only)
     int* last;
+    int* count;    // [n-1] primitives under the internal node
     Box3* box;     // [2n-1]
     int* arrived;  // [n-1]
 };
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long 
         t.right[i] = rightNode;
         t.first[i] = lo;
         t.last[i] = hi;
+        t.count[i] = hi - lo + 1;
         t.parent[leftNode] = i;
         t.parent[rightNode] = i;
         if (i == 0) t.parent[0] = -1;
@@ -204,6 +206,82 @@ __global__ void __launch_bounds__(kBlock) fit_kernel(const Box3* __restrict__ tr
             node = t.parent[node];
         }
     }
+}
+
+// ---- 4b. the alternative to steps 3-4: parallel locally-ordered clustering (Meister & Bittner 2018).  The sorted primitives
+// start as clusters; every round each cluster looks `radius` places to either side along the Morton order for the neighbour whose
+// union with it has the smallest surface area, pairs that chose each other merge into a new BVH2 node, and the survivors are
+// compacted (order preserved).  Bottom-up and surface-area driven, the tree comes close to a top-down SAH build where the
+// radix tree only follows the bits of the space-filling curve — at the price of a few dozen rounds instead of one launch.
+// Node ids as in the radix tree: leaf k = n - 1 + k; internal nodes are numbered downwards from n - 2 so that the last
+// merge — the root — is node 0, which the collapse starts from.
+__device__ __forceinline__ float union_half_area(const Box3& a, const Box3& b)
+{
+    const float ex = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), ey = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]), ez = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return ex * ey + ey * ez + ex * ez;
+}
+
+__global__ void __launch_bounds__(kBlock) ploc_leaves_kernel(const Box3* __restrict__ primBox, const uint32_t* __restrict__ order, const int n, Bvh2 t, int* __restrict__ cluster)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        t.box[(n - 1) + k] = primBox[order[k]];
+        cluster[k] = (n - 1) + k;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ploc_neighbour_kernel(const Bvh2 t, const int* __restrict__ cluster, const int m, const int radius, int* __restrict__ nearest)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const Box3 mine = t.box[cluster[i]];
+        float best = 0.0f;
+        int bestLo = -1, bestHi = -1, pick = -1;
+        const int from = max(0, i - radius), to = min(m - 1, i + radius);
+        for (int j = from; j <= to; j++) {
+            if (j == i) continue;
+            float a = union_half_area(mine, t.box[cluster[j]]);
+            if (!(a == a)) a = 3.0e38f;  // a box with NaNs pairs up last
+            // ties are broken on the PAIR (smaller index, then larger), so that the two members of the best pair pick each other:
+            // every round then merges at least one pair
+            const int lo = min(i, j), hi = max(i, j);
+            if (pick < 0 || a < best || (a == best && (lo < bestLo || (lo == bestLo && hi < bestHi)))) {
+                best = a; bestLo = lo; bestHi = hi; pick = j;
+            }
+        }
+        nearest[i] = pick;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ploc_merge_kernel(Bvh2 t, const int n, const int* __restrict__ cluster, const int* __restrict__ nearest, const int m, int* __restrict__ merged,
+                                                            int* __restrict__ keep, int* __restrict__ mergeCounter)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int j = nearest[i];
+        int node = cluster[i], kept = 1;
+        if (j >= 0 && nearest[j] == i) {
+            if (i < j) {
+                const int a = cluster[i], b = cluster[j];
+                const int id = (n - 2) - atomicAdd(mergeCounter, 1);
+                const Box3 ba = t.box[a], bb = t.box[b];
+                Box3 u;
+                for (int x = 0; x < 3; x++) { u.lo[x] = fminf(ba.lo[x], bb.lo[x]); u.hi[x] = fmaxf(ba.hi[x], bb.hi[x]); }
+                t.left[id] = a;
+                t.right[id] = b;
+                t.box[id] = u;
+                t.count[id] = (a >= n - 1 ? 1 : t.count[a]) + (b >= n - 1 ? 1 : t.count[b]);
+                node = id;
+            } else {
+                kept = 0;  // absorbed by its partner
+            }
+        }
+        merged[i] = node;
+        keep[i] = kept;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ploc_compact_kernel(const int* __restrict__ merged, const int* __restrict__ keep, const int* __restrict__ offset, const int m, int* __restrict__ next)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        if (keep[i]) next[offset[i]] = merged[i];
 }
 
 // ---- 5. collapse into 8-wide nodes, one level per launch
@@ -288,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
         for (int s = 0; s < 8; s++) {
             if (childAt[s] < 0) continue;
             const int c = child[childAt[s]];
-            const int tris = c >= n - 1 ? 1 : t.last[c] - t.first[c] + 1;
+            const int tris = c >= n - 1 ? 1 : t.count[c];
             if (tris > 3) innerCount++;
             else primCount += (uint32_t)tris;
         }
@@ -323,18 +401,28 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
             node.qhix[s] = (uint8_t)quantize(ceilf((b.hi[0] - nb.lo[0]) * invScale[0]));
             node.qhiy[s] = (uint8_t)quantize(ceilf((b.hi[1] - nb.lo[1]) * invScale[1]));
             node.qhiz[s] = (uint8_t)quantize(ceilf((b.hi[2] - nb.lo[2]) * invScale[2]));
-            const int firstPos = c >= n - 1 ? c - (n - 1) : t.first[c];
-            const int tris = c >= n - 1 ? 1 : t.last[c] - t.first[c] + 1;
+            const int tris = c >= n - 1 ? 1 : t.count[c];
             if (tris > 3) {
                 node.meta[s] = (uint8_t)(0x20 | (24 + s));
                 node.imask |= (uint8_t)(1u << s);
                 nextWork[workBase + innerSeen] = WorkItem{c, childBase + innerSeen};
                 innerSeen++;
             } else {
+                // the (at most three) primitives under this child, left to right: a subtree of at most two internal nodes
+                int leaves[3], found = 0, todo[3], top = 0;
+                todo[top++] = c;
+                while (top > 0 && found < 3) {
+                    const int x = todo[--top];
+                    if (x >= n - 1) leaves[found++] = x - (n - 1);
+                    else {
+                        todo[top++] = t.right[x];
+                        todo[top++] = t.left[x];
+                    }
+                }
                 uint32_t unary = 0;
                 for (int j = 0; j < tris; j++) {
                     unary |= 1u << (j + 5);
-                    primIdx[primBase + primSeen + (uint32_t)j] = order[firstPos + j];
+                    primIdx[primBase + primSeen + (uint32_t)j] = order[leaves[j]];
                 }
                 node.meta[s] = (uint8_t)(unary | primSeen);
                 primSeen += (uint32_t)tris;
@@ -396,7 +484,7 @@ int grid_for(uint32_t n, int cus) { return (int)std::min<uint32_t>((n + kBlock -
 
 // The build from primitive boxes on: Morton codes, sort, radix tree, bounds, collapse.  `triBox` / `bounds` (centroid bounds,
 // ordered-uint encoded) are on the device and filled by a kernel already queued on the stream.  primIdx: n entries.
-static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bounds, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
+static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bounds, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
@@ -414,15 +502,50 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     if (!sortTemp.alloc(std::max<size_t>(tempBytes, 16))) return NXHIP_ERR_HIP;
     NX_HIP(rocprim::radix_sort_pairs(sortTemp.p, tempBytes, codes.as<unsigned long long>(), codesSorted.as<unsigned long long>(), order.as<uint32_t>(), orderSorted.as<uint32_t>(), n, 0, 63, st));
 
-    // binary radix tree + bounds
+    // the binary tree over the sorted primitives: radix tree + bottom-up bounds, or locally-ordered clustering
     const size_t inner = (size_t)n - 1, all = 2 * (size_t)n - 1;
-    DevBuf left, right, parent, first, last, box, arrived;
-    if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !box.alloc(all * sizeof(Box3)) ||
-        !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
-    NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
-    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), box.as<Box3>(), arrived.as<int>()};
-    radix_tree_kernel<<<grid_for(n - 1, cus), kBlock, 0, st>>>(codesSorted.as<unsigned long long>(), (int)n, t);
-    fit_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), orderSorted.as<uint32_t>(), (int)n, t);
+    DevBuf left, right, parent, first, last, count, box, arrived;
+    if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !count.alloc(inner * 4) ||
+        !box.alloc(all * sizeof(Box3)) || !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
+    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>()};
+    if (plocRadius <= 0) {
+        NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
+        radix_tree_kernel<<<grid_for(n - 1, cus), kBlock, 0, st>>>(codesSorted.as<unsigned long long>(), (int)n, t);
+        fit_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), orderSorted.as<uint32_t>(), (int)n, t);
+    } else {
+        DevBuf clusterA, clusterB, nearest, merged, keep, offset, mergeCounter, scanTemp;
+        if (!clusterA.alloc((size_t)n * 4) || !clusterB.alloc((size_t)n * 4) || !nearest.alloc((size_t)n * 4) || !merged.alloc((size_t)n * 4) || !keep.alloc((size_t)n * 4) ||
+            !offset.alloc((size_t)n * 4) || !mergeCounter.alloc(4)) return NXHIP_ERR_HIP;
+        size_t scanBytes = 0;
+        NX_HIP(rocprim::exclusive_scan(nullptr, scanBytes, keep.as<int>(), offset.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
+        if (!scanTemp.alloc(std::max<size_t>(scanBytes, 16))) return NXHIP_ERR_HIP;
+        NX_HIP(hipMemsetAsync(mergeCounter.p, 0, 4, st));
+        int* cur = clusterA.as<int>();
+        int* nxt = clusterB.as<int>();
+        ploc_leaves_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), orderSorted.as<uint32_t>(), (int)n, t, cur);
+        int m = (int)n;
+        for (int round = 0; m > 1; round++) {
+            if (round > 4096) {
+                set_error("lbvh_build: the clustering does not terminate");
+                return NXHIP_ERR_INVALID;
+            }
+            ploc_neighbour_kernel<<<grid_for((uint32_t)m, cus), kBlock, 0, st>>>(t, cur, m, plocRadius, nearest.as<int>());
+            ploc_merge_kernel<<<grid_for((uint32_t)m, cus), kBlock, 0, st>>>(t, (int)n, cur, nearest.as<int>(), m, merged.as<int>(), keep.as<int>(), mergeCounter.as<int>());
+            NX_HIP(rocprim::exclusive_scan(scanTemp.p, scanBytes, keep.as<int>(), offset.as<int>(), 0, (size_t)m, rocprim::plus<int>(), st));
+            ploc_compact_kernel<<<grid_for((uint32_t)m, cus), kBlock, 0, st>>>(merged.as<int>(), keep.as<int>(), offset.as<int>(), m, nxt);
+            int tail[2];
+            NX_HIP(hipMemcpyAsync(&tail[0], offset.as<int>() + (m - 1), 4, hipMemcpyDeviceToHost, st));
+            NX_HIP(hipMemcpyAsync(&tail[1], keep.as<int>() + (m - 1), 4, hipMemcpyDeviceToHost, st));
+            NX_HIP(hipStreamSynchronize(st));
+            const int next = tail[0] + tail[1];
+            if (next >= m || next < 1) {
+                set_error("lbvh_build: a clustering round merged nothing");
+                return NXHIP_ERR_INVALID;
+            }
+            m = next;
+            std::swap(cur, nxt);
+        }
+    }
 
     // collapse.  Every BVH8 node but the root stands for a distinct internal BVH2 node, so n - 1 nodes cannot be exceeded
     // (typical use: 0.1 - 0.2 n); the caller shrinks the array to the used size.
@@ -464,7 +587,7 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
 
 // Builds nodes / primIdx / isect for the `n` triangles at dTris (device).  All device buffers come back through the
 // arguments; *nodeCount = nodes used.
-int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount)
+int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
@@ -473,7 +596,7 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
     tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
-    const int rc = lbvh_from_boxes(c, triBox, bounds, n, nodes, primIdx, nodeCount);
+    const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
     NX_HIP(hipStreamSynchronize(st));
@@ -483,7 +606,7 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes
 
 // The same builder over instance boxes: a TLAS for `n` instances (device array, world bounds filled in).  nodes / primIdx
 // (the TLAS's instance index list, leaf order) stay on the device; *nodeCount = nodes used.
-int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
@@ -492,7 +615,7 @@ int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n,
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
     instance_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dInstances, n, box.as<Box3>(), bounds.as<uint32_t>());
-    const int rc = lbvh_from_boxes(c, box, bounds, n, nodes, primIdx, nodeCount);
+    const int rc = lbvh_from_boxes(c, box, bounds, n, plocRadius, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     NX_HIP(hipStreamSynchronize(st));
     NX_HIP(hipGetLastError());

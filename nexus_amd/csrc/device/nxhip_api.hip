@@ -26,8 +26,8 @@ const void* bsdf_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
-int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
-int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount);
+int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount);
 
 static thread_local std::string g_lastError;
 
@@ -624,7 +624,7 @@ try {
     NX_HIP(hipMemcpy(b.tris.p, tris, (size_t)triCount * sizeof(nx_triangle), hipMemcpyHostToDevice));
     DevBuf wide;
     uint32_t nodeCount = 0;
-    const int rc = lbvh_build(c, b.tris.as<nx_triangle>(), triCount, wide, b.triIdx, b.isect, &nodeCount);
+    const int rc = lbvh_build(c, b.tris.as<nx_triangle>(), triCount, c->deviceBuilderRadius, wide, b.triIdx, b.isect, &nodeCount);
     if (rc != NXHIP_OK) return rc;
     NX_ALLOC(b.nodes, (size_t)nodeCount * sizeof(nx_bvh8_node));  // the builder's array is sized for the worst case
     NX_HIP(hipMemcpy(b.nodes.p, wide.p, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToDevice));
@@ -635,6 +635,14 @@ try {
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_build_blas: ") + e.what());
     return NXHIP_ERR_INVALID;
+}
+
+int nxhip_set_device_builder(nxhip_ctx* c, int clusteringRadius)
+{
+    NX_CHECK_CTX(c);
+    if (clusteringRadius < 0 || clusteringRadius > 256) return fail_invalid("nxhip_set_device_builder: radius must be in [0, 256]");
+    c->deviceBuilderRadius = clusteringRadius;
+    return NXHIP_OK;
 }
 
 int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t nodeCapacity, uint32_t* primIdx, uint32_t primCapacity, uint32_t* nodeCount)
@@ -777,7 +785,7 @@ try {
     NX_ALLOC(dInst, (size_t)instanceCount * sizeof(nx_bvh_instance));
     NX_HIP(hipMemcpy(dInst.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
     uint32_t nodeCount = 0;
-    int rc = lbvh_build_tlas(c, dInst.as<nx_bvh_instance>(), instanceCount, wide, primIdx, &nodeCount);
+    int rc = lbvh_build_tlas(c, dInst.as<nx_bvh_instance>(), instanceCount, c->deviceBuilderRadius, wide, primIdx, &nodeCount);
     if (rc != NXHIP_OK) return rc;
     // The tree is a few hundred nodes per thousand instances: it comes back once so that nxhip_set_tlas — range checks, the
     // traversal records in leaf order, the schedule of the device-side refit — installs it like any other TLAS.
@@ -1667,6 +1675,21 @@ int nxhip_set_frames_per_pass(nxhip_ctx* c, uint32_t frames)
     c->pathCount = c->localCount * frames;
     c->h.framesPerPass = frames;
     c->h.pathCount = c->pathCount;
+    return NXHIP_OK;
+}
+
+int nxhip_release_queues(nxhip_ctx* c)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    if (c->radianceBoundCapacity != 0) return fail_invalid("nxhip_release_queues: a caller-owned radiance buffer is bound (nxhip_bind_radiance(ctx, NULL, 0) first)");
+    c->pending.clear();
+    for (uint32_t k = 0; k < slot_count(c); k++) {
+        PassSlot* q = slot_at(c, k);
+        q->awaitingAccumulate = false;
+        if (q->pathCapacity) release_slot_queues(c, q);
+    }
     return NXHIP_OK;
 }
 

@@ -24,9 +24,18 @@ PathTracer::~PathTracer() { nxhip_destroy(m_Ctx); }
 
 void PathTracer::Reset()
 {
+    // A tile split is set up for one viewport: its tiles, gather buffers and (across ranks) the collective's element count no
+    // longer fit another.  It is shut down here; EnableTileSplit sets it up again for the new size, on every rank.
+    if (m_TileSplit) {
+        Check(nxhip_mgpu_shutdown(m_Ctx), "nxhip_mgpu_shutdown");
+        m_TileSplit = false;
+        m_Rank = 0;
+    }
     Check(nxhip_resize(m_Ctx, m_ViewportWidth, m_ViewportHeight), "nxhip_resize");
     m_FrameNumber = 0;
 }
+
+void PathTracer::FreeDeviceBuffers() { Check(nxhip_release_queues(m_Ctx), "nxhip_release_queues"); }
 
 void PathTracer::ResetFrameNumber()
 {

@@ -211,3 +211,52 @@ def test_a_bvh_that_is_not_a_tree_ends_in_an_error_status_not_in_a_hang(gpu_ctx_
     ctx.debug_write_blas_node(0, 0, nodes[0])
     assert SH.hit_records_equal(ctx.trace_batch(rays), want)
     ctx.sync()
+
+
+def test_released_queues_come_back_with_the_next_render(gpu_ctx_factory):
+    """nxhip_release_queues (PathTracer::FreeDeviceBuffers): the image, the scene and the frame count survive, rendering and
+    the ray-batch hook allocate again on demand; the same holds for the slots of passes in flight."""
+    import numpy as np
+    from nexus_amd import pod, scenegen
+    from tests import scene_helpers as SH
+
+    W = H = 96
+    scene = SH.cornell_scene(W, H, path_length=3)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    for _ in range(2):
+        ctx.render_frame()
+        ctx.accumulate()
+    two = ctx.read_accumulation()
+    ctx.release_queues()
+    assert np.array_equal(ctx.read_accumulation().view(np.uint32), two.view(np.uint32))
+    rays = scenegen.interior_rays(2048, seed=2, extent=0.9)
+    rays["origin"][:, 1] += 1.0
+    assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
+    ctx.release_queues()
+    ctx.render_frame()
+    ctx.accumulate()
+    three = ctx.read_accumulation()
+    # the same three frames without the releases in between
+    ref = gpu_ctx_factory(W, H)
+    scene.upload(ref)
+    ref.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    for _ in range(3):
+        ref.render_frame()
+        ref.accumulate()
+    assert np.array_equal(three.view(np.uint32), ref.read_accumulation().view(np.uint32))
+    # passes in flight: slot 0 gives its queues back while the passes render in the extra slots, and takes them again for the hook
+    ctx.set_passes_in_flight(3)
+    for _ in range(4):
+        ctx.render_frame()
+        ctx.accumulate()
+    assert SH.hit_records_equal(ctx.trace_batch(rays), scene.oracle().trace_closest(rays))
+    ctx.set_passes_in_flight(1)
+    ctx.render_frame()
+    ctx.accumulate()
+    ref.set_passes_in_flight(1)
+    for _ in range(5):
+        ref.render_frame()
+        ref.accumulate()
+    assert np.array_equal(ctx.read_accumulation().view(np.uint32), ref.read_accumulation().view(np.uint32))

@@ -50,3 +50,31 @@ def test_single_rank_rccl_gather_equals_the_local_image(gpu_ctx_factory):
     assert np.array_equal(got_acc.view(np.uint32), want_acc.view(np.uint32))
     assert np.array_equal(got_px, want_px)
     ctx.mgpu_shutdown()
+
+
+@pytest.mark.gpu
+def test_a_resize_after_the_tile_split_is_refused_by_the_gather_not_launched(gpu_ctx_factory):
+    """nxhip_resize / nxhip_set_pixel_map change the pixel set the split's gather buffers and maps were built for.
+    The gather then returns an error status instead of launching a collective and compose kernels with stale sizes."""
+    from tests import scene_helpers as SH
+
+    W, H = 64, 40
+    scene = SH.cornell_scene(W, H, path_length=2)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.mgpu_init(1, 0, capi.mgpu_unique_id(), 5)
+    ctx.render_frame()
+    ctx.accumulate()
+    ctx.mgpu_gather()
+    ctx.resize(W, 2 * H)
+    with pytest.raises(capi.NexusError, match="changed after the tile split"):
+        ctx.mgpu_gather()
+    ctx.mgpu_shutdown()
+    ctx.mgpu_init(1, 0, capi.mgpu_unique_id(), 5)  # set up again for the new size: works
+    cam = capi.camera_init((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, W, 2 * H, 5.0, 0.0)
+    ctx.set_camera(cam)
+    ctx.render_frame()
+    ctx.accumulate()
+    ctx.mgpu_gather()
+    assert len(ctx.mgpu_read_rgba8()) == W * 2 * H
+    ctx.mgpu_shutdown()
