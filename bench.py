@@ -7,12 +7,14 @@
     python bench.py --config 5        # configs[4]: the 9.9 M-triangle interior whose traversal streams from HBM (1 GPU)
 
 A "step" is one frame = one primary sample per pixel through the whole hot path (generate, trace, then pathLength x
-(logic, shade x4 + NEE, trace || shadow trace), accumulate).  Frames are rendered in passes of up to --frames-per-pass
-frames (one hipGraph replay per pass; each frame keeps its own frame number and RNG streams and the result is
-bit-identical to rendering them one by one); exactly K frames are timed, the last pass being shorter if need be.  The
-K-frame region is timed --reps times, each bracketed by a barrier + device synchronisation, and the MEDIAN is reported
-(`steps` stays K, `ms_per_step` = median / K; every repetition is listed in `config.rep_ms`): at the driver's K = 20 a
-region is one 30 ms graph replay, and single replays vary by several per cent.  Msamples/s is the reference viewer's
+(logic, shade per material type + NEE, trace || shadow trace), accumulate).  Frames are rendered in passes (one hipGraph
+replay per pass; each frame keeps its own frame number and RNG streams and the result is bit-identical to rendering them
+one by one); exactly K frames are timed.  plan_schedule() chooses the pass size from measurements: a budget that fits the
+queues (up to 128 full frames' worth of paths) is ONE pass, a longer one is a sequence of --frames-per-pass (64) frame
+passes, four in flight.  The K-frame region is timed --reps times, each bracketed by a barrier + device synchronisation,
+and the MEDIAN is reported (`steps` stays K, `ms_per_step` = median / K; every repetition is listed in `config.rep_ms`):
+at the driver's K = 20 a region is one 24 ms graph replay, and single replays vary by several per cent.  Phase stamps go
+to stderr, and a watchdog dumps the Python stacks if a phase takes longer than NX_BENCH_WATCHDOG (150) seconds.  Msamples/s is the reference viewer's
 "Megarays/sec": width * height * frames / seconds / 1e6 (/root/reference/Nexus/src/Renderer/Panels/MetricsPanel.cpp:28,35,56).
 Scene and BVH live in HBM before the timed region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every
 rank renders AND accumulates its tiles with the scene replicated, and the accumulated tiles (16 B per pixel) are gathered
@@ -39,8 +41,12 @@ Rank 0 prints ONE JSON line.  It also carries
                                 come from the Infinity Cache, 1.0 from HBM).  VALU issue and the gather share the kernel's
                                 time nearly additively: neither fraction alone can approach 1.
                  `bound` names the ceiling with the larger fraction; `frac`, `achieved`, `peak`, `unit` belong to it.
+  roofline.classes : the second kernel class — logic and the material (shade) kernels — per queue item: HBM-side bytes and VALU
+                 instructions from the same committed counter passes, against 8 TB/s and the issue rate.
   cpu_baseline : the CPU oracle (port of the reference algorithm) on full frames of the same scene, timed on the
-                 host cores of this box.  A reported baseline, not a target.
+                 host cores of this box (trace, logic and shade threaded).  A reported baseline, not a target.
+  emulated_rank (--emulate-rank-of N): rank 0's share of an N-way tile split rendered in this process, against full / N.
+Counter constants carry the hash of the kernel sources they were measured on; a mismatch reports `traffic: null` and why.
 """
 import argparse
 import json
@@ -144,8 +150,8 @@ def cpu_baseline(sc, width, height, threads, frames, single_core=True):
         w.accumulate(f)
     dt = time.time() - t0
     out = dict(value=width * height * frames / dt / 1e6, unit="Msamples/s", cores=threads, kind="port",
-               sample="%d full frame%s (%dx%d, same scene/camera/settings, frames 1..%d); both trace passes on %d pthreads, logic/shade serial; %.1f s"
-                      % (frames, "s" if frames > 1 else "", width, height, frames, threads, dt))
+               sample="%d full frame%s (%dx%d, same scene/camera/settings, frames 1..%d); trace, logic and shade on %d pthreads (slots handed out in item order afterwards: "
+                      "bit-identical to the serial run), generate / accumulate serial; %.1f s" % (frames, "s" if frames > 1 else "", width, height, frames, threads, dt))
     if single_core:
         # one more frame on a single thread: the 1-core figure SURVEY.md section 8d asks for beside the all-cores one
         t0 = time.time()
@@ -218,8 +224,9 @@ def main():
                     help="N: after the full-frame measurement, render rank 0's share of an N-way tile split (same tiles, pass sizes and passes in flight as a "
                          "rank of bench.py --gpus N, no collective) in this process and report per_rank_ms beside full_ms / N: the communication-free "
                          "scaling efficiency a 1-GPU box can measure")
-    ap.add_argument("--from-obj", action="store_true", help="config 2: write the mesh as a Wavefront .obj, read it back with the product's OBJLoader and assert that "
-                                                            "the triangles equal the in-memory ones (untimed; configs[1] says 'single 1M-triangle .obj mesh')")
+    ap.add_argument("--no-obj-check", action="store_true", help="config 2: skip the .obj round trip.  By default the mesh is written as a Wavefront .obj, read back with the "
+                                                                "product's OBJLoader and required to equal the in-memory triangles the BVH was built from (untimed, ~16 s; "
+                                                                "configs[1] says 'single 1M-triangle .obj mesh')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -280,7 +287,7 @@ def main():
     sc, workload_name, t_build = build_workload(args)
     stamp("scene built on the host (%.1f s)" % t_build)
     obj_check = None
-    if args.from_obj:
+    if args.config == 2 and not args.no_obj_check:
         obj_check = workloads.check_obj_round_trip(sc)
         stamp("mesh written as .obj, read back by OBJLoader and compared")
     if os.environ.get("NX_BENCH_NO_MIS"):  # experiment only: how much of the shade kernels is next-event estimation

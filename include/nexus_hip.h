@@ -61,10 +61,13 @@ int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCo
  * the BLAS id like nxhip_upload_blas. */
 int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount, int32_t *blasId);
 /* Which binary tree the device builders (nxhip_build_blas, nxhip_rebuild_tlas) collapse into 8-wide nodes.
- * clusteringRadius > 0 (default 16): parallel locally-ordered clustering — the Morton-sorted primitives are merged bottom-up,
- * every cluster pairing with the neighbour within `radius` places whose union has the smallest surface area; a few dozen
- * rounds, tree quality close to the host's binned-SAH build.  0: the binary radix tree of the Morton codes (LBVH): one
- * launch, a tree that visits more nodes per ray on irregular geometry.  Either way the result is a valid conservative CWBVH. */
+ * 0 (default): the binary radix tree of the Morton codes (LBVH), one launch.  clusteringRadius > 0: parallel locally-ordered
+ * clustering — the Morton-sorted primitives are merged bottom-up, every cluster pairing with the neighbour within `radius`
+ * places whose union has the smallest surface area; a few dozen rounds, same build time to within a few milliseconds.
+ * Measured (profiles/r03_builder_quality.txt): the clustering visits fewer nodes per ray on a height field and on replicated
+ * Cornell boxes (-10 % / -5 %), more on the regular torus and on triangle soup (+11 % / +15 %), and the host's binned-SAH build
+ * stays ahead of both on irregular meshes (-20 %); in rays per second the three are within 7 % — hence the cheaper default.
+ * Either way the result is a valid conservative CWBVH. */
 int nxhip_set_device_builder(nxhip_ctx *ctx, int clusteringRadius);
 /* Read a BLAS's nodes / primitive index list back (either may be NULL; *nodeCount = nodes it has). */
 int nxhip_read_blas(nxhip_ctx *ctx, int32_t blasId, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *primIdx, uint32_t primCapacity,

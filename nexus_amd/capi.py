@@ -501,8 +501,8 @@ class Context:
         check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
         return nodes, idx
 
-    def set_device_builder(self, clustering_radius=16):
-        """device BLAS / TLAS builders: clustering (PLOC) with this search radius, 0 = radix tree (LBVH)"""
+    def set_device_builder(self, clustering_radius=0):
+        """device BLAS / TLAS builders: 0 = radix tree (LBVH, the default), > 0 = clustering (PLOC) with this search radius"""
         check(self.L.nxhip_set_device_builder(self.h, int(clustering_radius)), "nxhip_set_device_builder")
 
     def release_queues(self):

@@ -71,14 +71,14 @@ static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
 // Traversal record of one TLAS leaf, stored in TLAS *leaf order* (entry k belongs to tlasInstIdx[k]) so that entering an
 // instance is one fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id, the BLAS root.
 struct __attribute__((aligned(16))) InstTrav {
-    // (first chunk = what entering the instance needs at once: a lane waits for this load only before it decides whether
-    //  the transform has to be applied; the pointers and the id are needed an iteration later at the earliest)
-    uint32_t instIdx;
-    uint32_t flags;     // kInstIdentity: the inverse transform's first three rows are exactly those of the identity matrix
-    uint32_t pad_[2];
+    float4 r0, r1, r2;  // rows 0..2 of invTransform: first, because a transformed entry needs them first (the lane starts the
+                        // transform while the rest of the record and the BLAS root are still arriving)
     const NX_G uint4* nodes;
     const NX_G float4* isect;
-    float4 r0, r1, r2;  // rows 0..2 of invTransform
+    uint32_t instIdx;
+    uint32_t flags;     // kInstIdentity: the rows above are exactly those of the identity matrix (kept per record by the host
+                        // upload and the device refit; the kernels use the scene-wide DeviceState::sceneFlags derived from it)
+    uint32_t pad_[2];
     uint4 root[5];      // a copy of the BLAS's root node: entering the instance and testing its root are one loop iteration
 };
 static_assert(sizeof(InstTrav) == 160, "InstTrav layout");

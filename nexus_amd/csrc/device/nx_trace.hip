@@ -294,11 +294,11 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             if (wantInst) {
                 nodes = fi.nodes();
                 isect = fi.isect();
-                instIdx = fi.head.x;
+                instIdx = fi.instIdx;
                 // the octant order keeps using the world-space direction (BVH8Traversal.cuh:259-264).
                 // A transform that maps this ray onto itself bit for bit leaves 1/dir as it is, so the three divisions here and
-                // the reload + three divisions on exit are skipped; an instance flagged as carrying the identity does not even
-                // compute the transform (enter_instance).
+                // the reload + three divisions on exit are skipped; in a scene of identity instances only the transform is not
+                // even computed (enter_instance).
                 f3 o2, d2;
                 xformed = enter_instance(fi, sceneIdentity, org, dir, o2, d2);
                 if (xformed) {

@@ -51,8 +51,8 @@ NXD uint2 stack_pop(lds_u64* lds, const uint2* spill, int& sp)
     return make_uint2(0u, 0u);
 }
 
-// Entering an instance whose inverse transform is exactly the identity (InstTrav::flags & kInstIdentity, set where the record
-// is written) leaves a ray as it is, bit for bit — unless one of its components is a zero (the transform's `+ 0 * y` terms
+// Entering an instance whose inverse transform is exactly the identity leaves a ray as it is, bit for bit — unless one of its
+// components is a zero (the transform's `+ 0 * y` terms
 // can flip the sign of a zero, and 1 / dir follows the sign), an infinity or a NaN (0 * inf), or a denormal.  Such rays are
 // rare (axis-parallel ones) and take the general path, which computes what the reference computes (BVH8Traversal.cuh:259-264);
 // all others skip the two matrix products, the six comparisons of the old "did anything change" test and the LDS parking.
@@ -68,39 +68,38 @@ NXD float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }
 NXD int imax3(int a, int b, int c) { return max(max(a, b), c); }                  // v_max3_i32
 NXD int imin3(int a, int b, int c) { return min(min(a, b), c); }                  // v_min3_i32
 
-// The part of an instance record in front of its BLAS root copy, loaded in record order: id + flags, pointers, transform rows.
-// In a scene whose instances all carry the identity (a uniform flag of the device state, DeviceState::sceneFlags) the three
-// transform rows are not even loaded.
+// The part of an instance record in front of its BLAS root copy.  In a scene whose instances all carry the identity (a uniform
+// flag of the device state, DeviceState::sceneFlags) the three transform rows are not even loaded.
 struct InstFetch {
-    uint4 head;     // instance id, InstTrav::flags, -, -
-    uint4 ptrs;
     uint4 rows[3];
+    uint4 ptrs;
+    uint32_t instIdx;
     NXD GU4 nodes() const { return (GU4)(((unsigned long long)ptrs.y << 32) | ptrs.x); }
     NXD GF4 isect() const { return (GF4)(((unsigned long long)ptrs.w << 32) | ptrs.z); }
 };
 NXD void fetch_instance(unsigned long long recAddr, bool sceneIdentity, InstFetch& f)
 {
     GU4 p = (GU4)recAddr;
-    f.head = p[0];
-    f.ptrs = p[1];
-    if (!sceneIdentity) { f.rows[0] = p[2]; f.rows[1] = p[3]; f.rows[2] = p[4]; }
+    if (!sceneIdentity) { f.rows[0] = p[0]; f.rows[1] = p[1]; f.rows[2] = p[2]; }
+    f.ptrs = p[3];
+    f.instIdx = *(const NX_G uint32_t*)(p + 4);
 }
 // The ray in the instance's frame (BVH8Traversal.cuh:259-264: origin and direction through the inverse transform, not
-// renormalised).  Returns whether it differs from the incoming ray; false leaves o2 / d2 unset and the caller's ray, 1 / dir
-// and (on exit) the restore untouched.  The comparison is on bit patterns: a zero whose sign the transform flips counts.
+// renormalised).  Returns whether it differs from the incoming ray; false leaves the caller's ray, 1 / dir and (on exit) the
+// restore untouched.  The comparison is on bit patterns: a zero whose sign the transform flips counts.
+// Scene of identity instances only: an ordinary ray is its own image (nothing of the record is needed for that decision, the
+// two matrix products and the six comparisons are skipped); the others go through the identity's rows as constants.
+// Any other scene: the general path for every entry — an identity instance among transformed ones is recognised by the
+// comparison as before.  (A per-record flag test in front of it was measured: it needs the record's flag word before the
+// first instruction of the step, and on scenes without identity instances — configs[3] / configs[4] — cost 3 %.)
 NXD bool enter_instance(const InstFetch& f, bool sceneIdentity, f3 org, f3 dir, f3& o2, f3& d2)
 {
     float4 r0 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-#ifndef NX_NO_IDENTITY_FLAG
-    const bool ordinary = ray_is_ordinary(org, dir);
     if (sceneIdentity) {
-        // (decided from registers alone: nothing of the record has to have arrived yet)
-        if (ordinary) return false;
-    } else {
-        if (ordinary && (f.head.y & kInstIdentity) != 0u) return false;  // waits for the record's first chunk only
-#else
-    {
+#ifndef NX_NO_IDENTITY_FLAG
+        if (ray_is_ordinary(org, dir)) return false;
 #endif
+    } else {
         r0 = make_float4(__uint_as_float(f.rows[0].x), __uint_as_float(f.rows[0].y), __uint_as_float(f.rows[0].z), __uint_as_float(f.rows[0].w));
         r1 = make_float4(__uint_as_float(f.rows[1].x), __uint_as_float(f.rows[1].y), __uint_as_float(f.rows[1].z), __uint_as_float(f.rows[1].w));
         r2 = make_float4(__uint_as_float(f.rows[2].x), __uint_as_float(f.rows[2].y), __uint_as_float(f.rows[2].z), __uint_as_float(f.rows[2].w));
@@ -240,7 +239,7 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
         if (wantInst) {
             nodes = fi.nodes();
             isect = fi.isect();
-            instIdx = fi.head.x;
+            instIdx = fi.instIdx;
             f3 o2, d2;
             xformed = enter_instance(fi, sceneIdentity, org, dir, o2, d2);
             if (xformed) {

@@ -50,10 +50,13 @@ MESHES = {
 }
 
 
+@pytest.mark.parametrize("radius", [0, 16, 3])
 @pytest.mark.parametrize("name", list(MESHES))
-def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name):
+def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name, radius):
+    """both device builders: the radix tree (radius 0) and locally-ordered clustering with a wide and a narrow search window"""
     tris = np.ascontiguousarray(MESHES[name](), dtype=pod.TRI_DT)
     ctx = gpu_ctx_factory(32, 32)
+    ctx.set_device_builder(radius)
     bid = ctx.build_blas(tris)
     nodes, idx = ctx.read_blas(bid, len(tris))
     _check_structure(nodes, idx, tris)
@@ -72,7 +75,10 @@ def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_fac
     scene.upload(ref)
     assert SH.hit_records_equal(ref.trace_batch(rays), want)
     ctx = gpu_ctx_factory(32, 32)
-    ids = [ctx.build_blas(m) for m in scene.meshes]
+    ctx.set_device_builder(16)  # one mesh through the clustering builder, one through the radix tree
+    ids = [ctx.build_blas(scene.meshes[0])]
+    ctx.set_device_builder(0)
+    ids.append(ctx.build_blas(scene.meshes[1]))
     assert ids == [0, 1]
     # the instances' world bounds come from the BLAS root frame (BVHInstance.cpp:8-21): recompute them for the device-built roots
     roots = [ctx.read_blas(i, len(m))[0][0] for i, m in zip(ids, scene.meshes)]

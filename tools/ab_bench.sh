@@ -17,7 +17,7 @@ for spec in "$@"; do
 done
 for r in $(seq 1 $ROUNDS); do
   for tag in "${tags[@]}"; do
-    NEXUS_AMD_LIB=build/variants/lib_$tag.so timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline > gpurun_out/ab/${tag}_$r.json 2>gpurun_out/ab/${tag}_$r.err || { echo "bench failed: $tag"; tail -3 gpurun_out/ab/${tag}_$r.err; exit 1; }
+    NEXUS_AMD_LIB=build/variants/lib_$tag.so timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline --no-obj-check > gpurun_out/ab/${tag}_$r.json 2>gpurun_out/ab/${tag}_$r.err || { echo "bench failed: $tag"; tail -3 gpurun_out/ab/${tag}_$r.err; exit 1; }
   done
 done
 python - "$ROUNDS" "${tags[@]}" <<'PY'

@@ -73,17 +73,21 @@ for d in a.passes:
 
 out = json.load(open(a.out)) if os.path.exists(a.out) else {}
 cfg = out.setdefault("config%d" % a.config, {})
-cfg["profile"] = {"tag": a.tag, "command": a.command, "frames": a.frames, "pass_dirs": [os.path.basename(os.path.normpath(p)) for p in a.passes]}
+cfg["profile"] = {"tag": a.tag, "command": a.command, "frames": sorted(set(frames_of.values()))[0] if frames_of else a.frames,
+                  "pass_dirs": [os.path.basename(os.path.normpath(p)) for p in a.passes]}
 per_frame = {"trace_closest": rf["rays_per_frame"], "trace_shadow": rf["shadow"]["rays_per_frame"],
              "logic": rf.get("items_per_frame", {}).get("logic", 0), "shade": rf.get("items_per_frame", {}).get("shade", 0)}
 for k in KERNELS:
     s, n = dict(sums[k]), max(1, rays[k])
     if not s:
         continue
-    # every counter divided by the units of ITS run: normalise the sums to the nominal frame count first
-    for c in list(s):
-        if not c.startswith("_") and frames_of.get(c, a.frames) != a.frames:
-            s[c] = s[c] * a.frames / frames_of[c]
+    # the units are those of the runs that collected the counters: frames each rendered x units per frame (every counter run
+    # of one profile_round is the same command, so they agree; the bench line beside each pass says how many it rendered)
+    seen_frames = sorted(set(frames_of.values())) or [a.frames]
+    if len(seen_frames) > 1:
+        raise SystemExit("counter passes rendered different numbers of frames: %s" % seen_frames)
+    n = max(1, per_frame[k] * seen_frames[0])
+    rays[k] = n
     e = {"rays_profiled": int(rays[k]), "unit": "ray" if k.startswith("trace") else "queue item", "source_sha16": source_hash(SOURCES[k])}
     if "FETCH_SIZE" in s:
         e["hbm_read_bytes_per_ray"] = round(2.0 * s["FETCH_SIZE"] * 1024.0 / n, 2)

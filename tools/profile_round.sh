@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 O=gpurun_out/prof_$tag; mkdir -p $O
 timeout -k 10 600 python bench.py --config $cfg "$@" > $O/bench_line.json 2> $O/bench_line.err || { tail -5 $O/bench_line.err; exit 1; }
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check > $O/bench_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python tools/level_timeline.py $O/stats 2 > $O/pass_timeline.txt 2>/dev/null
 i=0
@@ -18,7 +18,7 @@ dirs=""
 while read -r ctrs; do
   [ -z "$ctrs" ] && continue
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-roofline > $O/pmc$i.json 2> $O/pmc$i.err
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check --no-roofline > $O/pmc$i.json 2> $O/pmc$i.err
   rc=$?; echo "pmc pass $i ($ctrs) rc=$rc"
   [ $rc -ne 0 ] && { tail -5 $O/pmc$i.err; exit 1; }
   python tools/pmc_sum.py $O/pmc$i > $O/pmc$i.summary.txt
