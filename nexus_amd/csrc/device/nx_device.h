@@ -118,11 +118,10 @@ struct MaterialQueue {
 };
 
 // Every queue is kept in kQueueShards REGIONS of its buffer (region k = slots [k * cap, (k + 1) * cap), cap =
-// DeviceState::queueShardCap) with one size word per region: a producer workgroup appends to region blockIdx % 8, so the
-// returning atomics that hand out slots are spread over eight words — a single word sustains only ~90 of them per microsecond,
-// which is what bound the logic and material kernels (one extra zero-adding atomic per tile: material kernels x4.2, DESIGN.md
-// section 6) — and the trace kernels' eight fetch heads (one per XCD group) walk one region each.  Grid-stride tiles make the
-// regions balanced and bound their fill: a kernel of M items in tiles of T gives each region at most M / 8 + 2 T outputs.
+// DeviceState::queueShardCap) with one size word per region.  A producer kernel cuts the tiles of ITS input queue into eight
+// contiguous runs and appends the outputs of run r to region r (nx_queue.h ProducerRegions), so a region holds what one stretch
+// of the previous queue produced, at most M / 8 + T slots per producer kernel of M items in tiles of T; the trace kernels' eight
+// fetch heads (one per XCD group) walk one region each, and their words sit on separate cache lines (RegionCounters below).
 // DeviceState::queueShards == 1 (ordered compaction: one workgroup, the reference's serial slot order) keeps everything in
 // region 0, whose capacity is then the whole buffer.
 constexpr int kQueueShards = 8;

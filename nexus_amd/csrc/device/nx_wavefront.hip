@@ -75,7 +75,8 @@ struct SlotAllocator {
             if (threadIdx.x < K) *counters[threadIdx.x] = sRun[threadIdx.x];
         }
     }
-    NXD void alloc(const bool (&want)[K], int (&slot)[K])
+    // `region`: the queue region this tile appends to (uniform over the workgroup); counters[] point at region 0's words
+    NXD void alloc(const bool (&want)[K], int (&slot)[K], const int region = 0)
     {
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
         const int nWaves = blockDim.x / kWave;
@@ -94,12 +95,13 @@ struct SlotAllocator {
                 sBase[threadIdx.x] = sRun[threadIdx.x];
                 sRun[threadIdx.x] += total;
             } else {
-                sBase[threadIdx.x] = total ? atomicAdd(counters[threadIdx.x], total) : 0;
+                int* const word = counters[threadIdx.x] + region * kRegionStride;
+                sBase[threadIdx.x] = total ? atomicAdd(word, total) : 0;
 #ifdef NX_EXTRA_ATOMICS
                 // experiment: are the logic / material kernels bound by the returning atomics on their queue
                 // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
                 for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
-                    if (total && atomicAdd(counters[threadIdx.x], 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
+                    if (total && atomicAdd(word, 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
 #endif
             }
         }
@@ -337,10 +339,10 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
     if ((int)(blockIdx.x * blockDim.x) >= size) return;
     const uint32_t frame = S->frame->frameNumber;
     SlotAllocator<ORDERED, 4> slots;
-    const int region = producer_region(S), regionBase = region * (int)S->queueShardCap;
-    RegionCounters* const rc = &C->region[region];
+    RegionCounters* const rc = &C->region[0];
     int* const ctr[4] = {&rc->materialSize[0][bounce], &rc->materialSize[1][bounce], &rc->materialSize[2][bounce], &rc->materialSize[3][bounce]};
     slots.init(ctr);
+    const ProducerRegions out = producer_regions(S, size, (int)blockDim.x);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
         const int index = tile + (int)threadIdx.x;
@@ -371,7 +373,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
         }
         const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
         int slot[4];
-        slots.alloc(want, slot);
+        const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
+        slots.alloc(want, slot, region);
         if (type >= 0) {
             const MaterialQueue mq = S->material[type];
             const int sl = regionBase + (type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3])));
@@ -594,9 +597,9 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
     const uint32_t frame = S->frame->frameNumber;
     const MaterialQueue mq = S->material[TYPE];
     SlotAllocator<ORDERED, 2> slots;  // 0: shadow requests, 1: continuation rays
-    const int region = producer_region(S), regionBase = region * (int)S->queueShardCap;
-    int* const ctr[2] = {&C->region[region].traceShadowSize[bounce], &C->region[region].traceSize[bounce]};
+    int* const ctr[2] = {&C->region[0].traceShadowSize[bounce], &C->region[0].traceSize[bounce]};
     slots.init(ctr);
+    const ProducerRegions out = producer_regions(S, size, (int)blockDim.x);
     const int stride = gridDim.x * blockDim.x;
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
         const int requestIdx = tile + (int)threadIdx.x;
@@ -629,7 +632,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         }
         const bool want[2] = {wantShadow, wantTrace};
         int slot[2];
-        slots.alloc(want, slot);
+        const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
+        slots.alloc(want, slot, region);
         const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);

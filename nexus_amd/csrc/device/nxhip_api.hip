@@ -1317,8 +1317,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
     const int pathLength = c->h.settings.pathLength;
-    // (grids of the producer kernels are multiples of the queue regions: workgroup w appends to region w % 8, and the bound on a
-    //  region's fill — nx_device.h — needs the grid-stride tiles to visit the regions evenly)
+    // (grids of the producer kernels stay multiples of the queue regions: harmless, and what a round-robin tile-to-region mapping
+    //  would need)
     auto whole_regions = [](int g) { return (g + kQueueShards - 1) / kQueueShards * kQueueShards; };
     const int og = ordered ? 1 : whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
     const int lg = ordered ? 1 : whole_regions(c->logicBlocksPerCU * c->numCUs), lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
