@@ -72,10 +72,10 @@ namespace nxd {
 struct PassSlot {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
-    DevBuf throughputPdf, radiance, rayOrigin;
-    DevBuf trRayO, trRayD, trHit, trHitInst;
+    DevBuf radiance, rayOrigin;
+    DevBuf trRayO, trRayD, trHit, trHitInst, trTp;
     DevBuf shRayO, shRayD, shRadiance;
-    DevBuf mqHit[4], mqDirInst[4];
+    DevBuf mqHit[4], mqDirInst[4], mqTp[4];
     DevBuf counters, frame, dState;
     size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
     // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in

@@ -106,6 +106,7 @@ struct TraceQueue {
     NX_G float4* rayD;
     NX_G float4* hit;
     NX_G uint32_t* hitInst;
+    NX_G float4* tp;       // the path's throughput (rgb) and last pdf (w) travel with its ray: see MaterialQueue::tp
 };
 struct ShadowQueue {
     NX_G float4* rayO;
@@ -115,6 +116,10 @@ struct ShadowQueue {
 struct MaterialQueue {
     NX_G float4* hit;      // (path index, u, v, triangle)
     NX_G float4* dirInst;  // (ray direction, instance)
+    // D_PathStateSOA::throughput / lastPdf (PathTracer.cuh:19-30) are per-pixel arrays in the reference: every logic and material
+    // thread reads and writes 16 bytes at its path's pixel, i.e. scattered from the first bounce on.  Here the two values ride
+    // along in the queue entries instead — written and read at the slot index, coalesced — and no per-pixel copy exists.
+    NX_G float4* tp;
 };
 
 // Every queue is kept in kQueueShards REGIONS of its buffer (region k = slots [k * cap, (k + 1) * cap), cap =
@@ -215,7 +220,6 @@ struct DeviceState {
     uint32_t queueShards;      // regions in use: kQueueShards, or 1 with ordered compaction
     uint32_t queueShardCap;    // slots per region
     const NX_G uint32_t* pixelMap;  // local -> global pixel, nullptr = identity
-    NX_G float4* throughputPdf;     // rgb throughput, w = lastPdf
     NX_G float4* radiance;
     NX_G float4* rayOrigin;
     NX_G float4* accumulation;

@@ -347,29 +347,35 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
     for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
         const int index = tile + (int)threadIdx.x;
         int type = -1;
-        float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0);
+        float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0), tpOut = make_float4(0, 0, 0, 0);
         uint32_t inst = 0, pixelIdx = 0;
         if (index < size) {
             const int at = in.slot(index);  // where item `index` of the trace queue lives
             hit = S->trace.hit[at];
             dirPix = S->trace.rayD[at];
             pixelIdx = __float_as_uint(dirPix.w);
-            const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
+            const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->trace.tp[at];
             bool miss, survived, needsPrevVertex;
             f3 bg = mk3(0.0f), t = mk3(0.0f);
             type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return S->trace.hitInst[at]; }, miss, bg, survived, t, inst,
                               needsPrevVertex);
             if (needsPrevVertex) keep_previous_vertex(S, pixelIdx, S->trace.rayO[at]);
             if (miss) {
-                float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
-                r.x += bg.x; r.y += bg.y; r.z += bg.z;
-                if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
-                S->radiance[pixelIdx] = r;
+                // A background contribution of exactly +0 in all three components (a black environment: the reference's default
+                // backgroundIntensity 0) leaves the pixel's radiance as it is — generate_kernel zeroed it, later additions never
+                // produce a negative zero from non-negative emission — so the scattered 16-byte read-modify-write is skipped:
+                // it was a third of this kernel's memory traffic on such scenes.  (Anything else, -0 included, is added.)
+                if ((__float_as_uint(bg.x) | __float_as_uint(bg.y) | __float_as_uint(bg.z)) != 0u) {
+                    float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
+                    r.x += bg.x; r.y += bg.y; r.z += bg.z;
+                    if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
+                    S->radiance[pixelIdx] = r;
+                }
                 if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
             }
             // (at bounce 1 every hit survives with throughput 1 and the material kernels use that constant instead of reading
-            //  it back: the store would be dead — except for a pass-through, which the material kernel then covers)
-            if (survived && bounce != 1) S->throughputPdf[pixelIdx] = make_float4(t.x, t.y, t.z, tp.w);
+            //  it back)
+            if (survived) tpOut = make_float4(t.x, t.y, t.z, tp.w);
         }
         const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
         int slot[4];
@@ -382,6 +388,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
             // which saves a third array (4 B written and read per path, one load and one store instruction each)
             mq.hit[sl] = make_float4(__uint_as_float(pixelIdx), hit.y, hit.z, hit.w);
             mq.dirInst[sl] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
+            if (bounce != 1) mq.tp[sl] = tpOut;  // the path's throughput after Russian roulette and its last pdf go with it
         }
     }
     slots.finish();
@@ -608,6 +615,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
         float nextPdf = 0.0f;
         uint32_t pixelIdx = 0;
+        float4 tpdf = make_float4(0, 0, 0, 0);
 
         if (requestIdx < size) {
             const int at = in.slot(requestIdx);
@@ -615,7 +623,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             const float4 dirInst = mq.dirInst[at];
             pixelIdx = __float_as_uint(hit.x);
             const uint32_t instanceIdx = __float_as_uint(dirInst.w);
-            const float4 tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->throughputPdf[pixelIdx];
+            tpdf = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : mq.tp[at];
             shade_path<TYPE>(S, bounce, frame, (uint32_t)requestIdx, pixelIdx, hit.y, hit.z, __float_as_uint(hit.w), instanceIdx, mk3(dirInst.x, dirInst.y, dirInst.z), tpdf,
                              [&]() { return S->rayOrigin[pixelIdx]; },
                              [&](f3 emitted, uint32_t instIdx) {
@@ -644,11 +652,8 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             // w: 1 for a pass-through continuation (the path's previous vertex stays what it was: keep_previous_vertex)
             S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, updatePath ? 0.0f : 1.0f);
             S->trace.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
-            if (updatePath) {
-                S->throughputPdf[pixelIdx] = make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf);
-            } else if (bounce == 1) {
-                S->throughputPdf[pixelIdx] = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);  // pass-through at the first hit: what the logic kernel did not store
-            }
+            // the path state that goes with the ray: the new one, or — a pass-through — the one the path arrived with
+            S->trace.tp[traceSlot] = updatePath ? make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf) : tpdf;
         }
     }
     slots.finish();
@@ -707,7 +712,7 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
                 pixelIdx = __float_as_uint(dirPix.w);
                 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
                 hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
-                tp = S->throughputPdf[pixelIdx];
+                tp = S->trace.tp[at];
                 // the path's previous vertex: the origin of the ray that produced this hit, or, after a pass-through, what
                 // the logic step of the pass-through surface kept
                 ro = S->trace.rayO[at];

@@ -145,12 +145,11 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     DeviceState& v = s->view;
     v = c->h;
     if (s != static_cast<PassSlot*>(c)) {
-        v.throughputPdf = s->throughputPdf.as<float4>();
         v.radiance = s->radiance.as<float4>();
         v.rayOrigin = s->rayOrigin.as<float4>();
-        v.trace = TraceQueue{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trHit.as<float4>(), s->trHitInst.as<uint32_t>()};
+        v.trace = TraceQueue{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trHit.as<float4>(), s->trHitInst.as<uint32_t>(), s->trTp.as<float4>()};
         v.shadow = ShadowQueue{s->shRayO.as<float4>(), s->shRayD.as<float4>(), s->shRadiance.as<float4>()};
-        for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>()};
+        for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>(), s->mqTp[m].as<float4>()};
     }
     v.counters = s->counters.as<Counters>();
     v.frame = s->frame.as<FrameState>();
@@ -179,29 +178,28 @@ static int upload_state(nxhip_ctx* c)
 // at its previous capacity.
 static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
 {
-    DevBuf* const slots[] = {&q->throughputPdf, &q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->shRayO, &q->shRayD, &q->shRadiance,
-                             &q->mqHit[0], &q->mqDirInst[0], &q->mqHit[1], &q->mqDirInst[1],
-                             &q->mqHit[2], &q->mqDirInst[2], &q->mqHit[3], &q->mqDirInst[3]};
-    const size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+    DevBuf* const slots[] = {&q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->trTp, &q->shRayO, &q->shRayD, &q->shRadiance,
+                             &q->mqHit[0], &q->mqDirInst[0], &q->mqTp[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqTp[1],
+                             &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2], &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3]};
+    const size_t elem[] = {16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
     static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
     DevBuf fresh[kCount];
-    for (int i = 0; i < kCount; i++)  // the first three are per path, the rest are queues (regions + slack)
-        if (!fresh[i].alloc((i < 3 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
-    NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // radiance
-    NX_HIP(hipMemset(fresh[2].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
+    for (int i = 0; i < kCount; i++)  // the first two are per path, the rest are queues (regions + slack)
+        if (!fresh[i].alloc((i < 2 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    NX_HIP(hipMemset(fresh[0].p, 0, n * 16));  // radiance
+    NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
     q->pathCapacity = n;
     if (q == static_cast<PassSlot*>(c)) {
         c->radianceBoundCapacity = 0;
         DeviceState& h = c->h;
-        h.throughputPdf = c->throughputPdf.as<float4>();
         h.radiance = c->radiance.as<float4>();
         h.rayOrigin = c->rayOrigin.as<float4>();
-        h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>()};
+        h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>(), c->trTp.as<float4>()};
         h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
-        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>()};
+        for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqTp[m].as<float4>()};
     }
     c->stateDirty = true;
     return NXHIP_OK;
@@ -210,13 +208,14 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
 // Give a slot's queue buffers back (nothing of it may be in flight: the caller has synchronised).
 static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
 {
-    DevBuf* const bufs[] = {&q->throughputPdf, &q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->shRayO, &q->shRayD, &q->shRadiance,
-                            &q->mqHit[0], &q->mqDirInst[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqHit[2], &q->mqDirInst[2], &q->mqHit[3], &q->mqDirInst[3]};
+    DevBuf* const bufs[] = {&q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->trTp, &q->shRayO, &q->shRayD, &q->shRadiance,
+                            &q->mqHit[0], &q->mqDirInst[0], &q->mqTp[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqTp[1], &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2],
+                            &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3]};
     for (DevBuf* b : bufs) b->release();
     q->pathCapacity = 0;
     if (q == static_cast<PassSlot*>(c)) {
         DeviceState& h = c->h;
-        h.throughputPdf = h.radiance = h.rayOrigin = nullptr;
+        h.radiance = h.rayOrigin = nullptr;
         h.trace = TraceQueue{};
         h.shadow = ShadowQueue{};
         for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{};
