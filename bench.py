@@ -265,6 +265,8 @@ def main():
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
     explicit_fpp = args.frames_per_pass is not None
     cap = max(1, min((args.frames_per_pass or (16 if big else 64)) * world, 512))
+    if args.config == 4 and not args.passes_in_flight:
+        args.passes_in_flight = 1  # configs[3] (heavily instanced: long trace launches, little to overlap): 271 Msamples/s with one pass at a time, 254 with four
     S, R, n_passes = plan_schedule(args.steps, cap, args.passes_in_flight, explicit_fpp, 1.0 / world, args.width * args.height)
     pass_sizes = [int(x) for x in args.pass_sizes.split(",")] if args.pass_sizes else None
     if pass_sizes:

@@ -376,27 +376,31 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         c->wideBlocks = 8 * c->numCUs;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, tail_kernel_ptr(), kTraceBlockThreads, 0) != hipSuccess || perCU < 1) perCU = 2;
         c->tailBlocks = std::max(1, perCU) * c->numCUs;
-        if (const char* e = std::getenv("NX_TAIL_BOUNCE")) {  // tuning experiments only: 0 = off
-            const int n = std::atoi(e);
-            if (n == 0 || n == -1 || (n >= 2 && n <= NX_PATH_MAX_LENGTH)) c->tailBounce = n;
-        }
-        if (const char* e = std::getenv("NX_TRACE_BLOCKS_PER_CU")) {  // tuning experiments only
-            const int n = std::atoi(e);
-            if (n >= 1 && n <= 16) { c->traceBlocks = c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
-        }
-        if (const char* e = std::getenv("NX_SHADE_BLOCKS_PER_CU")) {  // tuning experiments only
-            const int n = std::atoi(e);
-            if (n >= 1 && n <= 64) c->shadeBlocksPerCU = n;
-        }
-        if (const char* e = std::getenv("NX_LOGIC_BLOCKS_PER_CU")) {  // tuning experiments only
-            const int n = std::atoi(e);
-            if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
-        }
-        if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
-        if (const char* e = std::getenv("NX_SHADE_PARALLEL")) c->parallelShade = std::atoi(e);    // tuning experiments only
-        if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
-            const int n = std::atoi(e);
-            if (n >= 1 && n <= 65536) { c->traceBlocks = c->shadowBlocks = n; c->traceGridForced = true; }
+        // Launch-geometry knobs of the measurement sweeps.  They are read only when NX_TUNING_KNOBS=1 says
+        // that a sweep is running: a stray variable in a user's environment does not reconfigure the product.
+        if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1) {
+            if (const char* e = std::getenv("NX_TAIL_BOUNCE")) {  // tuning experiments only: 0 = off
+                const int n = std::atoi(e);
+                if (n == 0 || n == -1 || (n >= 2 && n <= NX_PATH_MAX_LENGTH)) c->tailBounce = n;
+            }
+            if (const char* e = std::getenv("NX_TRACE_BLOCKS_PER_CU")) {  // tuning experiments only
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 16) { c->traceBlocks = c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
+            }
+            if (const char* e = std::getenv("NX_SHADE_BLOCKS_PER_CU")) {  // tuning experiments only
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 64) c->shadeBlocksPerCU = n;
+            }
+            if (const char* e = std::getenv("NX_LOGIC_BLOCKS_PER_CU")) {  // tuning experiments only
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
+            }
+            if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
+            if (const char* e = std::getenv("NX_SHADE_PARALLEL")) c->parallelShade = std::atoi(e);    // tuning experiments only
+            if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 65536) { c->traceBlocks = c->shadowBlocks = n; c->traceGridForced = true; }
+            }
         }
     } while (false);
     if (rc != NXHIP_OK) {

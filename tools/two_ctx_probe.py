@@ -38,6 +38,7 @@ def run(ctxs, passes, S):
 for S in (32, 16):
     for blocks in ("", "4", "3"):
         if blocks:
+            os.environ["NX_TUNING_KNOBS"] = "1"
             os.environ["NX_TRACE_BLOCKS_PER_CU"] = blocks
         else:
             os.environ.pop("NX_TRACE_BLOCKS_PER_CU", None)
