@@ -5,15 +5,16 @@
 // collapse of BVH8Builder.cpp:63-117, 273-393: ~10 s per million triangles); the host builder of this repo is the same
 // algorithm task-parallel (0.4 s per million).  This is the GPU path for scenes where even that dominates time to first
 // frame (10 M triangles replicated on 8 ranks): a linear BVH — 63-bit Morton codes of the centroids, one radix sort, the
-// binary radix tree of Karras 2012 with every internal node found independently, bounds fitted bottom-up with one arrival
-// counter per node — collapsed top-down, level by level, into 8-wide nodes: each node starts from the two children of its
-// BVH2 root and keeps opening the child with the largest surface area until it has eight; children that hold at most
-// three triangles become leaf slots.  Children are assigned to octant slots with the reference's greedy rule
+// binary radix tree of Karras 2012 with every internal node found independently (or a clustering build, 4b), bounds fitted
+// bottom-up with one arrival counter per node — collapsed top-down, level by level, into 8-wide nodes by the reference's SAH
+// dynamic programme (BVH8Builder.cpp:63-117): its cost table is filled bottom-up like the bounds (4c), and each wide node takes
+// the up to eight subtrees the table chose, as wide nodes or as leaf slots of at most three triangles.  Children are assigned to octant slots with the reference's greedy rule
 // (BVH8Builder.cpp:170-252) and quantised exactly as the host builder does (8-bit grid, floor / ceil, power-of-two scale).
 // The tree is a valid, conservative CWBVH for the unchanged traversal kernels; its node bytes differ from the SAH builder's
 // (a different tree): hits are identical, traversal visits more nodes (quality is the price of the build speed).
 #include <string.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -145,7 +146,21 @@ struct Bvh2 {
     int* count;    // [n-1] primitives under the internal node
     Box3* box;     // [2n-1]
     int* arrived;  // [n-1]
+    struct Eval* eval;  // [7 (n-1)] cost table of the collapse (internal nodes; a leaf's entries follow from its box), or nullptr
 };
+
+// One entry of the collapse's cost table (Ylitie, Karras, Laine 2017; the reference's BVH8Builder.cpp:63-117 and the host's
+// Collapse.cpp): eval[7 node + i] = cheapest way to present the subtree under `node` as at most i + 1 children of a wide node —
+// as one leaf slot (at most three primitives), as one wide node of its own (entry 0 only), or by handing leftCount + 1 and
+// rightCount + 1 roots to its two children.
+enum : int8_t { kDecLeaf = 0, kDecInternal = 1, kDecDistribute = 2 };
+struct Eval {
+    float cost;
+    int8_t decision, leftCount, rightCount, pad_;
+};
+static_assert(sizeof(Eval) == 8, "one 8-byte word per entry");
+constexpr float kCostPrim = 0.3f, kCostNode = 1.0f;  // nexus::C_PRIM, C_NODE (include/nexus/BVH8.h)
+constexpr int kLeafMax = 3;                            // nexus::P_MAX
 
 __global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long long* __restrict__ codes, const int n, Bvh2 t)
 {
@@ -266,6 +281,9 @@ __global__ void __launch_bounds__(kBlock) ploc_merge_kernel(Bvh2 t, const int n,
                 for (int x = 0; x < 3; x++) { u.lo[x] = fminf(ba.lo[x], bb.lo[x]); u.hi[x] = fmaxf(ba.hi[x], bb.hi[x]); }
                 t.left[id] = a;
                 t.right[id] = b;
+                t.parent[a] = id;
+                t.parent[b] = id;
+                if (id == 0) t.parent[0] = -1;  // the last merge is the root
                 t.box[id] = u;
                 t.count[id] = (a >= n - 1 ? 1 : t.count[a]) + (b >= n - 1 ? 1 : t.count[b]);
                 node = id;
@@ -284,17 +302,69 @@ __global__ void __launch_bounds__(kBlock) ploc_compact_kernel(const int* __restr
         if (keep[i]) next[offset[i]] = merged[i];
 }
 
+// ---- 4c. the collapse's cost table, bottom-up like the bounds: the second child to arrive at a node fills its seven entries
+__device__ __forceinline__ float half_area(const Box3& b)
+{
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ex * ez;
+}
+__device__ __forceinline__ Eval eval_of(const Bvh2& t, const int n, const int node, const int i, const bool fresh)
+{
+    if (node >= n - 1) return Eval{half_area(t.box[node]) * kCostPrim, kDecLeaf, 0, 0, 0};  // one primitive: a leaf slot whatever i
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(&t.eval[(size_t)node * 7 + i]);
+    const unsigned long long w = fresh ? *reinterpret_cast<const volatile unsigned long long*>(p) : *p;
+    Eval e;
+    memcpy(&e, &w, 8);
+    return e;
+}
+
+__global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        int node = t.parent[(n - 1) + k];
+        while (node >= 0) {
+            __threadfence();  // (as fit_kernel: this thread's entries are visible before its arrival is)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&t.arrived[node], 1) == 0) break;
+            __threadfence();
+            const int l = t.left[node], r = t.right[node];
+            float lc[7], rc[7];
+            for (int i = 0; i < 7; i++) {
+                lc[i] = eval_of(t, n, l, i, true).cost;
+                rc[i] = eval_of(t, n, r, i, true).cost;
+            }
+            const float area = half_area(t.box[node]);
+            const int prims = t.count[node];
+            Eval e[7];
+            // C(n, 0) = min(leaf, best split into 8 + one node test); C(n, i) = min(best split into i + 1, C(n, i - 1))
+            for (int i = 0; i < 7; i++) {
+                const int j = i == 0 ? 7 : i;  // roots to hand out: j, one of them at least to each side
+                float best = 1.0e30f;
+                int bl = 0, br = 0;
+                for (int a = 0; a < j; a++) {
+                    const float c = lc[a] + rc[j - 1 - a];
+                    if (c < best) { best = c; bl = a; br = j - 1 - a; }
+                }
+                if (i == 0) {
+                    const float leaf = prims <= kLeafMax ? area * (float)prims * kCostPrim : 1.0e30f;
+                    const float inner = best + area * kCostNode;
+                    e[0] = leaf < inner ? Eval{leaf, kDecLeaf, 0, 0, 0} : Eval{inner, kDecInternal, (int8_t)bl, (int8_t)br, 0};
+                } else {
+                    e[i] = best < e[i - 1].cost ? Eval{best, kDecDistribute, (int8_t)bl, (int8_t)br, 0} : e[i - 1];
+                }
+            }
+            for (int i = 0; i < 7; i++) t.eval[(size_t)node * 7 + i] = e[i];
+            node = t.parent[node];
+        }
+    }
+}
+
 // ---- 5. collapse into 8-wide nodes, one level per launch
 struct WorkItem {
     int bvh2Node;   // root of the BVH2 subtree this BVH8 node covers (internal node id)
     uint32_t outNode;
 };
 
-__device__ __forceinline__ float half_area(const Box3& b)
-{
-    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
-    return ex * ey + ey * ez + ex * ez;
-}
 __device__ __forceinline__ uint32_t quantize(float v)  // nexus::collapse Quantize
 {
     if (!(v == v)) return 0u;
@@ -303,18 +373,48 @@ __device__ __forceinline__ uint32_t quantize(float v)  // nexus::collapse Quanti
     return (uint32_t)v;
 }
 
+// a child of a wide node becomes a wide node itself, or a leaf slot of its (at most three) primitives
+__device__ __forceinline__ bool is_inner(const Bvh2& t, const int n, const int c)
+{
+    if (c >= n - 1) return false;
+    if (t.eval) return eval_of(t, n, c, 0, false).decision == kDecInternal;
+    return t.count[c] > kLeafMax;
+}
+
 __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, const int n, const uint32_t* __restrict__ order, const WorkItem* __restrict__ work,
                                                                 const uint32_t workCount, WorkItem* __restrict__ nextWork, uint32_t* __restrict__ counters /* [0] nodes used, [1] prims used, [2] next work count */,
                                                                 nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx, const uint32_t nodeCapacity)
 {
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < workCount; w += gridDim.x * blockDim.x) {
         const WorkItem item = work[w];
-        // open children by largest area until eight (a BVH2 leaf, one triangle, cannot be opened)
         int child[8];
-        int count = 2;
-        child[0] = t.left[item.bvh2Node];
-        child[1] = t.right[item.bvh2Node];
-        while (count < 8) {
+        int count = 0;
+        if (t.eval) {
+            // the children the cost table chose (Collapse.cpp GatherChildren): follow the "distribute" decisions down from
+            // entry 0 of this node; whatever is reached with another decision is a child
+            int todoNode[8], todoIdx[8], top = 0;
+            todoNode[top] = item.bvh2Node;
+            todoIdx[top++] = 0;
+            while (top > 0) {
+                const int x = todoNode[--top];
+                const Eval e = eval_of(t, n, x, todoIdx[top], false);
+                const int side[2] = {t.left[x], t.right[x]}, sideIdx[2] = {e.leftCount, e.rightCount};
+                for (int h = 0; h < 2; h++) {
+                    if (eval_of(t, n, side[h], sideIdx[h], false).decision == kDecDistribute && top < 8) {
+                        todoNode[top] = side[h];
+                        todoIdx[top++] = sideIdx[h];
+                    } else if (count < 8) {
+                        child[count++] = side[h];
+                    }
+                }
+            }
+        } else {
+            count = 2;
+            child[0] = t.left[item.bvh2Node];
+            child[1] = t.right[item.bvh2Node];
+        }
+        // without a cost table: open children by largest area until eight (a BVH2 leaf, one triangle, cannot be opened)
+        while (!t.eval && count < 8) {
             int best = -1;
             float bestArea = -1.0f;
             for (int k = 0; k < count; k++) {
@@ -367,7 +467,7 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
             if (childAt[s] < 0) continue;
             const int c = child[childAt[s]];
             const int tris = c >= n - 1 ? 1 : t.count[c];
-            if (tris > 3) innerCount++;
+            if (is_inner(t, n, c)) innerCount++;
             else primCount += (uint32_t)tris;
         }
         const uint32_t childBase = innerCount ? atomicAdd(&counters[0], innerCount) : 0u;
@@ -402,7 +502,7 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
             node.qhiy[s] = (uint8_t)quantize(ceilf((b.hi[1] - nb.lo[1]) * invScale[1]));
             node.qhiz[s] = (uint8_t)quantize(ceilf((b.hi[2] - nb.lo[2]) * invScale[2]));
             const int tris = c >= n - 1 ? 1 : t.count[c];
-            if (tris > 3) {
+            if (is_inner(t, n, c)) {
                 node.meta[s] = (uint8_t)(0x20 | (24 + s));
                 node.imask |= (uint8_t)(1u << s);
                 nextWork[workBase + innerSeen] = WorkItem{c, childBase + innerSeen};
@@ -507,7 +607,7 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     DevBuf left, right, parent, first, last, count, box, arrived;
     if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !count.alloc(inner * 4) ||
         !box.alloc(all * sizeof(Box3)) || !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
-    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>()};
+    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>(), nullptr};
     if (plocRadius <= 0) {
         NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
         radix_tree_kernel<<<grid_for(n - 1, cus), kBlock, 0, st>>>(codesSorted.as<unsigned long long>(), (int)n, t);
@@ -545,6 +645,20 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
             m = next;
             std::swap(cur, nxt);
         }
+    }
+
+    // which subtrees become wide nodes, which leaf slots: the cost table of the SAH collapse, bottom-up over the finished tree
+    // (NX_DEVICE_COLLAPSE=greedy with NX_TUNING_KNOBS=1: the round-2 rule instead — open the largest child until there are eight,
+    // subtrees of at most three primitives become leaf slots — kept for the quality comparison of tools/builder_quality.py)
+    DevBuf evals;
+    bool greedy = false;
+    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1)
+        if (const char* e = std::getenv("NX_DEVICE_COLLAPSE")) greedy = std::strcmp(e, "greedy") == 0;
+    if (!greedy) {
+        if (!evals.alloc(inner * 7 * sizeof(Eval))) return NXHIP_ERR_HIP;
+        t.eval = evals.as<Eval>();
+        NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
+        cost_kernel<<<grid_for(n, cus), kBlock, 0, st>>>((int)n, t);
     }
 
     // collapse.  Every BVH8 node but the root stands for a distinct internal BVH2 node, so n - 1 nodes cannot be exceeded

@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 from nexus_amd import capi, loaders, pod, scenegen  # noqa: E402
 
 IDENT = np.eye(4, dtype=np.float32).reshape(16)
+# device builders: (clustering radius, 0 = radix tree; collapse: the SAH cost table, or round 2's greedy rule)
+DEVICE = {"PLOC r16": (16, "sah"), "PLOC r8": (8, "sah"), "LBVH": (0, "sah"), "PLOC r16 greedy": (16, "greedy"), "LBVH greedy": (0, "greedy")}
+BUILDERS = ("host SAH", "PLOC r16", "PLOC r8", "LBVH", "PLOC r16 greedy", "LBVH greedy")
 
 
 def meshes():
@@ -49,12 +52,12 @@ def rays_for(tris, n, seed):
 
 
 def main():
-    print("%-48s %-10s %9s %9s %10s %10s %9s" % ("mesh", "builder", "build s", "nodes", "nodes/ray", "tris/ray", "Grays/s"))
+    print("%-48s %-16s %9s %9s %10s %10s %9s" % ("mesh", "builder", "build s", "nodes", "nodes/ray", "tris/ray", "Grays/s"))
     for name, tris in meshes():
         tris = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
         rays = rays_for(tris, 2000000, 7)
         ref = None
-        for builder in ("host SAH", "PLOC r16", "PLOC r8", "LBVH"):
+        for builder in BUILDERS:
             ctx = capi.Context(1920, 1080)
             ctx.set_frames_per_pass(1)
             t0 = time.time()
@@ -63,7 +66,10 @@ def main():
                 t_build = time.time() - t0
                 bid = ctx.upload_blas(nodes, tris, idx)
             else:
-                ctx.set_device_builder({"PLOC r16": 16, "PLOC r8": 8, "LBVH": 0}[builder])
+                radius, collapse = DEVICE[builder]
+                os.environ["NX_TUNING_KNOBS"] = "1"
+                os.environ["NX_DEVICE_COLLAPSE"] = collapse  # read by every build
+                ctx.set_device_builder(radius)
                 ctx.build_blas(tris[:64])  # first use: code objects
                 ctx.clear_blas()
                 ctx.sync()
@@ -92,7 +98,7 @@ def main():
             if ref is None:
                 ref = hits
             same = np.array_equal(ref["hitDistance"].view(np.uint32), hits["hitDistance"].view(np.uint32))
-            print("%-48s %-10s %9.3f %9d %10.2f %10.2f %9.2f %s" % (name, builder, t_build, len(nodes), st["nodes"] / st["rays"], st["tris"] / st["rays"], grays,
+            print("%-48s %-16s %9.3f %9d %10.2f %10.2f %9.2f %s" % (name, builder, t_build, len(nodes), st["nodes"] / st["rays"], st["tris"] / st["rays"], grays,
                                                                    "" if same else "HIT DISTANCES DIFFER FROM THE SAH BUILD"))
             ctx.close()
 
