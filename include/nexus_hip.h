@@ -68,6 +68,7 @@ int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount,
  * Cornell boxes (-10 % / -5 %), more on the regular torus and on triangle soup (+11 % / +15 %), and the host's binned-SAH build
  * stays ahead of both on irregular meshes (-20 %); in rays per second the three are within 7 % — hence the cheaper default.
  * Either way the result is a valid conservative CWBVH. */
+#define NXHIP_BUILDER_SAH (-1) /* top-down binned surface-area build on the device (the host builder's rule, nx_lbvh.hip 4d) */
 int nxhip_set_device_builder(nxhip_ctx *ctx, int clusteringRadius);
 /* Read a BLAS's nodes / primitive index list back (either may be NULL; *nodeCount = nodes it has). */
 int nxhip_read_blas(nxhip_ctx *ctx, int32_t blasId, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *primIdx, uint32_t primCapacity,

@@ -502,7 +502,8 @@ class Context:
         return nodes, idx
 
     def set_device_builder(self, clustering_radius=0):
-        """device BLAS / TLAS builders: 0 = radix tree (LBVH, the default), > 0 = clustering (PLOC) with this search radius"""
+        """device BLAS / TLAS builders: 0 = radix tree (LBVH, the default), > 0 = clustering (PLOC) with this search radius,
+        -1 (NXHIP_BUILDER_SAH) = top-down binned SAH"""
         check(self.L.nxhip_set_device_builder(self.h, int(clustering_radius)), "nxhip_set_device_builder")
 
     def release_queues(self):

@@ -144,7 +144,7 @@ struct nxhip_ctx : nxd::PassSlot {
     nxd::DevBuf pixelMap, accumulation, rgba8;
     nxd::DevBuf traceStats;
 
-    int deviceBuilderRadius = 0;  // nxhip_build_blas / nxhip_rebuild_tlas: 0 = radix tree (LBVH), > 0 = neighbour search radius of the clustering builder
+    int deviceBuilderRadius = -1;  // nxhip_build_blas / nxhip_rebuild_tlas: -1 = top-down binned SAH (NXHIP_BUILDER_SAH), 0 = radix tree (LBVH), > 0 = neighbour search radius of the clustering builder
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber
     bool statsEnabled = false;
     bool timingEnabled = false;

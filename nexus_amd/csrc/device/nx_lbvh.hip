@@ -230,6 +230,11 @@ __global__ void __launch_bounds__(kBlock) fit_kernel(const Box3* __restrict__ tr
 // radix tree only follows the bits of the space-filling curve — at the price of a few dozen rounds instead of one launch.
 // Node ids as in the radix tree: leaf k = n - 1 + k; internal nodes are numbered downwards from n - 2 so that the last
 // merge — the root — is node 0, which the collapse starts from.
+__device__ __forceinline__ float half_area(const Box3& b)
+{
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ex * ez;
+}
 __device__ __forceinline__ float union_half_area(const Box3& a, const Box3& b)
 {
     const float ex = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), ey = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]), ez = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
@@ -302,12 +307,407 @@ __global__ void __launch_bounds__(kBlock) ploc_compact_kernel(const int* __restr
         if (keep[i]) next[offset[i]] = merged[i];
 }
 
-// ---- 4c. the collapse's cost table, bottom-up like the bounds: the second child to arrive at a node fills its seven entries
-__device__ __forceinline__ float half_area(const Box3& b)
+// ---- 4d. the third way to the binary tree: the host builder's rule on the device — top-down, binned surface-area heuristic
+// (BVH.cpp; the reference's Geometry/BVH/BVH.cpp:65-210: bins over the centroid bounds of the node, the plane with the smallest
+// count x area sum over the three axes, one primitive per leaf, "split in half" when nothing separates).  Level by level: every
+// node of a level bins its primitives with atomics (a workgroup whose 256 primitives share a node bins in LDS first), one
+// thread per node picks the plane and creates the children, a scan of the "goes left" flags gives every primitive its place
+// in the next level's order, and the scatter pass collects the children's centroid bounds.  Nodes of at most kSahSmall primitives
+// leave the levels and are finished by one thread each with an exact sweep.
+constexpr int kSahBins = 16;
+constexpr int kSahSmall = 8;
+struct SahBin {
+    uint32_t count;
+    uint32_t lo[3], hi[3];  // float_ordered
+};
+constexpr int kSahBinWords = 7;
+struct SahSeg {
+    int first, count, node;
+    uint32_t cb[6];   // centroid bounds (float_ordered), collected by the scatter pass that created the segment
+    int axis;         // chosen axis; -1: split in half by position
+    int plane;        // bins <= plane go left
+    int countL;
+    int child[2];     // the children's places in the next level's list; -1: not there (a leaf, or finished by sah_small_kernel)
+};
+struct SahSmall {
+    int first, count, node;
+};
+struct SahCounters {
+    uint32_t nodes;       // internal node ids handed out (the root is 0)
+    uint32_t nextCount;   // segments of the next level
+    uint32_t smallCount;  // segments handed to sah_small_kernel
+    uint32_t pad_;
+};
+
+__device__ __forceinline__ void box_centre(const Box3& b, float c[3])
 {
-    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
-    return ex * ey + ey * ez + ex * ez;
+    for (int a = 0; a < 3; a++) c[a] = 0.5f * (b.lo[a] + b.hi[a]);
 }
+// the bin of a centroid coordinate — the one expression the binning, the flags and the scatter all use
+__device__ __forceinline__ int sah_bin(const float c, const float lo, const float hi)
+{
+    const float scale = (float)kSahBins / (hi - lo);
+    const float f = (c - lo) * scale;
+    int b = f >= 0.0f ? (int)fminf(f, (float)(kSahBins - 1)) : 0;  // (a NaN lands in bin 0)
+    return min(max(b, 0), kSahBins - 1);
+}
+__device__ __forceinline__ bool sah_goes_left(const SahSeg& sg, const Box3& pb, const int i)
+{
+    if (sg.axis < 0) return i - sg.first < sg.countL;
+    float c[3];
+    box_centre(pb, c);
+    return sah_bin(c[sg.axis], ordered_float(sg.cb[sg.axis]), ordered_float(sg.cb[3 + sg.axis])) <= sg.plane;
+}
+
+// union of all primitive boxes (the root's box) — 6 words, float_ordered
+__global__ void __launch_bounds__(kBlock) box_union_kernel(const Box3* __restrict__ primBox, const uint32_t n, uint32_t* __restrict__ out)
+{
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Box3 b = primBox[i];
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], b.lo[a]); hi[a] = fmaxf(hi[a], b.hi[a]); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&out[a], float_ordered(lo[a]));
+            atomicMax(&out[3 + a], float_ordered(hi[a]));
+        }
+    }
+}
+
+__global__ void sah_root_kernel(const uint32_t* __restrict__ centroidBounds, const uint32_t* __restrict__ rootBox, const int n, Bvh2 t, SahSeg* __restrict__ segs, int* __restrict__ segOf)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SahSeg sg{};
+        sg.first = 0; sg.count = n; sg.node = 0;
+        for (int k = 0; k < 6; k++) sg.cb[k] = centroidBounds[k];
+        sg.child[0] = sg.child[1] = -1;
+        segs[0] = sg;
+        Box3 b;
+        for (int a = 0; a < 3; a++) { b.lo[a] = ordered_float(rootBox[a]); b.hi[a] = ordered_float(rootBox[3 + a]); }
+        t.box[0] = b;
+        t.count[0] = n;
+        t.parent[0] = -1;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) segOf[i] = 0;
+}
+
+__device__ __forceinline__ void sah_bin_add(uint32_t* bin /* 7 words */, const Box3& pb)
+{
+    atomicAdd(&bin[0], 1u);
+    for (int x = 0; x < 3; x++) {
+        atomicMin(&bin[1 + x], float_ordered(pb.lo[x]));
+        atomicMax(&bin[4 + x], float_ordered(pb.hi[x]));
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) sah_bins_init_kernel(uint32_t* __restrict__ bins, const size_t words)
+{
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < words; k += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(k % kSahBinWords);
+        bins[k] = (w >= 1 && w <= 3) ? 0xffffffffu : 0u;
+    }
+}
+
+// bins[seg][axis][bin]: count and box of the primitives whose centroid falls into the bin
+__global__ void __launch_bounds__(kBlock) sah_bin_kernel(const Box3* __restrict__ primBox, const int* __restrict__ ids, const int* __restrict__ segOf, const int n,
+                                                         const SahSeg* __restrict__ segs, uint32_t* __restrict__ bins)
+{
+    __shared__ uint32_t local[3 * kSahBins * kSahBinWords];
+    for (int tile = blockIdx.x * blockDim.x; tile < n; tile += gridDim.x * blockDim.x) {
+        const int i = tile + (int)threadIdx.x;
+        const int s = i < n ? segOf[i] : -1;
+        const int s0 = segOf[tile];
+        // a workgroup whose primitives all belong to one segment (every workgroup of the upper levels) bins in LDS and adds
+        // its 336 words to the segment's bins once: 16 x fewer atomics on the few words all primitives of a large node share
+        const bool uniform = __syncthreads_and(i >= n || s == s0) != 0 && s0 >= 0;
+        if (uniform) {
+            for (int k = threadIdx.x; k < 3 * kSahBins * kSahBinWords; k += blockDim.x) {
+                const int w = k % kSahBinWords;
+                local[k] = w == 0 ? 0u : (w <= 3 ? 0xffffffffu : 0u);
+            }
+            __syncthreads();
+        }
+        if (s >= 0) {
+            const SahSeg& sg = segs[s];
+            const Box3 pb = primBox[ids[i]];
+            float c[3];
+            box_centre(pb, c);
+            for (int a = 0; a < 3; a++) {
+                const float lo = ordered_float(sg.cb[a]), hi = ordered_float(sg.cb[3 + a]);
+                if (!(lo < hi)) continue;  // dead axis
+                const int b = sah_bin(c[a], lo, hi);
+                uint32_t* dst = uniform ? &local[(a * kSahBins + b) * kSahBinWords] : &bins[((size_t)s * 3 * kSahBins + a * kSahBins + b) * kSahBinWords];
+                sah_bin_add(dst, pb);
+            }
+        }
+        if (uniform) {
+            __syncthreads();
+            uint32_t* dst = &bins[(size_t)s0 * 3 * kSahBins * kSahBinWords];
+            for (int k = threadIdx.x; k < 3 * kSahBins * kSahBinWords; k += blockDim.x) {
+                const int w = k % kSahBinWords;
+                const uint32_t v = local[k];
+                if (w == 0) { if (v) atomicAdd(&dst[k], v); }
+                else if (w <= 3) { if (v != 0xffffffffu) atomicMin(&dst[k], v); }
+                else if (v) atomicMax(&dst[k], v);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void bin_box(const uint32_t* bin, Box3& b)
+{
+    for (int x = 0; x < 3; x++) { b.lo[x] = ordered_float(bin[1 + x]); b.hi[x] = ordered_float(bin[4 + x]); }
+}
+__device__ __forceinline__ void grow(Box3& a, const Box3& b)
+{
+    for (int x = 0; x < 3; x++) { a.lo[x] = fminf(a.lo[x], b.lo[x]); a.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+}
+__device__ __forceinline__ Box3 empty_box()
+{
+    Box3 b;
+    for (int x = 0; x < 3; x++) { b.lo[x] = 1e30f; b.hi[x] = -1e30f; }
+    return b;
+}
+
+// One thread per segment: the plane (BVH.cpp FindBestSplitPlane), the two children, their places in the next level.
+__global__ void __launch_bounds__(kBlock) sah_split_kernel(SahSeg* __restrict__ segs, const uint32_t segCount, const uint32_t* __restrict__ bins, const int n, Bvh2 t,
+                                                           SahSeg* __restrict__ nextSegs, SahSmall* __restrict__ small, SahCounters* __restrict__ ctr)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < segCount; s += gridDim.x * blockDim.x) {
+        SahSeg sg = segs[s];
+        const uint32_t* sb = &bins[(size_t)s * 3 * kSahBins * kSahBinWords];
+        float bestCost = 3.0e38f;
+        int axis = -1, plane = 0, countL = 0;
+        for (int a = 0; a < 3; a++) {
+            const float lo = ordered_float(sg.cb[a]), hi = ordered_float(sg.cb[3 + a]);
+            if (!(lo < hi)) continue;
+            // counts x areas of "bins above k", downwards, then the sweep upwards
+            float aboveCost[kSahBins];
+            int aboveCount[kSahBins];
+            Box3 run = empty_box();
+            int cnt = 0;
+            for (int k = kSahBins - 1; k >= 1; k--) {
+                const uint32_t* bin = &sb[(a * kSahBins + k) * kSahBinWords];
+                if (bin[0]) { Box3 b; bin_box(bin, b); grow(run, b); cnt += (int)bin[0]; }
+                aboveCount[k - 1] = cnt;
+                aboveCost[k - 1] = cnt ? (float)cnt * half_area(run) : 0.0f;
+            }
+            run = empty_box();
+            cnt = 0;
+            for (int k = 0; k < kSahBins - 1; k++) {
+                const uint32_t* bin = &sb[(a * kSahBins + k) * kSahBinWords];
+                if (bin[0]) { Box3 b; bin_box(bin, b); grow(run, b); cnt += (int)bin[0]; }
+                if (cnt == 0 || aboveCount[k] == 0) continue;  // nothing on one side: not a split
+                const float cost = (float)cnt * half_area(run) + aboveCost[k];
+                if (cost < bestCost) { bestCost = cost; axis = a; plane = k; countL = cnt; }
+            }
+        }
+        Box3 childBox[2];
+        if (axis >= 0) {
+            childBox[0] = empty_box();
+            childBox[1] = empty_box();
+            for (int k = 0; k < kSahBins; k++) {
+                const uint32_t* bin = &sb[(axis * kSahBins + k) * kSahBinWords];
+                if (bin[0]) { Box3 b; bin_box(bin, b); grow(childBox[k <= plane ? 0 : 1], b); }
+            }
+        } else {
+            // no axis separates the centroids (or the boxes hold NaNs): halves by position under the node's own box — conservative
+            countL = sg.count / 2;
+            childBox[0] = childBox[1] = t.box[sg.node];
+        }
+        sg.axis = axis;
+        sg.plane = plane;
+        sg.countL = countL;
+        int childId[2];
+        for (int h = 0; h < 2; h++) {
+            const int first = h == 0 ? sg.first : sg.first + countL, count = h == 0 ? countL : sg.count - countL;
+            sg.child[h] = -1;
+            if (count == 1) {
+                childId[h] = (n - 1) + first;  // a leaf: its box is its primitive's, filled in when the order is final
+            } else {
+                const int id = (int)atomicAdd(&ctr->nodes, 1u);
+                childId[h] = id;
+                t.box[id] = childBox[h];
+                t.count[id] = count;
+                if (count <= kSahSmall) {
+                    small[atomicAdd(&ctr->smallCount, 1u)] = SahSmall{first, count, id};
+                } else {
+                    const int at = (int)atomicAdd(&ctr->nextCount, 1u);
+                    SahSeg c{};
+                    c.first = first; c.count = count; c.node = id;
+                    for (int x = 0; x < 3; x++) { c.cb[x] = 0xffffffffu; c.cb[3 + x] = 0u; }
+                    if (axis < 0)
+                        for (int x = 0; x < 6; x++) c.cb[x] = sg.cb[x];  // (the scatter pass collects nothing for a position split)
+                    c.child[0] = c.child[1] = -1;
+                    nextSegs[at] = c;
+                    sg.child[h] = at;
+                }
+            }
+            t.parent[childId[h]] = sg.node;
+        }
+        t.left[sg.node] = childId[0];
+        t.right[sg.node] = childId[1];
+        segs[s] = sg;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) sah_flag_kernel(const Box3* __restrict__ primBox, const int* __restrict__ ids, const int* __restrict__ segOf, const int n,
+                                                          const SahSeg* __restrict__ segs, int* __restrict__ flag)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int s = segOf[i];
+        flag[i] = (s >= 0 && sah_goes_left(segs[s], primBox[ids[i]], i)) ? 1 : 0;
+    }
+}
+
+// every primitive to its place in the next level's order; the children's centroid bounds on the way
+__global__ void __launch_bounds__(kBlock) sah_scatter_kernel(const Box3* __restrict__ primBox, const int* __restrict__ ids, const int* __restrict__ segOf, const int n,
+                                                             const SahSeg* __restrict__ segs, const int* __restrict__ flag, const int* __restrict__ scan,
+                                                             int* __restrict__ idsOut, int* __restrict__ segOfOut, SahSeg* __restrict__ nextSegs)
+{
+    for (int tile = blockIdx.x * blockDim.x; tile < n; tile += gridDim.x * blockDim.x) {
+        const int i = tile + (int)threadIdx.x;
+        int child = -1;
+        float c[3] = {0.0f, 0.0f, 0.0f};
+        bool collect = false;
+        if (i < n) {
+            const int s = segOf[i];
+            const int prim = ids[i];
+            if (s < 0) {
+                idsOut[i] = prim;
+                segOfOut[i] = -1;
+            } else {
+                const SahSeg& sg = segs[s];
+                const int leftBefore = scan[i] - scan[sg.first];
+                const bool left = flag[i] != 0;
+                const int pos = left ? sg.first + leftBefore : sg.first + sg.countL + ((i - sg.first) - leftBefore);
+                child = sg.child[left ? 0 : 1];
+                idsOut[pos] = prim;
+                segOfOut[pos] = child;
+                if (child >= 0 && sg.axis >= 0) {
+                    box_centre(primBox[prim], c);
+                    collect = true;
+                }
+            }
+        }
+        // centroid bounds of the child segments: one set of atomics per wave where the wave's primitives share a child
+        const int child0 = __shfl(child, __ffsll((long long)__ballot(collect)) - 1);
+        const bool waveUniform = __ballot(collect && child != child0) == 0ull;
+        if (waveUniform) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                lo[a] = collect ? c[a] : 1e30f;
+                hi[a] = collect ? c[a] : -1e30f;
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+                    hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+                }
+            }
+            if (__ballot(collect) != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(collect)) - 1)) {
+                for (int a = 0; a < 3; a++) {
+                    atomicMin(&nextSegs[child0].cb[a], float_ordered(lo[a]));
+                    atomicMax(&nextSegs[child0].cb[3 + a], float_ordered(hi[a]));
+                }
+            }
+        } else if (collect) {
+            for (int a = 0; a < 3; a++) {
+                atomicMin(&nextSegs[child].cb[a], float_ordered(c[a]));
+                atomicMax(&nextSegs[child].cb[3 + a], float_ordered(c[a]));
+            }
+        }
+    }
+}
+
+// Segments of at most kSahSmall primitives, one thread each: exact sweep over the three centroid orders (every partition of
+// the sorted order is tried, count x area as above), children created depth first.
+__global__ void __launch_bounds__(64) sah_small_kernel(const Box3* __restrict__ primBox, int* __restrict__ ids, const SahSmall* __restrict__ small, const uint32_t smallCount,
+                                                       const int n, Bvh2 t, SahCounters* __restrict__ ctr)
+{
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < smallCount; w += gridDim.x * blockDim.x) {
+        const SahSmall sm = small[w];
+        int id[kSahSmall];
+        Box3 box[kSahSmall];
+        for (int k = 0; k < sm.count; k++) {
+            id[k] = ids[sm.first + k];
+            box[k] = primBox[id[k]];
+        }
+        int stFirst[kSahSmall], stCount[kSahSmall], stNode[kSahSmall], top = 0;
+        stFirst[top] = 0; stCount[top] = sm.count; stNode[top++] = sm.node;
+        while (top > 0) {
+            top--;
+            const int first = stFirst[top], count = stCount[top], node = stNode[top];
+            float bestCost = 3.0e38f;
+            int bestPerm[kSahSmall], bestK = count / 2;
+            for (int k = 0; k < count; k++) bestPerm[k] = first + k;
+            for (int a = 0; a < 3; a++) {
+                int perm[kSahSmall];
+                float key[kSahSmall];
+                for (int k = 0; k < count; k++) {  // insertion sort by the centroid coordinate
+                    const float c = 0.5f * (box[first + k].lo[a] + box[first + k].hi[a]);
+                    int j = k;
+                    while (j > 0 && key[j - 1] > c) { key[j] = key[j - 1]; perm[j] = perm[j - 1]; j--; }
+                    key[j] = c;
+                    perm[j] = first + k;
+                }
+                float above[kSahSmall];
+                Box3 run = empty_box();
+                for (int k = count - 1; k >= 1; k--) {
+                    grow(run, box[perm[k]]);
+                    above[k] = (float)(count - k) * half_area(run);
+                }
+                run = empty_box();
+                for (int k = 1; k < count; k++) {
+                    grow(run, box[perm[k - 1]]);
+                    const float cost = (float)k * half_area(run) + above[k];
+                    if (cost < bestCost) {
+                        bestCost = cost;
+                        bestK = k;
+                        for (int j = 0; j < count; j++) bestPerm[j] = perm[j];
+                    }
+                }
+            }
+            {  // the chosen order, in place
+                int nid[kSahSmall];
+                Box3 nbox[kSahSmall];
+                for (int k = 0; k < count; k++) { nid[k] = id[bestPerm[k]]; nbox[k] = box[bestPerm[k]]; }
+                for (int k = 0; k < count; k++) { id[first + k] = nid[k]; box[first + k] = nbox[k]; }
+            }
+            int childId[2];
+            for (int h = 0; h < 2; h++) {
+                const int cf = h == 0 ? first : first + bestK, cc = h == 0 ? bestK : count - bestK;
+                if (cc == 1) {
+                    childId[h] = (n - 1) + sm.first + cf;
+                } else {
+                    const int nid = (int)atomicAdd(&ctr->nodes, 1u);
+                    childId[h] = nid;
+                    Box3 b = empty_box();
+                    for (int k = 0; k < cc; k++) grow(b, box[cf + k]);
+                    t.box[nid] = b;
+                    t.count[nid] = cc;
+                    stFirst[top] = cf; stCount[top] = cc; stNode[top++] = nid;
+                }
+                t.parent[childId[h]] = node;
+            }
+            t.left[node] = childId[0];
+            t.right[node] = childId[1];
+        }
+        for (int k = 0; k < sm.count; k++) ids[sm.first + k] = id[k];
+    }
+}
+
+// the leaves' boxes, once the order is final
+__global__ void __launch_bounds__(kBlock) sah_leaves_kernel(const Box3* __restrict__ primBox, const int* __restrict__ ids, const int n, Bvh2 t)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) t.box[(n - 1) + k] = primBox[ids[k]];
+}
+
+// ---- 4c. the collapse's cost table, bottom-up like the bounds: the second child to arrive at a node fills its seven entries
 __device__ __forceinline__ Eval eval_of(const Bvh2& t, const int n, const int node, const int i, const bool fresh)
 {
     if (node >= n - 1) return Eval{half_area(t.box[node]) * kCostPrim, kDecLeaf, 0, 0, 0};  // one primitive: a leaf slot whatever i
@@ -608,7 +1008,59 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !count.alloc(inner * 4) ||
         !box.alloc(all * sizeof(Box3)) || !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
     Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>(), nullptr};
-    if (plocRadius <= 0) {
+    const uint32_t* leafOrder = orderSorted.as<uint32_t>();  // leaf k of the binary tree = primitive leafOrder[k]
+    DevBuf sahIdsA, sahIdsB;
+    if (plocRadius < 0) {
+        // top-down binned SAH (4d), level by level
+        const size_t maxSegs = (size_t)n / (kSahSmall + 1) + 2, binWords = (size_t)3 * kSahBins * kSahBinWords;
+        DevBuf segOfA, segOfB, flag, scan, scanTemp, segsA, segsB, small, ctr, bins, rootBox;
+        if (!sahIdsA.alloc((size_t)n * 4) || !sahIdsB.alloc((size_t)n * 4) || !segOfA.alloc((size_t)n * 4) || !segOfB.alloc((size_t)n * 4) || !flag.alloc((size_t)n * 4) ||
+            !scan.alloc((size_t)n * 4) || !segsA.alloc(maxSegs * sizeof(SahSeg)) || !segsB.alloc(maxSegs * sizeof(SahSeg)) || !small.alloc(((size_t)n / 2 + 2) * sizeof(SahSmall)) ||
+            !ctr.alloc(sizeof(SahCounters)) || !bins.alloc(maxSegs * binWords * 4) || !rootBox.alloc(6 * 4)) return NXHIP_ERR_HIP;
+        size_t scanBytes = 0;
+        NX_HIP(rocprim::exclusive_scan(nullptr, scanBytes, flag.as<int>(), scan.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
+        if (!scanTemp.alloc(std::max<size_t>(scanBytes, 16))) return NXHIP_ERR_HIP;
+        const uint32_t boxInit[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        const SahCounters ctrInit{1u, 0u, 0u, 0u};
+        NX_HIP(hipMemcpyAsync(rootBox.p, boxInit, sizeof boxInit, hipMemcpyHostToDevice, st));
+        NX_HIP(hipMemcpyAsync(ctr.p, &ctrInit, sizeof ctrInit, hipMemcpyHostToDevice, st));
+        NX_HIP(hipMemcpyAsync(sahIdsA.p, orderSorted.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));  // start from the Morton order: neighbours in memory are neighbours in space
+        box_union_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), n, rootBox.as<uint32_t>());
+        int *ids = sahIdsA.as<int>(), *idsNext = sahIdsB.as<int>(), *segOf = segOfA.as<int>(), *segOfNext = segOfB.as<int>();
+        SahSeg *segs = segsA.as<SahSeg>(), *segsNext = segsB.as<SahSeg>();
+        sah_root_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(bounds.as<uint32_t>(), rootBox.as<uint32_t>(), (int)n, t, segs, segOf);
+        uint32_t segCount = 1;
+        SahCounters h{};
+        for (int level = 0; segCount > 0; level++) {
+            if (level > 4096 || segCount > maxSegs) {
+                set_error("lbvh_build: the top-down build does not terminate");
+                return NXHIP_ERR_INVALID;
+            }
+            sah_bins_init_kernel<<<grid_for((uint32_t)std::min<size_t>(segCount * binWords, 0x7fffffffu), cus), kBlock, 0, st>>>(bins.as<uint32_t>(), segCount * binWords);
+            sah_bin_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, bins.as<uint32_t>());
+            sah_split_kernel<<<grid_for(segCount, cus), kBlock, 0, st>>>(segs, segCount, bins.as<uint32_t>(), (int)n, t, segsNext, small.as<SahSmall>(), ctr.as<SahCounters>());
+            sah_flag_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, flag.as<int>());
+            NX_HIP(rocprim::exclusive_scan(scanTemp.p, scanBytes, flag.as<int>(), scan.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
+            sah_scatter_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, flag.as<int>(), scan.as<int>(), idsNext, segOfNext, segsNext);
+            NX_HIP(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+            NX_HIP(hipStreamSynchronize(st));
+            segCount = h.nextCount;
+            const uint32_t zero = 0;
+            NX_HIP(hipMemcpyAsync(&ctr.as<SahCounters>()->nextCount, &zero, 4, hipMemcpyHostToDevice, st));
+            std::swap(ids, idsNext);
+            std::swap(segOf, segOfNext);
+            std::swap(segs, segsNext);
+        }
+        if (h.smallCount) sah_small_kernel<<<(int)std::min<uint32_t>((h.smallCount + 63) / 64, (uint32_t)(64 * cus)), 64, 0, st>>>(triBox.as<Box3>(), ids, small.as<SahSmall>(), h.smallCount, (int)n, t, ctr.as<SahCounters>());
+        sah_leaves_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, (int)n, t);
+        NX_HIP(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+        NX_HIP(hipStreamSynchronize(st));
+        if (h.nodes != n - 1) {
+            set_error("lbvh_build: the top-down build made " + std::to_string(h.nodes) + " internal nodes for " + std::to_string(n) + " primitives");
+            return NXHIP_ERR_INVALID;
+        }
+        leafOrder = reinterpret_cast<const uint32_t*>(ids);
+    } else if (plocRadius == 0) {
         NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
         radix_tree_kernel<<<grid_for(n - 1, cus), kBlock, 0, st>>>(codesSorted.as<unsigned long long>(), (int)n, t);
         fit_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), orderSorted.as<uint32_t>(), (int)n, t);
@@ -681,7 +1133,7 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
             set_error("lbvh_build: the collapse does not terminate");
             return NXHIP_ERR_INVALID;
         }
-        collapse_level_kernel<<<grid_for(workCount, cus), kBlock, 0, st>>>(t, (int)n, orderSorted.as<uint32_t>(), cur, workCount, nxt, counters.as<uint32_t>(), nodes.as<nx_bvh8_node>(),
+        collapse_level_kernel<<<grid_for(workCount, cus), kBlock, 0, st>>>(t, (int)n, leafOrder, cur, workCount, nxt, counters.as<uint32_t>(), nodes.as<nx_bvh8_node>(),
                                                                            primIdx.as<uint32_t>(), nodeCapacity);
         uint32_t h[3];
         NX_HIP(hipMemcpyAsync(h, counters.p, sizeof h, hipMemcpyDeviceToHost, st));

@@ -643,7 +643,7 @@ try {
 int nxhip_set_device_builder(nxhip_ctx* c, int clusteringRadius)
 {
     NX_CHECK_CTX(c);
-    if (clusteringRadius < 0 || clusteringRadius > 256) return fail_invalid("nxhip_set_device_builder: radius must be in [0, 256]");
+    if (clusteringRadius < NXHIP_BUILDER_SAH || clusteringRadius > 256) return fail_invalid("nxhip_set_device_builder: NXHIP_BUILDER_SAH (-1), 0 (radix tree) or a clustering radius up to 256");
     c->deviceBuilderRadius = clusteringRadius;
     return NXHIP_OK;
 }

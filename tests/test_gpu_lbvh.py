@@ -41,6 +41,7 @@ def _check_structure(nodes, idx, tris):
 
 MESHES = {
     "soup": lambda: scenegen.random_soup(5000, seed=3),
+    "soup40k": lambda: scenegen.random_soup(40000, seed=8, extent=1.0, size=0.03),
     "torus": lambda: scenegen.displaced_torus(96, 48, seed=2),
     "tiny": lambda: scenegen.random_soup(5, seed=1),
     "nine": lambda: scenegen.random_soup(9, seed=4),
@@ -50,10 +51,11 @@ MESHES = {
 }
 
 
-@pytest.mark.parametrize("radius", [0, 16, 3])
+@pytest.mark.parametrize("radius", [0, 16, 3, -1])
 @pytest.mark.parametrize("name", list(MESHES))
 def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name, radius):
-    """both device builders: the radix tree (radius 0) and locally-ordered clustering with a wide and a narrow search window"""
+    """the three device builders: the radix tree (radius 0), locally-ordered clustering with a wide and a narrow search window,
+    and the top-down binned SAH build (NXHIP_BUILDER_SAH = -1)"""
     tris = np.ascontiguousarray(MESHES[name](), dtype=pod.TRI_DT)
     ctx = gpu_ctx_factory(32, 32)
     ctx.set_device_builder(radius)
@@ -62,7 +64,8 @@ def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name, 
     _check_structure(nodes, idx, tris)
 
 
-def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_factory):
+@pytest.mark.parametrize("builders", [(16, 0), (-1, -1)], ids=["clustering+radix", "top-down-sah"])
+def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_factory, builders):
     """Same scene twice: BLASes from the host SAH builder vs. built on the device; the oracle traverses the SAH version.
     Hit distances are identical (the closest hit does not depend on the tree); ids may differ only on equidistant ties."""
     meshes = [scenegen.displaced_torus(128, 64, seed=3, major=0.6, minor=0.25, amp=0.05), scenegen.random_soup(3000, seed=9, extent=0.6, size=0.05)]
@@ -75,9 +78,10 @@ def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_fac
     scene.upload(ref)
     assert SH.hit_records_equal(ref.trace_batch(rays), want)
     ctx = gpu_ctx_factory(32, 32)
-    ctx.set_device_builder(16)  # one mesh through the clustering builder, one through the radix tree
+    first, second = builders
+    ctx.set_device_builder(first)
     ids = [ctx.build_blas(scene.meshes[0])]
-    ctx.set_device_builder(0)
+    ctx.set_device_builder(second)
     ids.append(ctx.build_blas(scene.meshes[1]))
     assert ids == [0, 1]
     # the instances' world bounds come from the BLAS root frame (BVHInstance.cpp:8-21): recompute them for the device-built roots
@@ -94,17 +98,19 @@ def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_fac
     assert np.array_equal(occl, ref.trace_shadow_batch(rays[:5000], np.full(5000, 3.0, np.float32)))
 
 
-def test_device_build_of_a_million_triangles_is_fast_and_valid(gpu_ctx_factory):
+@pytest.mark.parametrize("builder", [0, -1], ids=["radix", "top-down-sah"])
+def test_device_build_of_a_million_triangles_is_fast_and_valid(gpu_ctx_factory, builder):
     import time
 
     tris = scenegen.displaced_torus(1024, 512, seed=1, major=1.0, minor=0.45, amp=0.06)
     ctx = gpu_ctx_factory(32, 32)
+    ctx.set_device_builder(builder)
     ctx.build_blas(scenegen.random_soup(100, seed=1))  # first use: code objects, sort temporaries
     t0 = time.time()
     bid = ctx.build_blas(tris)
     dt = time.time() - t0
     nodes, idx = ctx.read_blas(bid, len(tris))
-    print("device build of %d triangles: %.3f s including the upload, %d nodes" % (len(tris), dt, len(nodes)))
+    print("device build (%s) of %d triangles: %.3f s including the upload, %d nodes" % ("radix tree" if builder == 0 else "top-down SAH", len(tris), dt, len(nodes)))
     assert dt < 2.0
     assert sorted(idx.tolist()) == list(range(len(tris)))
     assert len(nodes) < len(tris) // 3
