@@ -52,23 +52,25 @@ int nxhip_sync(nxhip_ctx *ctx);
  * (symbol `bvhs`).  Returns the BLAS id == index instances refer to as bvhIdx.  ids are dense from 0. */
 int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const nx_triangle *tris,
                       uint32_t triCount, const uint32_t *triIdx, int32_t *blasId);
-/* BLAS built ON THE DEVICE from triangles alone: 63-bit Morton codes, radix sort, Karras' binary
- * radix tree, bottom-up bounds, then a level-by-level collapse into the same 80-byte nodes (children opened by largest
- * surface area, leaf slots of at most three triangles, the reference's octant slot assignment and quantisation).  Replaces
- * BVH2::Build + BVH8Builder::Init / Build + BVH8::InitDeviceData (Geometry/BVH/BVH.cpp:13-210, BVH8Builder.cpp:10-393,
- * BVH8.cpp:28-33) when build time matters more than tree quality: a valid, conservative CWBVH whose node bytes differ from
- * the SAH builder's (another tree); hit records are the same up to equidistant ties, traversal visits more nodes.  Returns
- * the BLAS id like nxhip_upload_blas. */
+/* BLAS built ON THE DEVICE from triangles alone.  Replaces BVH2::Build + BVH8Builder::Init /
+ * Build + BVH8::InitDeviceData (Geometry/BVH/BVH.cpp:13-210, BVH8Builder.cpp:10-393, BVH8.cpp:28-33) with the same two
+ * steps in HBM: a binary tree by the reference's rule — top-down, binned surface-area heuristic over the centroid bounds,
+ * one primitive per leaf, "split in half" when nothing separates (level-synchronous: atomics into 16 bins per axis and node,
+ * a scan partition per level, nodes of up to 8 primitives finished by an exact sweep) — and the reference's SAH dynamic
+ * programme for the collapse into 80-byte 8-wide nodes (cost table bottom-up, decisions followed top-down, the reference's
+ * octant slot assignment and quantisation).  36 ms per million triangles (host builder of this repo: 0.4 s on 16 threads; the
+ * reference: ~10 s on one) and fewer node visits per ray than the host build on every mesh of
+ * profiles/r03_builder_quality.txt.  A valid, conservative CWBVH whose node bytes differ from the host builder's (another
+ * tree); hit records are the same up to equidistant ties.  Returns the BLAS id like nxhip_upload_blas. */
 int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount, int32_t *blasId);
 /* Which binary tree the device builders (nxhip_build_blas, nxhip_rebuild_tlas) collapse into 8-wide nodes.
- * 0 (default): the binary radix tree of the Morton codes (LBVH), one launch.  clusteringRadius > 0: parallel locally-ordered
+ * NXHIP_BUILDER_SAH (default): the top-down binned SAH build described above.  0: the binary radix tree of the 63-bit
+ * Morton codes (LBVH: sort + one launch; 21 ms per million triangles).  clusteringRadius > 0: parallel locally-ordered
  * clustering — the Morton-sorted primitives are merged bottom-up, every cluster pairing with the neighbour within `radius`
- * places whose union has the smallest surface area; a few dozen rounds, same build time to within a few milliseconds.
- * Measured (profiles/r03_builder_quality.txt): the clustering visits fewer nodes per ray on a height field and on replicated
- * Cornell boxes (-10 % / -5 %), more on the regular torus and on triangle soup (+11 % / +15 %), and the host's binned-SAH build
- * stays ahead of both on irregular meshes (-20 %); in rays per second the three are within 7 % — hence the cheaper default.
- * Either way the result is a valid conservative CWBVH. */
-#define NXHIP_BUILDER_SAH (-1) /* top-down binned surface-area build on the device (the host builder's rule, nx_lbvh.hip 4d) */
+ * places whose union has the smallest surface area; a few dozen rounds.  All three go through the same SAH collapse.
+ * Measured (profiles/r03_builder_quality.txt, node visits per ray against the host SAH build): top-down SAH -1 ... -14 %,
+ * radix tree +1 ... +25 %, clustering +2 ... +15 %.  Either way the result is a valid conservative CWBVH. */
+#define NXHIP_BUILDER_SAH (-1)
 int nxhip_set_device_builder(nxhip_ctx *ctx, int clusteringRadius);
 /* Read a BLAS's nodes / primitive index list back (either may be NULL; *nodeCount = nodes it has). */
 int nxhip_read_blas(nxhip_ctx *ctx, int32_t blasId, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *primIdx, uint32_t primCapacity,
@@ -77,9 +79,9 @@ int nxhip_clear_blas(nxhip_ctx *ctx);
 /* TLAS::UpdateDeviceData — Geometry/BVH/TLAS.cpp:93-100 (symbols `tlas`, `blas`). */
 int nxhip_set_tlas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCount, const uint32_t *instanceIdx,
                    const nx_bvh_instance *instances, uint32_t instanceCount);
-/* TLAS built ON THE DEVICE from the instances alone ("refit / rebuild on device"): the linear-BVH
- * builder of nxhip_build_blas run over the instances' world-space boxes (Morton codes of the box centres, radix sort, Karras'
- * radix tree, bottom-up bounds, level-wise collapse into 80-byte nodes with up to three instances per leaf slot), then
+/* TLAS built ON THE DEVICE from the instances alone ("refit / rebuild on device"): the builder
+ * of nxhip_build_blas (whichever nxhip_set_device_builder selected; default: top-down binned SAH) run over the instances'
+ * world-space boxes, collapsed into 80-byte nodes with up to three instances per leaf slot, then
  * installed exactly as nxhip_set_tlas installs a host-built tree (instances[i].boundsMin / boundsMax must be filled in, as
  * BVHInstance::SetTransform does).  Replaces TLAS::Build + TLAS::Convert — the reference's O(n^2) agglomerative clustering
  * on the CPU and BVH8 conversion, re-run on every edit (Geometry/BVH/TLAS.cpp:13-91, Scene/Scene.cpp:29-55) — when instances are
