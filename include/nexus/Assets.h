@@ -4,6 +4,7 @@
 // them raw: DeviceVector<Material, D_Material> with no ToDevice, AssetManager.h:55).
 #pragma once
 
+#include <functional>
 #include <set>
 #include <string>
 #include <vector>
@@ -74,7 +75,12 @@ struct MeshInstance {
 class AssetManager {
 public:
     void Reset();
-    int32_t CreateBVH(const std::vector<Triangle>& triangles);  // BVH8Builder(tris).Init().Build()
+    int32_t CreateBVH(const std::vector<Triangle>& triangles);  // BVH8Builder(tris).Init().Build(), or the installed builder
+    // Extension: who builds a mesh's BVH8.  Default (empty): the host builder, as the reference.  PathTracer::SetDeviceBlasBuild
+    // installs one that builds on the GPU (nxhip_build_blas) and returns the tree with deviceBlasId set; `index` is the id the
+    // new BVH will have in GetBVHs().
+    using BlasBuilder = std::function<BVH8(const std::vector<Triangle>& triangles, size_t index)>;
+    void SetBlasBuilder(BlasBuilder builder) { m_BlasBuilder = std::move(builder); }
     int32_t AddMesh(Mesh&& mesh);
     void AddMaterial();
     int AddMaterial(const Material& material);
@@ -101,6 +107,7 @@ private:
     std::vector<Texture> m_DiffuseMaps, m_EmissiveMaps;
     std::vector<BVH8> m_Bvhs;
     std::vector<Mesh> m_Meshes;
+    BlasBuilder m_BlasBuilder;
 };
 
 }  // namespace nexus

@@ -26,6 +26,11 @@ public:
     void Render(const Scene& scene);  // one frame: generate, trace, pathLength x (logic, shade, trace, shadow), accumulate
     void OnResize(uint32_t width, uint32_t height);
     void UpdateDeviceScene(const Scene& scene);
+    // Extension, off by default: meshes added to `scene` from now on get their BVH8 from the device builder (nxhip_build_blas:
+    // the reference's binned-SAH rule and SAH-DP collapse run in HBM, a tenth of the host builder's time) instead of
+    // AssetManager::CreateBVH's host build; the nodes come back once, so BVH8::nodes / triangleIdx hold the tree as they do for
+    // a host-built one.  The scene must not outlive this PathTracer while the switch is on.
+    void SetDeviceBlasBuild(Scene& scene, bool enable);
     void SetPixelQuery(uint32_t x, uint32_t y);
     int32_t GetSelectedInstance();
     uint32_t GetFrameNumber() const { return m_FrameNumber; }
@@ -52,6 +57,7 @@ public:
     uint32_t GetHeight() const { return m_ViewportHeight; }
 
 private:
+    void UploadPendingBlas(AssetManager& assets);
     nxhip_ctx* m_Ctx = nullptr;
     uint32_t m_FrameNumber = 0;
     uint32_t m_FramesPerPass = 1;

@@ -29,6 +29,9 @@ public:
     // Extension: the float accumulation as OpenEXR (scanline, uncompressed, 32-bit float R G B), top row first.
     bool SaveAccumulationEXR(const std::string& filepath);
 
+    // Extension: PathTracer::SetDeviceBlasBuild for the renderer's scene (meshes loaded from now on are built on the GPU)
+    void SetDeviceBlasBuild(bool enable) { m_PathTracer.SetDeviceBlasBuild(*m_Scene, enable); }
+
     PathTracer& GetPathTracer() { return m_PathTracer; }
     uint32_t GetFrameNumber() const { return m_PathTracer.GetFrameNumber(); }
     // MetricsPanel: samples per second over the frames rendered since the last Reset, in millions (width * height * frames / s)

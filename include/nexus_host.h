@@ -119,6 +119,9 @@ int nxs_pathtracer_set_modes(nxs_pathtracer *p, int rngMode, int compactMode, in
  * Render() calls in flight */
 int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer *p, uint32_t frames);
 int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer *p, uint32_t passes);
+/* PathTracer::SetDeviceBlasBuild (extension, off by default): meshes added to `s` from now on get their BVH8 from the device
+ * builder (nxhip_build_blas) instead of the host's; switch it off, or destroy the scene, before `p` goes away. */
+int nxs_pathtracer_set_device_blas_build(nxs_pathtracer *p, nxs_scene *s, int enable);
 int nxs_pathtracer_update_device_scene(nxs_pathtracer *p, nxs_scene *s);
 int nxs_pathtracer_render(nxs_pathtracer *p, nxs_scene *s);
 int nxs_pathtracer_reset_frame_number(nxs_pathtracer *p);

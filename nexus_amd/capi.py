@@ -38,7 +38,7 @@ HOST_SYMBOLS = [
     "nxs_renderer_save_screenshot", "nxs_renderer_save_exr", "nxs_renderer_frame_number", "nxs_renderer_megasamples_per_second", "nxs_renderer_device_context",
     "nxs_renderer_set_modes",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
-    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit", "nxs_scene_set_device_tlas",
+    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit", "nxs_scene_set_device_tlas", "nxs_pathtracer_set_device_blas_build",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
     "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes", "nxs_pathtracer_set_frames_per_pass", "nxs_pathtracer_set_passes_in_flight",
@@ -501,9 +501,9 @@ class Context:
         check(self.L.nxhip_read_blas(self.h, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
         return nodes, idx
 
-    def set_device_builder(self, clustering_radius=0):
-        """device BLAS / TLAS builders: 0 = radix tree (LBVH, the default), > 0 = clustering (PLOC) with this search radius,
-        -1 (NXHIP_BUILDER_SAH) = top-down binned SAH"""
+    def set_device_builder(self, clustering_radius=-1):
+        """device BLAS / TLAS builders: -1 (NXHIP_BUILDER_SAH, the default) = top-down binned SAH, 0 = radix tree (LBVH),
+        > 0 = clustering (PLOC) with this search radius"""
         check(self.L.nxhip_set_device_builder(self.h, int(clustering_radius)), "nxhip_set_device_builder")
 
     def release_queues(self):
@@ -948,6 +948,11 @@ class PathTracer:
     def set_passes_in_flight(self, passes):
         _scheck(self.L.nxs_pathtracer_set_passes_in_flight(self.h, passes), "nxs_pathtracer_set_passes_in_flight")
 
+    def set_device_blas_build(self, scene, enable=True):
+        """PathTracer::SetDeviceBlasBuild: meshes added to `scene` from now on are built into BVH8s on the GPU"""
+        self.L.nxs_pathtracer_set_device_blas_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _scheck(self.L.nxs_pathtracer_set_device_blas_build(self.h, scene.h, 1 if enable else 0), "nxs_pathtracer_set_device_blas_build")
+
     def update_device_scene(self, scene):
         _scheck(self.L.nxs_pathtracer_update_device_scene(self.h, scene.h), "nxs_pathtracer_update_device_scene")
 
@@ -969,3 +974,14 @@ class PathTracer:
         out = np.zeros((self.width * self.height, 3), np.float32)
         check(self.L.nxhip_read_radiance(self.L.nxs_pathtracer_device_context(self.h), _ptr(out)), "nxhip_read_radiance")
         return out
+
+    def read_blas(self, blas_id, tri_count):
+        """nodes and primitive index list of BLAS `blas_id` of this path tracer's device context"""
+        ctx = self.L.nxs_pathtracer_device_context(self.h)
+        self.L.nxhip_read_blas.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        n = C.c_uint32(0)
+        check(self.L.nxhip_read_blas(ctx, blas_id, None, 0, None, 0, C.byref(n)), "nxhip_read_blas")
+        nodes = np.zeros(n.value, dtype=pod.NODE_DT)
+        idx = np.zeros(tri_count, dtype=np.uint32)
+        check(self.L.nxhip_read_blas(ctx, blas_id, _ptr(nodes), n.value, _ptr(idx), tri_count, C.byref(n)), "nxhip_read_blas")
+        return nodes, idx

@@ -261,6 +261,10 @@ int nxs_pathtracer_set_modes(nxs_pathtracer* p, int rngMode, int compactMode, in
 }
 int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer* p, uint32_t frames) { return guarded([&] { p->pt.SetFramesPerPass(frames); }); }
 int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer* p, uint32_t passes) { return guarded([&] { p->pt.SetPassesInFlight(passes); }); }
+int nxs_pathtracer_set_device_blas_build(nxs_pathtracer* p, nxs_scene* s, int enable)
+{
+    return guarded([&] { p->pt.SetDeviceBlasBuild(s->scene, enable != 0); });
+}
 int nxs_pathtracer_update_device_scene(nxs_pathtracer* p, nxs_scene* s)
 {
     return guarded([&] { p->pt.UpdateDeviceScene(s->scene); });

@@ -19,6 +19,10 @@ void AssetManager::Reset()
 
 int32_t AssetManager::CreateBVH(const std::vector<Triangle>& triangles)
 {
+    if (m_BlasBuilder) {
+        m_Bvhs.push_back(m_BlasBuilder(triangles, m_Bvhs.size()));
+        return static_cast<int32_t>(m_Bvhs.size()) - 1;
+    }
     BVH8Builder builder(triangles);
     builder.Init();
     m_Bvhs.push_back(builder.Build());

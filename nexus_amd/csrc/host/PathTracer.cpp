@@ -54,22 +54,56 @@ void PathTracer::OnResize(uint32_t width, uint32_t height)
 
 void PathTracer::SetModes(int rngMode, int compactMode, int conductorMode) { Check(nxhip_set_modes(m_Ctx, rngMode, compactMode, conductorMode), "nxhip_set_modes"); }
 
-void PathTracer::UpdateDeviceScene(const Scene& scene)
+// BLAS k of the device == BVH k of the asset manager (instances carry the *mesh* id, whose bvhId the reference assumes equal:
+// Scene.cpp:69).  A scene that starts over (AssetManager::Reset) starts the device's list over too.
+void PathTracer::UploadPendingBlas(AssetManager& assets)
 {
-    const AssetManager& assets = scene.GetAssetManager();
-    AssetManager& mutableAssets = const_cast<AssetManager&>(assets);
-    // BLAS k of the device == BVH k of the asset manager (instances carry the *mesh* id, whose bvhId the reference assumes
-    // equal: Scene.cpp:69)
-    const std::vector<BVH8>& bvhs = assets.GetBVHs();
+    std::vector<BVH8>& bvhs = assets.GetBVHs();
+    if (assets.uploadedBvhs == 0 && !bvhs.empty()) Check(nxhip_clear_blas(m_Ctx), "nxhip_clear_blas");
     for (size_t i = assets.uploadedBvhs; i < bvhs.size(); i++) {
         std::vector<nx_triangle> tris(bvhs[i].triangles.size());
         for (size_t t = 0; t < tris.size(); t++) tris[t] = Triangle::ToDevice(bvhs[i].triangles[t]);
         int32_t id = -1;
         Check(nxhip_upload_blas(m_Ctx, bvhs[i].nodes.data(), static_cast<uint32_t>(bvhs[i].nodes.size()), tris.data(), static_cast<uint32_t>(tris.size()),
                                 bvhs[i].triangleIdx.data(), &id), "nxhip_upload_blas");
-        mutableAssets.GetBVHs()[i].deviceBlasId = id;
-        mutableAssets.uploadedBvhs = i + 1;
+        if (id != static_cast<int32_t>(i)) throw std::runtime_error("PathTracer: the device's BLAS ids and the asset manager's BVH ids have diverged");
+        bvhs[i].deviceBlasId = id;
+        assets.uploadedBvhs = i + 1;
     }
+}
+
+void PathTracer::SetDeviceBlasBuild(Scene& scene, bool enable)
+{
+    AssetManager& assets = scene.GetAssetManager();
+    if (!enable) {
+        assets.SetBlasBuilder(nullptr);
+        return;
+    }
+    assets.SetBlasBuilder([this, &assets](const std::vector<Triangle>& triangles, size_t index) {
+        // everything created before is on the device first, so that this tree's id there is its id here
+        UploadPendingBlas(assets);
+        if (assets.uploadedBvhs == 0) Check(nxhip_clear_blas(m_Ctx), "nxhip_clear_blas");
+        BVH8 bvh(triangles);
+        std::vector<nx_triangle> tris(triangles.size());
+        for (size_t t = 0; t < tris.size(); t++) tris[t] = Triangle::ToDevice(triangles[t]);
+        int32_t id = -1;
+        Check(nxhip_build_blas(m_Ctx, tris.data(), static_cast<uint32_t>(tris.size()), &id), "nxhip_build_blas");
+        if (id != static_cast<int32_t>(index)) throw std::runtime_error("PathTracer: the device's BLAS ids and the asset manager's BVH ids have diverged");
+        uint32_t nodeCount = 0;
+        Check(nxhip_read_blas(m_Ctx, id, nullptr, 0, nullptr, 0, &nodeCount), "nxhip_read_blas");
+        bvh.nodes.resize(nodeCount);
+        Check(nxhip_read_blas(m_Ctx, id, bvh.nodes.data(), nodeCount, bvh.triangleIdx.data(), static_cast<uint32_t>(bvh.triangleIdx.size()), &nodeCount), "nxhip_read_blas");
+        bvh.deviceBlasId = id;
+        assets.uploadedBvhs = index + 1;
+        return bvh;
+    });
+}
+
+void PathTracer::UpdateDeviceScene(const Scene& scene)
+{
+    const AssetManager& assets = scene.GetAssetManager();
+    AssetManager& mutableAssets = const_cast<AssetManager&>(assets);
+    UploadPendingBlas(mutableAssets);
     if (assets.texturesDirty) {
         Check(nxhip_clear_textures(m_Ctx), "nxhip_clear_textures");
         for (const Texture& t : assets.GetDiffuseMaps()) Check(nxhip_upload_texture(m_Ctx, 0, t.pixels.data(), t.width, t.height, nullptr), "nxhip_upload_texture");
