@@ -95,8 +95,8 @@ def build_workload(args):
     return sc, name, time.time() - t0
 
 
-def upload(ctx, sc, device_bvh=False):
-    sc.upload(ctx, device_bvh=device_bvh)
+def upload(ctx, sc, device_bvh=False, device_tlas=False):
+    sc.upload(ctx, device_bvh=device_bvh, device_tlas=device_tlas)
     ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
 
 
@@ -221,6 +221,8 @@ def main():
                                                             "algorithm) instead of building them on the GPU (nxhip_build_blas: the same rule top-down on the device with 16 bins, "
                                                             "then the same collapse; 36 ms instead of 0.4 s per million triangles and 2 % fewer node visits per ray)")
     ap.add_argument("--device-bvh", action="store_true", help="(the default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--host-tlas", action="store_true", help="with the device-built BLASes: the TLAS from the host builder (the reference's agglomerative clustering + collapse) "
+                                                             "instead of nxhip_rebuild_tlas")
     ap.add_argument("--pass-sizes", type=str, default="", help="experiment: explicit pass sizes of the timed region, e.g. 8,6,4,2 (must sum to --steps)")
     ap.add_argument("--emulate-rank-of", type=int, default=0,
                     help="N: after the full-frame measurement, render rank 0's share of an N-way tile split (same tiles, pass sizes and passes in flight as a "
@@ -329,7 +331,7 @@ def main():
         ctx = capi.Context(W, H, device=0)
     stamp("device context created")
     args.device_bvh = not args.host_bvh
-    upload(ctx, sc, device_bvh=args.device_bvh)
+    upload(ctx, sc, device_bvh=args.device_bvh, device_tlas=args.device_bvh and not args.host_tlas)
     stamp("scene uploaded")
 
     if dist_mode:
@@ -490,7 +492,8 @@ def main():
             "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
             "pass_sizes": schedule(args.steps), "frames_rendered_by_the_timed_loop": frames_rendered[0],
-            "host_scene_build_s": round(t_build, 2), "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
+            "host_scene_build_s": round(t_build, 2), "tlas_builder": "device (nxhip_rebuild_tlas)" if (args.device_bvh and not args.host_tlas) else "host: agglomerative clustering + SAH-DP collapse (the reference's algorithm)",
+            "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
         },
     }
 
@@ -578,6 +581,7 @@ def main():
             "avg_launch_ms": round(avg_ms, 5), "launches": launches, "rays_per_launch": int(rays_per_launch),
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
+            "instances_per_ray": round(closest["instances"] / max(1, closest["rays"]), 2),
             "simd": {"iters_per_ray_lane": round(64.0 * closest["waveIters"] / max(1, closest["rays"]), 2),
                      "active_frac": round(closest["lanesActive"] / max(1, 64 * closest["waveIters"]), 3),
                      "node_frac": round(closest["lanesNode"] / max(1, 64 * closest["waveIters"]), 3),

@@ -147,6 +147,7 @@ struct Bvh2 {
     Box3* box;     // [2n-1]
     int* arrived;  // [n-1]
     struct Eval* eval;  // [7 (n-1)] cost table of the collapse (internal nodes; a leaf's entries follow from its box), or nullptr
+    float primCost;     // the collapse's cost of testing one primitive of a leaf slot, relative to one node test
 };
 
 // One entry of the collapse's cost table (Ylitie, Karras, Laine 2017; the reference's BVH8Builder.cpp:63-117 and the host's
@@ -159,7 +160,12 @@ struct Eval {
     int8_t decision, leftCount, rightCount, pad_;
 };
 static_assert(sizeof(Eval) == 8, "one 8-byte word per entry");
-constexpr float kCostPrim = 0.3f, kCostNode = 1.0f;  // nexus::C_PRIM, C_NODE (include/nexus/BVH8.h)
+constexpr float kCostPrim = 0.3f, kCostNode = 1.0f;  // nexus::C_PRIM, C_NODE (include/nexus/BVH8.h): a triangle test against a node test
+// A TLAS "primitive" is an instance: entering one costs a loop iteration of its own (record fetch, transform, test of the BLAS
+// root) before anything of the BLAS is traversed, so instances that share a leaf slot are all entered by every ray that
+// touches the slot's box.  With the triangle's 0.3 the collapse packs up to three instances into a slot wherever that saves
+// a node; priced as what they are, instances get slots of their own.
+constexpr float kCostInstance = 4.0f;
 constexpr int kLeafMax = 3;                            // nexus::P_MAX
 
 __global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long long* __restrict__ codes, const int n, Bvh2 t)
@@ -710,7 +716,7 @@ __global__ void __launch_bounds__(kBlock) sah_leaves_kernel(const Box3* __restri
 // ---- 4c. the collapse's cost table, bottom-up like the bounds: the second child to arrive at a node fills its seven entries
 __device__ __forceinline__ Eval eval_of(const Bvh2& t, const int n, const int node, const int i, const bool fresh)
 {
-    if (node >= n - 1) return Eval{half_area(t.box[node]) * kCostPrim, kDecLeaf, 0, 0, 0};  // one primitive: a leaf slot whatever i
+    if (node >= n - 1) return Eval{half_area(t.box[node]) * t.primCost, kDecLeaf, 0, 0, 0};  // one primitive: a leaf slot whatever i
     const unsigned long long* p = reinterpret_cast<const unsigned long long*>(&t.eval[(size_t)node * 7 + i]);
     const unsigned long long w = fresh ? *reinterpret_cast<const volatile unsigned long long*>(p) : *p;
     Eval e;
@@ -746,7 +752,9 @@ __global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
                     if (c < best) { best = c; bl = a; br = j - 1 - a; }
                 }
                 if (i == 0) {
-                    const float leaf = prims <= kLeafMax ? area * (float)prims * kCostPrim : 1.0e30f;
+                    // (the root is a wide node whatever the table says: as a "leaf" it would be a node with one slot holding all
+                    //  its primitives — the table charges the node test to the other choice only)
+                    const float leaf = (prims <= kLeafMax && t.parent[node] >= 0) ? area * (float)prims * t.primCost : 1.0e30f;
                     const float inner = best + area * kCostNode;
                     e[0] = leaf < inner ? Eval{leaf, kDecLeaf, 0, 0, 0} : Eval{inner, kDecInternal, (int8_t)bl, (int8_t)br, 0};
                 } else {
@@ -984,7 +992,7 @@ int grid_for(uint32_t n, int cus) { return (int)std::min<uint32_t>((n + kBlock -
 
 // The build from primitive boxes on: Morton codes, sort, radix tree, bounds, collapse.  `triBox` / `bounds` (centroid bounds,
 // ordered-uint encoded) are on the device and filled by a kernel already queued on the stream.  primIdx: n entries.
-static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bounds, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
+static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bounds, uint32_t n, int plocRadius, float primCost, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
@@ -1007,7 +1015,7 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     DevBuf left, right, parent, first, last, count, box, arrived;
     if (!left.alloc(inner * 4) || !right.alloc(inner * 4) || !parent.alloc(all * 4) || !first.alloc(inner * 4) || !last.alloc(inner * 4) || !count.alloc(inner * 4) ||
         !box.alloc(all * sizeof(Box3)) || !arrived.alloc(inner * 4)) return NXHIP_ERR_HIP;
-    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>(), nullptr};
+    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), first.as<int>(), last.as<int>(), count.as<int>(), box.as<Box3>(), arrived.as<int>(), nullptr, primCost};
     const uint32_t* leafOrder = orderSorted.as<uint32_t>();  // leaf k of the binary tree = primitive leafOrder[k]
     DevBuf sahIdsA, sahIdsB;
     if (plocRadius < 0) {
@@ -1162,7 +1170,7 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadiu
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
     tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
-    const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, nodes, primIdx, nodeCount);
+    const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, kCostPrim, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
     NX_HIP(hipStreamSynchronize(st));
@@ -1181,7 +1189,10 @@ int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n,
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
     instance_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dInstances, n, box.as<Box3>(), bounds.as<uint32_t>());
-    const int rc = lbvh_from_boxes(c, box, bounds, n, plocRadius, nodes, primIdx, nodeCount);
+    float instanceCost = kCostInstance;
+    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1)
+        if (const char* e = std::getenv("NX_TLAS_PRIM_COST")) instanceCost = (float)std::atof(e);  // sweeps only
+    const int rc = lbvh_from_boxes(c, box, bounds, n, plocRadius, instanceCost, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     NX_HIP(hipStreamSynchronize(st));
     NX_HIP(hipGetLastError());

@@ -82,7 +82,7 @@ class Workload:
         """device bytes the trace kernels read from: 80-byte nodes + 48-byte intersection records + instance records"""
         return int(sum(80 * len(b[0]) + 48 * len(b[1]) for b in self.blas) + 80 * len(self.tlas_nodes) + 80 * len(self.instances))
 
-    def upload(self, ctx, device_bvh=False):
+    def upload(self, ctx, device_bvh=False, device_tlas=False):
         """device_bvh: build every BLAS on the GPU (nxhip_build_blas: LBVH + wide collapse) instead of uploading the host
         builder's; the instances' world bounds follow the BLAS root frame, so instances and TLAS are rebuilt for those roots."""
         ctx.clear_blas()
@@ -94,8 +94,11 @@ class Workload:
                 roots.append(ctx.read_blas(bid, len(tris))[0][0])
             insts = np.array([capi.instance_init(int(i["bvhIdx"]), int(i["materialId"]), i["transform"], roots[int(i["bvhIdx"])]) for i in self.instances],
                              dtype=pod.INST_DT)
-            tlas_nodes, tlas_idx = capi.tlas_build(insts)
-            ctx.set_tlas(tlas_nodes, tlas_idx, insts)
+            if device_tlas:
+                ctx.rebuild_tlas(insts)
+            else:
+                tlas_nodes, tlas_idx = capi.tlas_build(insts)
+                ctx.set_tlas(tlas_nodes, tlas_idx, insts)
         else:
             for nodes, tris, idx in self.blas:
                 ctx.upload_blas(nodes, tris, idx)
