@@ -320,8 +320,14 @@ __global__ void __launch_bounds__(kBlock) ploc_compact_kernel(const int* __restr
 // thread per node picks the plane and creates the children, a scan of the "goes left" flags gives every primitive its place
 // in the next level's order, and the scatter pass collects the children's centroid bounds.  Nodes of at most kSahSmall primitives
 // leave the levels and are finished by one thread each with an exact sweep.
-constexpr int kSahBins = 16;
-constexpr int kSahSmall = 8;
+#ifndef NX_SAH_BINS
+#define NX_SAH_BINS 16
+#endif
+#ifndef NX_SAH_SMALL
+#define NX_SAH_SMALL 8
+#endif
+constexpr int kSahBins = NX_SAH_BINS;
+constexpr int kSahSmall = NX_SAH_SMALL;
 struct SahBin {
     uint32_t count;
     uint32_t lo[3], hi[3];  // float_ordered
@@ -1170,7 +1176,10 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadiu
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
     tri_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, triBox.as<Box3>(), bounds.as<uint32_t>());
-    const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, kCostPrim, nodes, primIdx, nodeCount);
+    float primCost = kCostPrim;
+    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1)
+        if (const char* e = std::getenv("NX_BLAS_PRIM_COST")) primCost = (float)std::atof(e);  // sweeps only
+    const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, primCost, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
     NX_HIP(hipStreamSynchronize(st));

@@ -17,7 +17,7 @@ from nexus_amd import capi, loaders, pod, scenegen  # noqa: E402
 IDENT = np.eye(4, dtype=np.float32).reshape(16)
 # device builders: (clustering radius, 0 = radix tree; collapse: the SAH cost table, or round 2's greedy rule)
 DEVICE = {"SAH device": (-1, "sah"), "PLOC r16": (16, "sah"), "PLOC r8": (8, "sah"), "LBVH": (0, "sah"), "PLOC r16 greedy": (16, "greedy"), "LBVH greedy": (0, "greedy")}
-BUILDERS = ("host SAH", "SAH device", "PLOC r16", "PLOC r8", "LBVH", "PLOC r16 greedy", "LBVH greedy")
+BUILDERS = tuple(os.environ["BQ_BUILDERS"].split(",")) if os.environ.get("BQ_BUILDERS") else ("host SAH", "SAH device", "PLOC r16", "PLOC r8", "LBVH", "PLOC r16 greedy", "LBVH greedy")
 
 
 def meshes():
