@@ -760,9 +760,12 @@ __global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
                 if (i == 0) {
                     // (the root is a wide node whatever the table says: as a "leaf" it would be a node with one slot holding all
                     //  its primitives — the table charges the node test to the other choice only)
-                    const float leaf = (prims <= kLeafMax && t.parent[node] >= 0) ? area * (float)prims * t.primCost : 1.0e30f;
+                    // A leaf slot holds at most three primitives — by the count, not by a cost comparison: with infinite boxes (a
+                    // damaged mesh) the cost of the wide node is +inf and "1e30 < inf" would make a leaf of any subtree.
+                    const bool canLeaf = prims <= kLeafMax && t.parent[node] >= 0;
+                    const float leaf = area * (float)prims * t.primCost;
                     const float inner = best + area * kCostNode;
-                    e[0] = leaf < inner ? Eval{leaf, kDecLeaf, 0, 0, 0} : Eval{inner, kDecInternal, (int8_t)bl, (int8_t)br, 0};
+                    e[0] = (canLeaf && leaf < inner) ? Eval{leaf, kDecLeaf, 0, 0, 0} : Eval{inner, kDecInternal, (int8_t)bl, (int8_t)br, 0};
                 } else {
                     e[i] = best < e[i - 1].cost ? Eval{best, kDecDistribute, (int8_t)bl, (int8_t)br, 0} : e[i - 1];
                 }
@@ -791,8 +794,9 @@ __device__ __forceinline__ uint32_t quantize(float v)  // nexus::collapse Quanti
 __device__ __forceinline__ bool is_inner(const Bvh2& t, const int n, const int c)
 {
     if (c >= n - 1) return false;
+    if (t.count[c] > kLeafMax) return true;  // (whatever the table says: a leaf slot cannot hold more)
     if (t.eval) return eval_of(t, n, c, 0, false).decision == kDecInternal;
-    return t.count[c] > kLeafMax;
+    return false;
 }
 
 __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, const int n, const uint32_t* __restrict__ order, const WorkItem* __restrict__ work,

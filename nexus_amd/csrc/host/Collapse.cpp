@@ -70,7 +70,9 @@ void ComputeCosts(const Tree& t, std::vector<Eval>& evals)
             int8_t lc = 0, rc = 0;
             const float cLeaf = CLeaf(box, t.subtreePrims(node));
             const float cInternal = CDistribute(evals.data(), l, r, 7, lc, rc) + box.Area() * C_NODE;
-            if (cLeaf < cInternal) e[0] = Eval{cLeaf, DEC_LEAF, 0, 0};
+            // (a leaf by the primitive count as well: with infinite boxes — a damaged mesh — cInternal is +inf, and CLeaf's
+            //  1e30 for "too many primitives" would win the comparison for any subtree; the reference asserts there)
+            if (t.subtreePrims(node) <= P_MAX && cLeaf < cInternal) e[0] = Eval{cLeaf, DEC_LEAF, 0, 0};
             else e[0] = Eval{cInternal, DEC_INTERNAL, lc, rc};
         }
         for (int i = 1; i < 7; i++) {

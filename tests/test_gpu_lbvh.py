@@ -64,6 +64,41 @@ def test_device_built_blas_is_a_valid_conservative_cwbvh(gpu_ctx_factory, name, 
     _check_structure(nodes, idx, tris)
 
 
+@pytest.mark.parametrize("radius", [0, 16, -1])
+def test_device_builders_survive_triangles_that_are_not_numbers(gpu_ctx_factory, radius):
+    """NaN and infinite vertices (a damaged file): every builder still ends, with every triangle exactly once in a tree the
+    traversal walks to its end.  (Round 3 found the collapse's cost table calling any subtree a leaf once its cost was +inf:
+    slots of thousands of primitives, writes past the slot's three entries, a device that never came back.)  With NaNs alone
+    the boxes stay finite — fmin / fmax drop them — and the rays keep finding the intact triangles; an infinite vertex makes
+    the root frame infinite, as it would for any builder, and nothing can be hit."""
+    tris = np.ascontiguousarray(scenegen.random_soup(4000, seed=12, extent=1.0, size=0.05), dtype=pod.TRI_DT)
+    rng = np.random.RandomState(3)
+    victims = rng.choice(len(tris), 40, replace=False)
+    rays = scenegen.interior_rays(20000, seed=5, extent=1.0)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    hits = {}
+    for kind in ("nan", "inf", "mixed"):
+        bad = tris.copy()
+        if kind in ("nan", "mixed"):
+            bad["pos0"][victims[:15], 0] = np.nan
+        if kind in ("inf", "mixed"):
+            bad["pos1"][victims[15:30]] = np.inf
+            bad["pos2"][victims[30:], 2] = -np.inf
+        ctx = gpu_ctx_factory(32, 32)
+        ctx.set_device_builder(radius)
+        bid = ctx.build_blas(bad)
+        nodes, idx = ctx.read_blas(bid, len(bad))
+        assert sorted(idx.tolist()) == list(range(len(bad))), kind
+        assert 0 < len(nodes) < len(bad)
+        inst = np.array([capi.instance_init(bid, 0, ident, nodes[0])], dtype=pod.INST_DT)
+        inst["boundsMin"], inst["boundsMax"] = -4.0, 4.0  # (the root frame of such a tree may not be a number either)
+        tn, ti = capi.tlas_build(inst)
+        ctx.set_tlas(tn, ti, inst)
+        got = ctx.trace_batch(rays)  # ends: a tree
+        hits[kind] = int((got["hitDistance"] < 1e29).sum())
+    assert hits["nan"] > 1000
+
+
 @pytest.mark.parametrize("builders", [(16, 0), (-1, -1)], ids=["clustering+radix", "top-down-sah"])
 def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_factory, builders):
     """Same scene twice: BLASes from the host SAH builder vs. built on the device; the oracle traverses the SAH version.
