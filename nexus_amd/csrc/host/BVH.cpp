@@ -74,7 +74,10 @@ struct Builder {
             const AABB& tb = bvh.trianglesAABB[t];
             for (int a = 0; a < 3; a++) {
                 if (!live[a]) continue;
-                const int binIdx = std::min(BINS - 1, static_cast<int>((comp(c, a) - comp(cmin, a)) * scale[a]));
+                // (clamped before the conversion: a NaN or infinite centroid — a damaged mesh — must not index outside the bins;
+                //  finite centroids give 0 <= f as before)
+                const double f = (comp(c, a) - comp(cmin, a)) * scale[a];
+                const int binIdx = !(f >= 0.0) ? 0 : (f >= static_cast<double>(BINS) ? BINS - 1 : static_cast<int>(f));
                 Bin& bin = bins[a][binIdx];
                 bin.triCount++;
                 bin.bounds.bMin = fminf(bin.bounds.bMin, tb.bMin);

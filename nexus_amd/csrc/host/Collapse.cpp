@@ -139,7 +139,15 @@ struct Collapser {
                     if (cost[c][s] < minCost) { minCost = cost[c][s]; bestChild = c; bestSlot = s; }
                 }
             }
-            if (bestChild == -1) break;
+            if (bestChild == -1) {
+                // no finite cost (boxes with NaNs or infinities): any free pair keeps the node well formed — the reference breaks
+                // out here and loses the children
+                for (int c = 0; c < childCount && bestChild == -1; c++)
+                    if (slotOf[c] == -1) bestChild = c;
+                for (int s = 0; s < 8 && bestSlot == -1; s++)
+                    if (!slotTaken[s]) bestSlot = s;
+                if (bestChild == -1 || bestSlot == -1) break;
+            }
             slotOf[bestChild] = bestSlot;
             slotTaken[bestSlot] = true;
         }

@@ -408,3 +408,37 @@ def test_cpp_decoders_survive_mutated_files(tmp_path):
         except capi.NexusError:
             outcomes["refused"] += 1
     assert outcomes["refused"] > 20 and outcomes["ok"] > 20 and outcomes["ok"] + outcomes["refused"] == len(pngs) * 60 + 40
+
+
+def test_host_bvh_builder_survives_triangles_that_are_not_numbers():
+    """A damaged mesh (NaN / infinite vertices) through the host builder: it returns, and the tree it returns still holds every
+    triangle exactly once (the reference indexes its bins with a converted NaN and drops children whose slot costs are not
+    finite; `tests/test_gpu_lbvh.py` has the device builders' version of this test)."""
+    from nexus_amd import capi, pod, scenegen
+
+    tris = np.ascontiguousarray(scenegen.random_soup(3000, seed=12, extent=1.0, size=0.05), dtype=pod.TRI_DT)
+    rng = np.random.RandomState(3)
+    victims = rng.choice(len(tris), 40, replace=False)
+    for kind in ("nan", "inf", "mixed"):
+        bad = tris.copy()
+        if kind in ("nan", "mixed"):
+            bad["pos0"][victims[:15], 0] = np.nan
+        if kind in ("inf", "mixed"):
+            bad["pos1"][victims[15:30]] = np.inf
+            bad["pos2"][victims[30:], 2] = -np.inf
+        nodes, idx = capi.bvh8_build(bad, threads=2)
+        seen, stack = [], [0]
+        while stack:
+            n = nodes[stack.pop()]
+            inner = 0
+            for s in range(8):
+                m = int(n["meta"][s])
+                if (int(n["imask"]) >> s) & 1:
+                    stack.append(int(n["childBaseIdx"]) + inner)
+                    inner += 1
+                elif m:
+                    count = bin(m >> 5).count("1")
+                    assert 1 <= count <= 3
+                    first = int(n["triangleBaseIdx"]) + (m & 31)
+                    seen += idx[first:first + count].tolist()
+        assert sorted(seen) == list(range(len(bad))), kind
