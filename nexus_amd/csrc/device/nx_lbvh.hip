@@ -78,8 +78,16 @@ __global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_in
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Box3 b;
         for (int a = 0; a < 3; a++) {
-            b.lo[a] = inst[i].boundsMin[a];
-            b.hi[a] = inst[i].boundsMax[a];
+            // (as the host builder's Finite(): a bound that is not a number moves out to +-1e9, so that one degenerate instance
+            //  does not make the root frame infinite and every other instance unreachable)
+            constexpr float kFar = 1.0e9f;
+            float lo = inst[i].boundsMin[a], hi = inst[i].boundsMax[a];
+            if (!(lo >= -kFar)) lo = -kFar;
+            if (!(lo <= kFar)) lo = kFar;
+            if (!(hi <= kFar)) hi = kFar;
+            if (!(hi >= -kFar)) hi = -kFar;
+            b.lo[a] = lo;
+            b.hi[a] = hi;
             const float c = 0.5f * (b.lo[a] + b.hi[a]);
             cl[a] = fminf(cl[a], c);
             ch[a] = fmaxf(ch[a], c);

@@ -10,11 +10,33 @@
 
 namespace nexus {
 
+namespace {
+
+// The clustering below is a nearest-neighbour chain: it ends because "the union with the smallest area" is a symmetric, finite
+// measure.  A box with NaNs or infinities (an instance of a damaged mesh, a degenerate transform) breaks both — the reference
+// indexes its table with -1 then — so such a box is made the conservative finite one first: every plane that is not a number
+// moves out to +-1e9, every other beyond that is clamped to it.  Boxes of ordinary scenes are untouched.
+AABB Finite(AABB b)
+{
+    constexpr float kFar = 1.0e9f;
+    float* lo[3] = {&b.bMin.x, &b.bMin.y, &b.bMin.z};
+    float* hi[3] = {&b.bMax.x, &b.bMax.y, &b.bMax.z};
+    for (int a = 0; a < 3; a++) {
+        if (!(*lo[a] >= -kFar)) *lo[a] = -kFar;  // NaN or below
+        if (!(*lo[a] <= kFar)) *lo[a] = kFar;
+        if (!(*hi[a] <= kFar)) *hi[a] = kFar;    // NaN or above
+        if (!(*hi[a] >= -kFar)) *hi[a] = -kFar;
+    }
+    return b;
+}
+
+}  // namespace
+
 void TLAS::Build()
 {
     std::vector<AABB> bounds;
     bounds.reserve(bvhInstances.size());
-    for (const BVHInstance& inst : bvhInstances) bounds.push_back(inst.GetBounds());
+    for (const BVHInstance& inst : bvhInstances) bounds.push_back(Finite(inst.GetBounds()));
     Cluster(bounds);
 }
 
@@ -22,7 +44,7 @@ void TLAS::BuildFromBounds(const nx_bvh_instance* instances, uint32_t count)
 {
     std::vector<AABB> bounds;
     bounds.reserve(count);
-    for (uint32_t i = 0; i < count; i++) bounds.emplace_back(make_float3(instances[i].boundsMin), make_float3(instances[i].boundsMax));
+    for (uint32_t i = 0; i < count; i++) bounds.push_back(Finite(AABB(make_float3(instances[i].boundsMin), make_float3(instances[i].boundsMax))));
     Cluster(bounds);
 }
 

@@ -442,3 +442,37 @@ def test_host_bvh_builder_survives_triangles_that_are_not_numbers():
                     first = int(n["triangleBaseIdx"]) + (m & 31)
                     seen += idx[first:first + count].tolist()
         assert sorted(seen) == list(range(len(bad))), kind
+
+
+def test_host_tlas_builder_survives_instance_bounds_that_are_not_numbers():
+    """Instances whose world bounds hold NaNs or infinities (a degenerate transform): the agglomerative clustering still ends —
+    its nearest-neighbour chain needs a symmetric finite measure, so such boxes are made conservative finite ones first — and
+    every instance is in the tree once.  (The reference indexes its table with -1 in this case; this builder used to spin.)"""
+    from nexus_amd import capi, pod
+
+    rng = np.random.RandomState(1)
+    n = 50
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    inst = np.zeros(n, dtype=pod.INST_DT)
+    for i in range(n):
+        inst[i]["transform"] = ident
+        inst[i]["invTransform"] = ident
+        lo = rng.uniform(-5, 5, 3).astype(np.float32)
+        inst[i]["boundsMin"], inst[i]["boundsMax"] = lo, lo + 1
+    clean_nodes, _ = capi.tlas_build(inst)
+    for kind in ("nan", "inf", "allnan"):
+        bad = inst.copy()
+        if kind == "nan":
+            bad["boundsMin"][3, 0] = np.nan
+            bad["boundsMax"][7] = np.nan
+        if kind == "inf":
+            bad["boundsMax"][3] = np.inf
+            bad["boundsMin"][9, 1] = -np.inf
+        if kind == "allnan":
+            bad["boundsMin"][:] = np.nan
+            bad["boundsMax"][:] = np.nan
+        nodes, idx = capi.tlas_build(bad)
+        assert sorted(idx.tolist()) == list(range(n)), kind
+        assert len(nodes) >= 1
+    again, _ = capi.tlas_build(inst)
+    assert again.tobytes() == clean_nodes.tobytes()

@@ -216,6 +216,26 @@ def test_device_built_tlas_is_valid_and_traces_like_the_oracle(gpu_ctx_factory, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("builder", [-1, 0, 16])
+def test_device_tlas_build_survives_bounds_that_are_not_numbers(gpu_ctx_factory, builder):
+    """instances with NaN / infinite world bounds through nxhip_rebuild_tlas (all three device builders): it returns, every
+    instance is in the tree once, a traversal of the tree ends"""
+    scene = SH.instanced_scene(seed=9, n_inst=60)
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    ctx.set_device_builder(builder)
+    bad = scene.instances.copy()
+    bad["boundsMin"][3, 0] = np.nan
+    bad["boundsMax"][7] = np.nan
+    bad["boundsMax"][11] = np.inf
+    bad["boundsMin"][13, 1] = -np.inf
+    nodes, idx = ctx.rebuild_tlas(bad)
+    assert sorted(idx.tolist()) == list(range(len(bad))) and len(nodes) >= 1
+    got = ctx.trace_batch(_rays(4000, 5))
+    assert len(got) == 4000 and (got["hitDistance"] < 1e29).sum() > 100
+
+
+@pytest.mark.gpu
 def test_device_tlas_build_of_sixteen_thousand_instances_is_fast(gpu_ctx_factory):
     """The case SURVEY.md section 8 row f3 names: the reference's O(n^2) clustering at 16 k instances (0.8 s for this repo's
     faster host version of it) against the device build."""
