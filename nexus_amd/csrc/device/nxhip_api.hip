@@ -93,6 +93,7 @@ static int fail_invalid(const char* msg)
     set_error(msg);
     return NXHIP_ERR_INVALID;
 }
+static int fail_invalid(const std::string& msg) { return fail_invalid(msg.c_str()); }
 
 // slot k of the context: 0 is the context itself, k >= 1 the extra in-flight passes
 static PassSlot* slot_at(nxhip_ctx* c, uint32_t k) { return k == 0 ? static_cast<PassSlot*>(c) : c->extra[k - 1].get(); }
@@ -557,6 +558,38 @@ static int refresh_inst_trav(nxhip_ctx* c)
     return NXHIP_OK;
 }
 
+// What the traversal kernels assume of 8-wide nodes, checked before anything reaches the GPU (BLAS: primitives = triangles of
+// the leaf-ordered list; TLAS: instances).  The kernels decode a slot from its META byte alone — bits 3 and 4 both set: an
+// inner child whose hit bit goes to position 24 .. 31 and whose node is childBaseIdx + (imask bits below its slot); otherwise
+// a leaf whose (meta >> 5) bits go to position (meta & 31) ... of the 24-bit primitive mask — so the check follows the meta
+// bytes: an inner slot must be announced in imask and carry exactly one bit (more would land on other slots' positions and
+// index one node past the children), a leaf's bits must stay below position 24 (beyond it they read as inner hits) and
+// inside the primitive list, children must exist and follow their parent (no cycles: the traversal would never end).
+static const char* wide_nodes_defect(const nx_bvh8_node* nodes, uint32_t nodeCount, uint32_t primCount)
+{
+    for (uint32_t i = 0; i < nodeCount; i++) {
+        const nx_bvh8_node& n = nodes[i];
+        int inner = 0, prims = 0;
+        for (int s = 0; s < 8; s++) {
+            const uint32_t m = n.meta[s];
+            if (n.imask & (1u << s)) inner++;
+            if ((m & 0x18u) == 0x18u && (m >> 5) != 0u) {  // decoded as an inner child
+                if (!(n.imask & (1u << s))) return "a slot is encoded as an inner child but not announced in imask";
+                if ((m >> 5) != 1u) return "an inner slot carries more than one hit bit";
+                if ((m & 0x07u) != (uint32_t)s) return "an inner slot is encoded with another slot's number";
+            } else if (m >> 5) {  // decoded as a leaf of 1 .. 3 primitives at offset (m & 31)
+                const int top = 32 - __builtin_clz(m >> 5);
+                if ((int)(m & 0x1fu) + top > 24) return "a leaf slot's primitive bits leave the 24-bit primitive mask";
+                prims = std::max(prims, (int)(m & 0x1fu) + top);
+            }
+        }
+        if (inner && (uint64_t)n.childBaseIdx + (uint64_t)inner > nodeCount) return "child index out of range";
+        if (inner && n.childBaseIdx <= i) return "child nodes must follow their parent";
+        if (prims && (uint64_t)n.triangleBaseIdx + (uint64_t)prims > primCount) return "leaf range out of range";
+    }
+    return nullptr;
+}
+
 int nxhip_upload_blas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, const nx_triangle* tris, uint32_t triCount,
                       const uint32_t* triIdx, int32_t* blasId)
 try {
@@ -566,22 +599,7 @@ try {
     // validate what the kernels assume before anything reaches the GPU: indices in range
     for (uint32_t i = 0; i < triCount; i++)
         if (triIdx[i] >= triCount) return fail_invalid("nxhip_upload_blas: triangle index out of range");
-    for (uint32_t i = 0; i < nodeCount; i++) {
-        const nx_bvh8_node& n = nodes[i];
-        int inner = 0, prims = 0;
-        for (int s = 0; s < 8; s++) {
-            if (n.imask & (1u << s)) inner++;
-            else if (n.meta[s]) {
-                const int cnt = __builtin_popcount(n.meta[s] >> 5);
-                prims = std::max(prims, (n.meta[s] & 0x1f) + cnt);
-            }
-        }
-        if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_upload_blas: child index out of range");
-        // children behind their parent in the array (what every builder here and the reference's emit): the node graph then
-        // cannot contain a cycle, which the traversal would follow forever
-        if (inner && n.childBaseIdx <= i) return fail_invalid("nxhip_upload_blas: child nodes must follow their parent");
-        if (prims && (uint64_t)n.triangleBaseIdx + prims > triCount) return fail_invalid("nxhip_upload_blas: leaf range out of range");
-    }
+    if (const char* defect = wide_nodes_defect(nodes, nodeCount, triCount)) return fail_invalid(std::string("nxhip_upload_blas: ") + defect);
     BlasHost b;
     b.nodeCount = nodeCount;
     b.triCount = triCount;
@@ -713,18 +731,8 @@ try {
         if (instanceIdx[i] >= instanceCount) return fail_invalid("nxhip_set_tlas: instance index out of range");
         if (instances[i].bvhIdx >= c->blas.size()) return fail_invalid("nxhip_set_tlas: instance refers to a BLAS id that has not been uploaded");
     }
-    for (uint32_t i = 0; i < nodeCount; i++) {
-        const nx_bvh8_node& n = nodes[i];
-        int inner = 0, prims = 0;
-        for (int s = 0; s < 8; s++) {
-            if (n.imask & (1u << s)) inner++;
-            else if (n.meta[s]) prims = std::max(prims, (n.meta[s] & 0x1f) + __builtin_popcount(n.meta[s] >> 5));
-        }
-        if (inner && (uint64_t)n.childBaseIdx + inner > nodeCount) return fail_invalid("nxhip_set_tlas: child index out of range");
-        if (prims && (uint64_t)n.triangleBaseIdx + prims > instanceCount) return fail_invalid("nxhip_set_tlas: leaf range out of range");
-        // (checked here, before the context is touched: a failure must leave the previous TLAS and its traversal records in place)
-        if (inner && n.childBaseIdx <= i) return fail_invalid("nxhip_set_tlas: child nodes must follow their parent");
-    }
+    // (checked here, before the context is touched: a failure must leave the previous TLAS and its traversal records in place)
+    if (const char* defect = wide_nodes_defect(nodes, nodeCount, instanceCount)) return fail_invalid(std::string("nxhip_set_tlas: ") + defect);
     NX_SYNC_ALL(c);
     std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
     NX_ALLOC(c->tlasNodes, padded.size() * sizeof(uint4));

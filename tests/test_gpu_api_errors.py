@@ -41,6 +41,22 @@ def test_malformed_bvh_uploads_are_rejected(gpu_ctx_factory):
         ctx.upload_blas(bad_nodes, tris, idx)
     with pytest.raises(NexusError, match="empty"):
         ctx.upload_blas(nodes[:0], tris, idx)
+    # the kernels decode a slot from its meta byte alone: what that decoding would make of a damaged byte is checked too
+    root = nodes[0]
+    inner_slot = next(s for s in range(8) if (int(root["imask"]) >> s) & 1)
+    leaf_node, leaf_slot = next((i, s) for i in range(len(nodes)) for s in range(8) if not (int(nodes[i]["imask"]) >> s) & 1 and int(nodes[i]["meta"][s]) >> 5)
+    for field, node, slot, value, what in (
+            ("imask", 0, None, int(root["imask"]) & ~(1 << inner_slot), "not announced in imask"),
+            ("meta", 0, inner_slot, 0x60 | (24 + inner_slot), "more than one hit bit"),
+            ("meta", 0, inner_slot, 0x20 | (24 + (inner_slot ^ 1)), "another slot's number"),
+            ("meta", leaf_node, leaf_slot, 0xe0 | 22, "leave the 24-bit primitive mask")):
+        bad_nodes = nodes.copy()
+        if slot is None:
+            bad_nodes[field][node] = value
+        else:
+            bad_nodes[field][node][slot] = value
+        with pytest.raises(NexusError, match=what):
+            ctx.upload_blas(bad_nodes, tris, idx)
     # instances that refer to a BLAS that was never uploaded
     with pytest.raises(NexusError, match="BLAS id"):
         ctx.set_tlas(scene.tlas_nodes, scene.tlas_idx, scene.instances)
