@@ -30,13 +30,21 @@ int main(int argc, char** argv)
     for (int k = 0; k < 7 && 8 + k < argc; k++) cam[k] = static_cast<float>(std::atof(argv[8 + k]));
     try {
         nexus::Scene scene(width, height);
+        nexus::PathTracer pathTracer(width, height, 0);
+        // NEXUS_DEVICE_BUILDERS=1: the BVH of every mesh the loader adds is built on the GPU (the reference's SAH rule and collapse
+        // in HBM: a tenth of the host builder's time, a thousandth of the reference's) and so is the TLAS; the default is the
+        // reference's flow, host builders and an upload
+        const bool deviceBuilders = std::getenv("NEXUS_DEVICE_BUILDERS") != nullptr;
+        if (deviceBuilders) {
+            pathTracer.SetDeviceBlasBuild(scene, true);
+            scene.SetDeviceTlasBuild(true);
+        }
         scene.CreateMeshInstanceFromFile(dir, file);
         scene.GetCamera()->LookAt(nexus::make_float3(cam[0], cam[1], cam[2]), nexus::make_float3(cam[3], cam[4], cam[5]));
         scene.GetCamera()->SetHorizontalFOV(cam[6]);
         scene.GetRenderSettings().pathLength = static_cast<unsigned char>(pathLength);
         scene.Update();
 
-        nexus::PathTracer pathTracer(width, height, 0);
         // NEXUS_DETERMINISTIC=1: pixel-keyed RNG, so the image does not depend on the order in which racing workgroups take
         // queue slots (the reference's slot-keyed RNG makes every run a different noise pattern)
         if (std::getenv("NEXUS_DETERMINISTIC")) pathTracer.SetModes(NX_RNG_PIXEL_KEYED, NX_COMPACT_FAST, NX_CONDUCTOR_REFERENCE);
@@ -61,7 +69,9 @@ int main(int argc, char** argv)
             std::fwrite(row.data(), 1, row.size(), fp);
         }
         std::fclose(fp);
-        std::printf("%s: %u x %u, %d frames, %zu instances, %zu lights\n", out.c_str(), width, height, frames, scene.GetBVHInstances().size(), scene.GetLights().size());
+        std::printf("%s: %u x %u, %d frames, %zu instances, %zu lights%s\n", out.c_str(), width, height, frames, scene.GetBVHInstances().size(), scene.GetLights().size(),
+                    deviceBuilders ? ", BVHs built on the device" : "");
+        if (deviceBuilders) pathTracer.SetDeviceBlasBuild(scene, false);  // the scene outlives the path tracer in this scope
     } catch (const std::exception& e) {
         std::fprintf(stderr, "nexus_render: %s\n", e.what());
         return 1;

@@ -254,6 +254,14 @@ def test_cpp_example_program_renders_the_same_image(tmp_path):
     want = pt.read_pixels().reshape(H, W).view(np.uint8).reshape(H, W, 4)[..., :3]
     pt.close()
     assert np.array_equal(got, want)
+    # the same program with the BVHs and the TLAS built on the device: the same picture up to equidistant ties
+    out2 = str(tmp_path / "cornell_device.ppm")
+    r = subprocess.run([exe, SH.GOLDEN + os.sep, "cornell_box.glb", out2, str(W), str(H), "3", "4"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, NEXUS_DETERMINISTIC="1", NEXUS_DEVICE_BUILDERS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "BVHs built on the device" in r.stdout
+    dev = np.frombuffer(open(out2, "rb").read()[len(header):], np.uint8).reshape(H, W, 3)[::-1]
+    assert (np.abs(dev.astype(int) - got.astype(int)).max(axis=2) <= 1).mean() > 0.995
     # bad input: a message and a non-zero status, no crash
     r = subprocess.run([exe, SH.GOLDEN + os.sep, "missing.glb", out], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
