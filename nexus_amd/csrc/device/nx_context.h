@@ -123,6 +123,7 @@ struct nxhip_ctx : nxd::PassSlot {
     // scene
     std::vector<nxd::BlasHost> blas;
     nxd::DevBuf blasTable;
+    nxd::DevBuf tlasTightBoxes;  // [instanceCount] x 24 B: the instance boxes a device-built TLAS was built from (nx_instbox.h); empty after nxhip_set_tlas
     nxd::DevBuf tlasNodes, tlasInstIdx, instTrav, instances;
     std::vector<nx_bvh_instance> hostInstances;
     std::vector<nx_material> hostMaterials;  // kept for the cross-table index check before a render

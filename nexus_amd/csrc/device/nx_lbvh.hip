@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "nx_context.h"
+#include "nx_instbox.h"
 #include "nx_math.h"
 
 namespace nxd {
@@ -71,8 +72,13 @@ __global__ void __launch_bounds__(kBlock) tri_bounds_kernel(const nx_triangle* _
     }
 }
 
-// the same for a TLAS: the primitives are the instances' world-space boxes (BVHInstance::SetTransform computed them)
-__global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_instance* __restrict__ inst, const uint32_t n, Box3* __restrict__ box, uint32_t* __restrict__ sceneBounds)
+// the same for a TLAS: the primitives are the instances' world-space boxes.  BVHInstance::SetTransform computed them from the BLAS
+// root's quantisation frame [p, p + 255 * 2^e], as the reference does — up to twice the mesh's extent per axis (the scale is a
+// power of two), before the transform's own inflation.  With `blas` the box is taken from what the frame holds instead: the
+// boxes of the root's children, each through the instance transform, intersected with the record's box.  Both contain the
+// geometry, so does their intersection; rays stop entering instances they pass at a distance.
+__global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_instance* __restrict__ inst, const uint32_t n, const BlasDev* __restrict__ blas,
+                                                                 Box3* __restrict__ box, uint32_t* __restrict__ sceneBounds)
 {
     float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -88,6 +94,15 @@ __global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_in
             if (!(hi >= -kFar)) hi = -kFar;
             b.lo[a] = lo;
             b.hi[a] = hi;
+        }
+        if (blas && kNodeStride == 5) {
+            const nx_bvh8_node root = *reinterpret_cast<const nx_bvh8_node*>(blas[inst[i].bvhIdx].nodes);
+            InstBox t;
+            for (int a = 0; a < 3; a++) { t.lo[a] = b.lo[a]; t.hi[a] = b.hi[a]; }
+            tighten_instance_box(root, inst[i].transform.cell, t);
+            for (int a = 0; a < 3; a++) { b.lo[a] = t.lo[a]; b.hi[a] = t.hi[a]; }
+        }
+        for (int a = 0; a < 3; a++) {
             const float c = 0.5f * (b.lo[a] + b.hi[a]);
             cl[a] = fminf(cl[a], c);
             ch[a] = fmaxf(ch[a], c);
@@ -1201,18 +1216,23 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadiu
 
 // The same builder over instance boxes: a TLAS for `n` instances (device array, world bounds filled in).  nodes / primIdx
 // (the TLAS's instance index list, leaf order) stay on the device; *nodeCount = nodes used.
-int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount)
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& box, bool* boxesAreTight, uint32_t* nodeCount)
 {
     hipStream_t st = c->stream;
     const int cus = std::max(1, c->numCUs);
-    DevBuf box, bounds;
+    DevBuf bounds;
     if (!box.alloc((size_t)n * sizeof(Box3)) || !bounds.alloc(6 * 4) || !primIdx.alloc((size_t)n * 4)) return NXHIP_ERR_HIP;
     const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     NX_HIP(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
-    instance_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dInstances, n, box.as<Box3>(), bounds.as<uint32_t>());
     float instanceCost = kCostInstance;
-    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1)
-        if (const char* e = std::getenv("NX_TLAS_PRIM_COST")) instanceCost = (float)std::atof(e);  // sweeps only
+    bool tight = true;
+    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1) {  // sweeps only
+        if (const char* e = std::getenv("NX_TLAS_PRIM_COST")) instanceCost = (float)std::atof(e);
+        if (const char* e = std::getenv("NX_TLAS_TIGHT")) tight = std::atoi(e) != 0;
+    }
+    tight = tight && kNodeStride == 5;
+    *boxesAreTight = tight;
+    instance_bounds_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dInstances, n, tight ? c->blasTable.as<BlasDev>() : nullptr, box.as<Box3>(), bounds.as<uint32_t>());
     const int rc = lbvh_from_boxes(c, box, bounds, n, plocRadius, instanceCost, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
     NX_HIP(hipStreamSynchronize(st));

@@ -11,6 +11,7 @@
 // re-deriving each node's quantisation frame and child boxes exactly as nexus::collapse::Refit does on the host.
 #define NX_KERNEL_TU 1
 #include "nx_device.h"
+#include "nx_instbox.h"
 #include "nx_math.h"
 
 namespace nxd {
@@ -65,7 +66,7 @@ NXD void mat4_invert(const float* m, float* out)
 //  differently from the host stub, which is compiled without it)
 __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceState* __restrict__ S, nx_bvh_instance* instancesArg, InstTrav* travArg,
                                                                  const uint32_t* __restrict__ leafOfInstance, const uint32_t* __restrict__ ids,
-                                                                 const float* __restrict__ transforms, const uint32_t count)
+                                                                 const float* __restrict__ transforms, const uint32_t count, InstBox* __restrict__ tightBoxes)
 {
     NX_G nx_bvh_instance* instances = (NX_G nx_bvh_instance*)instancesArg;
     NX_G InstTrav* trav = (NX_G InstTrav*)travArg;
@@ -92,6 +93,15 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
         }
         for (int i = 0; i < 16; i++) { inst->transform.cell[i] = m[i]; inst->invTransform.cell[i] = inv[i]; }
         for (int a = 0; a < 3; a++) { inst->boundsMin[a] = wb.lo[a]; inst->boundsMax[a] = wb.hi[a]; }
+        if (tightBoxes && kNodeStride == 5) {  // a TLAS built on the device keeps its tighter boxes (nx_instbox.h) through the refit
+            nx_bvh8_node rootNode;
+            uint4* words = reinterpret_cast<uint4*>(&rootNode);
+            for (int q = 0; q < 5; q++) words[q] = root[q];
+            InstBox tb;
+            for (int a = 0; a < 3; a++) { tb.lo[a] = wb.lo[a]; tb.hi[a] = wb.hi[a]; }
+            tighten_instance_box(rootNode, m, tb);
+            tightBoxes[id] = tb;
+        }
         NX_G InstTrav* t = &trav[leafOfInstance[id]];
         t->r0 = make_float4(inv[0], inv[1], inv[2], inv[3]);
         t->r1 = make_float4(inv[4], inv[5], inv[6], inv[7]);
@@ -117,7 +127,8 @@ NXD float ceil_log2(float x) { return ceilf((float)log2((double)x)); }
 // levelStart[l] .. levelStart[l + 1] is level l of that list.  One workgroup: levels are separated by a barrier.
 __global__ void __launch_bounds__(kRefitBlock) tlas_refit_kernel(nx_bvh8_node* nodesArg, const uint32_t* __restrict__ primIdx,
                                                                  const nx_bvh_instance* instancesArg, const uint32_t* __restrict__ order,
-                                                                 const uint32_t* __restrict__ levelStart, const uint32_t levels, Box* __restrict__ nodeBox)
+                                                                 const uint32_t* __restrict__ levelStart, const uint32_t levels, Box* __restrict__ nodeBox,
+                                                                 const InstBox* __restrict__ tightBoxes)
 {
     NX_G nx_bvh8_node* nodes = (NX_G nx_bvh8_node*)nodesArg;
     const NX_G nx_bvh_instance* instances = (const NX_G nx_bvh_instance*)instancesArg;
@@ -140,7 +151,13 @@ __global__ void __launch_bounds__(kRefitBlock) tlas_refit_kernel(nx_bvh8_node* n
                     const uint32_t first = primBase + (meta & 0x1fu);
                     const int cnt = __popc(meta >> 5);
                     for (int j = 0; j < cnt; j++) {
-                        const NX_G nx_bvh_instance* in = &instances[primIdx[first + (uint32_t)j]];
+                        const uint32_t instanceId = primIdx[first + (uint32_t)j];
+                        if (tightBoxes) {  // (a device-built TLAS: the boxes it was built from, kept up to date by the transform kernel)
+                            const InstBox tb = tightBoxes[instanceId];
+                            box_grow(cb, tb.lo, tb.hi);
+                            continue;
+                        }
+                        const NX_G nx_bvh_instance* in = &instances[instanceId];
                         const float lo[3] = {in->boundsMin[0], in->boundsMin[1], in->boundsMin[2]}, hi[3] = {in->boundsMax[0], in->boundsMax[1], in->boundsMax[2]};
                         box_grow(cb, lo, hi);
                     }

@@ -27,7 +27,7 @@ const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
 int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
-int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, uint32_t* nodeCount);
+int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& box, bool* boxesAreTight, uint32_t* nodeCount);
 
 static thread_local std::string g_lastError;
 
@@ -711,6 +711,7 @@ try {
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     c->blas.clear();
+    c->tlasTightBoxes.release();
     c->hostInstances.clear();
     c->hostInstIdx.clear();
     c->h.tlasNodes = nullptr;
@@ -734,6 +735,7 @@ try {
     // (checked here, before the context is touched: a failure must leave the previous TLAS and its traversal records in place)
     if (const char* defect = wide_nodes_defect(nodes, nodeCount, instanceCount)) return fail_invalid(std::string("nxhip_set_tlas: ") + defect);
     NX_SYNC_ALL(c);
+    c->tlasTightBoxes.release();  // (a tree from outside: its boxes are the records')
     std::vector<uint4> padded = pad_nodes(nodes, nodeCount);
     NX_ALLOC(c->tlasNodes, padded.size() * sizeof(uint4));
     NX_ALLOC(c->tlasInstIdx, (size_t)instanceCount * 4);
@@ -792,11 +794,12 @@ try {
         if (instances[i].bvhIdx >= c->blas.size()) return fail_invalid("nxhip_rebuild_tlas: instance refers to a BLAS id that has not been uploaded");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
-    DevBuf dInst, wide, primIdx;
+    DevBuf dInst, wide, primIdx, boxes;
+    bool boxesAreTight = false;
     NX_ALLOC(dInst, (size_t)instanceCount * sizeof(nx_bvh_instance));
     NX_HIP(hipMemcpy(dInst.p, instances, (size_t)instanceCount * sizeof(nx_bvh_instance), hipMemcpyHostToDevice));
     uint32_t nodeCount = 0;
-    int rc = lbvh_build_tlas(c, dInst.as<nx_bvh_instance>(), instanceCount, c->deviceBuilderRadius, wide, primIdx, &nodeCount);
+    int rc = lbvh_build_tlas(c, dInst.as<nx_bvh_instance>(), instanceCount, c->deviceBuilderRadius, wide, primIdx, boxes, &boxesAreTight, &nodeCount);
     if (rc != NXHIP_OK) return rc;
     // The tree is a few hundred nodes per thousand instances: it comes back once so that nxhip_set_tlas — range checks, the
     // traversal records in leaf order, the schedule of the device-side refit — installs it like any other TLAS.
@@ -804,7 +807,10 @@ try {
     std::vector<uint32_t> idx(instanceCount);
     NX_HIP(hipMemcpy(nodes.data(), wide.p, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
     NX_HIP(hipMemcpy(idx.data(), primIdx.p, (size_t)instanceCount * 4, hipMemcpyDeviceToHost));
-    return nxhip_set_tlas(c, nodes.data(), nodeCount, idx.data(), instances, instanceCount);
+    rc = nxhip_set_tlas(c, nodes.data(), nodeCount, idx.data(), instances, instanceCount);
+    // the boxes the tree was built from stay with it: the device-side refit keeps using them instead of the records' looser ones
+    if (rc == NXHIP_OK && boxesAreTight) c->tlasTightBoxes = std::move(boxes);
+    return rc;
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_rebuild_tlas: ") + e.what());
     return NXHIP_ERR_INVALID;
@@ -846,7 +852,8 @@ try {
         const uint32_t* leafOf = c->leafOfInstance.as<uint32_t>();
         const uint32_t* ids = c->refitIds.as<uint32_t>();
         const float* mats = c->refitMatrices.as<float>();
-        void* args[7] = {(void*)&S, (void*)&inst, (void*)&trav, (void*)&leafOf, (void*)&ids, (void*)&mats, (void*)&count};
+        void* tight = c->tlasTightBoxes.p;
+        void* args[8] = {(void*)&S, (void*)&inst, (void*)&trav, (void*)&leafOf, (void*)&ids, (void*)&mats, (void*)&count, (void*)&tight};
         const unsigned grid = std::min<unsigned>((count + 255u) / 256u, (unsigned)c->wideBlocks);
         NX_HIP(hipLaunchKernel(instance_transform_kernel_ptr(), dim3(grid), dim3(256), args, 0, c->stream));
     }
@@ -858,7 +865,8 @@ try {
         const uint32_t* levelStart = c->refitLevelStart.as<uint32_t>();
         const uint32_t levels = c->refitLevels;
         void* boxes = c->refitBoxes.p;
-        void* args[7] = {(void*)&nodes, (void*)&primIdx, (void*)&inst, (void*)&order, (void*)&levelStart, (void*)&levels, (void*)&boxes};
+        void* tight = c->tlasTightBoxes.p;
+        void* args[8] = {(void*)&nodes, (void*)&primIdx, (void*)&inst, (void*)&order, (void*)&levelStart, (void*)&levels, (void*)&boxes, (void*)&tight};
         NX_HIP(hipLaunchKernel(tlas_refit_kernel_ptr(), dim3(1), dim3(1024), args, 0, c->stream));
     }
     // pageable host arrays: the copies above are staged before hipMemcpyAsync returns on this runtime, but that is not a

@@ -145,9 +145,24 @@ def test_device_side_transforms_keep_the_identity_shortcut_honest(gpu_ctx_factor
     assert SH.hit_records_equal(got, scene.oracle().trace_closest(rays))
 
 
-def _check_tlas_structure(nodes, idx, instances):
+def _geometry_bounds(scene, instances):
+    """world-space box of every instance's triangles (exact: the vertices through the instance transform)"""
+    lo, hi = [], []
+    for inst in instances:
+        m = scene.meshes[int(inst["bvhIdx"])]
+        T = np.asarray(inst["transform"], np.float64).reshape(4, 4)
+        v = np.concatenate([m["pos0"], m["pos1"], m["pos2"]]).astype(np.float64)
+        w = v @ T[:3, :3].T + T[:3, 3]
+        lo.append(w.min(0))
+        hi.append(w.max(0))
+    return np.array(lo), np.array(hi)
+
+
+def _check_tlas_structure(nodes, idx, instances, geometry=None):
     """every instance exactly once; children behind their parent; every leaf slot's quantised box contains its instances'
-    world boxes; inner children consecutive"""
+    world boxes — the record's (BVHInstance::SetTransform's, from the BLAS root frame), or with `geometry` = (lo, hi) per instance
+    the triangles' own: the device build tightens the record's box to what the BLAS root's children hold —; inner children
+    consecutive"""
     from tests.test_builder_parity import _decode_children
 
     assert sorted(idx.tolist()) == list(range(len(instances)))
@@ -170,7 +185,8 @@ def _check_tlas_structure(nodes, idx, instances):
                     assert k not in seen
                     seen.add(k)
                     inst = instances[idx[k]]
-                    assert np.all(lo <= inst["boundsMin"] + eps) and np.all(hi >= inst["boundsMax"] - eps), (ni, s, k)
+                    want_lo, want_hi = (inst["boundsMin"], inst["boundsMax"]) if geometry is None else (geometry[0][idx[k]], geometry[1][idx[k]])
+                    assert np.all(lo <= want_lo + eps) and np.all(hi >= want_hi - eps), (ni, s, k)
         assert inner == list(range(inner[0], inner[0] + len(inner))) if inner else True
     assert len(seen_nodes) == len(nodes) and len(seen) == len(instances)
 
@@ -188,7 +204,7 @@ def test_device_built_tlas_is_valid_and_traces_like_the_oracle(gpu_ctx_factory, 
     host = scene.oracle().trace_closest(rays)
     assert SH.hit_records_equal(ctx.trace_batch(rays), host)
     nodes, idx = ctx.rebuild_tlas(scene.instances)
-    _check_tlas_structure(nodes, idx, scene.instances)
+    _check_tlas_structure(nodes, idx, scene.instances, _geometry_bounds(scene, scene.instances))
     assert len(nodes) <= max(1, n_inst)
     rebuilt = SH.BuiltScene.__new__(SH.BuiltScene)
     rebuilt.__dict__.update(scene.__dict__)
@@ -213,6 +229,11 @@ def test_device_built_tlas_is_valid_and_traces_like_the_oracle(gpu_ctx_factory, 
             moved[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), xf, scene.blas[int(old["bvhIdx"])][0][0])
         rebuilt.instances, rebuilt.tlas_nodes = moved, capi.tlas_refit(nodes, idx, moved)
         assert SH.hit_records_equal(ctx.trace_batch(rays), rebuilt.oracle().trace_closest(rays))
+        # the refitted tree on the device still bounds the geometry — with the tighter boxes it was built from, not the records'
+        refitted, _ = ctx.read_tlas(len(nodes), n_inst)
+        _check_tlas_structure(refitted, idx, moved, _geometry_bounds(scene, moved))
+        if n_inst >= 60:
+            assert refitted.tobytes() != rebuilt.tlas_nodes.tobytes()
 
 
 @pytest.mark.gpu
@@ -255,7 +276,11 @@ def test_device_tlas_build_of_sixteen_thousand_instances_is_fast(gpu_ctx_factory
     dt = time.time() - t0
     print("device TLAS build of %d instances: %.4f s including upload and install, %d nodes" % (n, dt, len(nodes)))
     assert dt < 0.5
-    _check_tlas_structure(nodes, idx, insts)
+
+    class _OneMesh:
+        meshes = [mesh]
+
+    _check_tlas_structure(nodes, idx, insts, _geometry_bounds(_OneMesh, insts))
     ctx.set_materials(np.array([pod.make_material()], dtype=pod.MAT_DT))
     rays = scenegen.random_rays(4000, seed=5, radius=60.0, target_extent=40.0)
     got = ctx.trace_batch(rays)
