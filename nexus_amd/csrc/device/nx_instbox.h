@@ -1,7 +1,7 @@
 // nx_instbox.h — the world-space box of an instance as the device-side TLAS builder and refit take it: not the transformed BLAS
 // root *frame* [p, p + 255 * 2^e] of BVHInstance::SetTransform (the reference's rule, BVHInstance.cpp:4-21: up to twice the
 // mesh's extent per axis, because the frame's scale is a power of two) but what the frame holds — the boxes of the root node's
-// children, each through the instance transform — intersected with the record's box.  Both contain the geometry, so does
+// children and grandchildren, each through the instance transform — intersected with the record's box.  Both contain the geometry, so does
 // their intersection.  Shared by nx_lbvh.hip (nxhip_rebuild_tlas) and nx_refit.hip (nxhip_set_instance_transforms on a
 // device-built TLAS).
 #pragma once
@@ -13,26 +13,44 @@ struct InstBox {
     float lo[3], hi[3];
 };
 
-// `root`: the BLAS root node (80 bytes, unpadded); `T`: the instance's object-to-world matrix (row-major 4 x 4);
-// `b`: in: the record's box, out: the tightened one
-__device__ __forceinline__ void tighten_instance_box(const nx_bvh8_node& root, const float* T, InstBox& b)
+// the boxes of `node`'s children through T, grown into t; returns whether it had any
+__device__ __forceinline__ bool grow_by_children(const nx_bvh8_node& node, const float* T, InstBox& t, uint32_t skipSlots)
 {
     float sc[3];
-    for (int a = 0; a < 3; a++) sc[a] = __uint_as_float((uint32_t)root.e[a] << 23);
-    InstBox t;
-    for (int a = 0; a < 3; a++) { t.lo[a] = 1e30f; t.hi[a] = -1e30f; }
+    for (int a = 0; a < 3; a++) sc[a] = __uint_as_float((uint32_t)node.e[a] << 23);
     bool any = false;
     for (int s = 0; s < 8; s++) {
-        if (root.meta[s] == 0) continue;
+        if (node.meta[s] == 0 || ((skipSlots >> s) & 1u)) continue;
         any = true;
-        const float lo[3] = {root.p[0] + (float)root.qlox[s] * sc[0], root.p[1] + (float)root.qloy[s] * sc[1], root.p[2] + (float)root.qloz[s] * sc[2]};
-        const float hi[3] = {root.p[0] + (float)root.qhix[s] * sc[0], root.p[1] + (float)root.qhiy[s] * sc[1], root.p[2] + (float)root.qhiz[s] * sc[2]};
+        const float lo[3] = {node.p[0] + (float)node.qlox[s] * sc[0], node.p[1] + (float)node.qloy[s] * sc[1], node.p[2] + (float)node.qloz[s] * sc[2]};
+        const float hi[3] = {node.p[0] + (float)node.qhix[s] * sc[0], node.p[1] + (float)node.qhiy[s] * sc[1], node.p[2] + (float)node.qhiz[s] * sc[2]};
         for (int corner = 0; corner < 8; corner++) {
             const float cx = (corner & 1) ? hi[0] : lo[0], cy = (corner & 2) ? hi[1] : lo[1], cz = (corner & 4) ? hi[2] : lo[2];
             const float w[3] = {T[0] * cx + T[1] * cy + T[2] * cz + T[3], T[4] * cx + T[5] * cy + T[6] * cz + T[7], T[8] * cx + T[9] * cy + T[10] * cz + T[11]};
             for (int a = 0; a < 3; a++) { t.lo[a] = fminf(t.lo[a], w[a]); t.hi[a] = fmaxf(t.hi[a], w[a]); }
         }
     }
+    return any;
+}
+
+// `nodes`: the BLAS's node array (80-byte nodes, unpadded; node 0 is the root); `T`: the instance's object-to-world matrix
+// (row-major 4 x 4); `b`: in: the record's box, out: the tightened one.  Two levels: the root's leaf children by their own
+// boxes, its inner children by the boxes of THEIR children (up to 64 boxes: a rotated mesh is hugged more closely by many small
+// boxes than by eight large ones).
+template <class NodePtr>
+__device__ __forceinline__ void tighten_instance_box(NodePtr nodes, const float* T, InstBox& b)
+{
+    const nx_bvh8_node root = nodes[0];
+    InstBox t;
+    for (int a = 0; a < 3; a++) { t.lo[a] = 1e30f; t.hi[a] = -1e30f; }
+    bool any = false;
+    uint32_t inner = 0;
+    for (int s = 0; s < 8; s++) {
+        if (!((root.imask >> s) & 1u) || root.meta[s] == 0) continue;
+        const nx_bvh8_node child = nodes[root.childBaseIdx + (uint32_t)__popc(root.imask & ((1u << s) - 1u))];
+        if (grow_by_children(child, T, t, 0u)) { any = true; inner |= 1u << s; }  // (a childless inner node: its own box below)
+    }
+    any = grow_by_children(root, T, t, inner) || any;
     bool finite = any;
     for (int a = 0; a < 3; a++) finite = finite && t.lo[a] > -1.0e9f && t.hi[a] < 1.0e9f && t.lo[a] <= t.hi[a];
     if (!finite) return;

@@ -96,10 +96,9 @@ __global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_in
             b.hi[a] = hi;
         }
         if (blas && kNodeStride == 5) {
-            const nx_bvh8_node root = *reinterpret_cast<const nx_bvh8_node*>(blas[inst[i].bvhIdx].nodes);
             InstBox t;
             for (int a = 0; a < 3; a++) { t.lo[a] = b.lo[a]; t.hi[a] = b.hi[a]; }
-            tighten_instance_box(root, inst[i].transform.cell, t);
+            tighten_instance_box(reinterpret_cast<const nx_bvh8_node*>(blas[inst[i].bvhIdx].nodes), inst[i].transform.cell, t);
             for (int a = 0; a < 3; a++) { b.lo[a] = t.lo[a]; b.hi[a] = t.hi[a]; }
         }
         for (int a = 0; a < 3; a++) {

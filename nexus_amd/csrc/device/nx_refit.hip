@@ -94,12 +94,9 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
         for (int i = 0; i < 16; i++) { inst->transform.cell[i] = m[i]; inst->invTransform.cell[i] = inv[i]; }
         for (int a = 0; a < 3; a++) { inst->boundsMin[a] = wb.lo[a]; inst->boundsMax[a] = wb.hi[a]; }
         if (tightBoxes && kNodeStride == 5) {  // a TLAS built on the device keeps its tighter boxes (nx_instbox.h) through the refit
-            nx_bvh8_node rootNode;
-            uint4* words = reinterpret_cast<uint4*>(&rootNode);
-            for (int q = 0; q < 5; q++) words[q] = root[q];
             InstBox tb;
             for (int a = 0; a < 3; a++) { tb.lo[a] = wb.lo[a]; tb.hi[a] = wb.hi[a]; }
-            tighten_instance_box(rootNode, m, tb);
+            tighten_instance_box(reinterpret_cast<const NX_G nx_bvh8_node*>(root), m, tb);
             tightBoxes[id] = tb;
         }
         NX_G InstTrav* t = &trav[leafOfInstance[id]];
