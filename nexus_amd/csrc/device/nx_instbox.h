@@ -40,6 +40,10 @@ __device__ __forceinline__ bool grow_by_children(const nx_bvh8_node& node, const
 template <class NodePtr>
 __device__ __forceinline__ void tighten_instance_box(NodePtr nodes, const float* T, InstBox& b)
 {
+    // A singular matrix (a mesh flattened by a zero scale) has no inverse — the reference then traverses with the identity
+    // (Mat4::Inverted's fallback), which places the hits where no box derived from T is: such an instance keeps the record's box.
+    const float det = T[0] * (T[5] * T[10] - T[6] * T[9]) - T[1] * (T[4] * T[10] - T[6] * T[8]) + T[2] * (T[4] * T[9] - T[5] * T[8]);
+    if (!(det != 0.0f)) return;
     const nx_bvh8_node root = nodes[0];
     InstBox t;
     for (int a = 0; a < 3; a++) { t.lo[a] = 1e30f; t.hi[a] = -1e30f; }

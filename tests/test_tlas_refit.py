@@ -237,6 +237,64 @@ def test_device_built_tlas_is_valid_and_traces_like_the_oracle(gpu_ctx_factory, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_device_tlas_boxes_hold_under_extreme_transforms(gpu_ctx_factory, seed):
+    """The device build takes an instance's box from two levels of its BLAS instead of the root frame (nx_instbox.h): a box that
+    is too tight loses hits.  Placements far from ordinary — scales from 1/300 to 300, mirrored, rotated about all three axes —
+    rebuilt on the device, then moved once more there: the closest hits equal brute force over all triangles, and the trees
+    bound the transformed triangles.  (A mesh flattened by a zero scale has no inverse transform; the reference then traverses
+    it with the identity, and neither its boxes nor anybody's bound those hits: such an instance keeps the record's box —
+    `singular` below only asks that the build and the traversal end.)"""
+    rng = np.random.RandomState(100 + seed)
+    meshes = [scenegen.random_soup(600, seed=seed, extent=0.5, size=0.1), scenegen.displaced_torus(32, 16, seed=seed, major=0.5, minor=0.2),
+              scenegen.height_field(12, seed=seed, amp=0.0)]
+
+    def placement(i):
+        scale = np.exp(rng.uniform(np.log(1 / 300.0), np.log(300.0), 3)) if i % 3 == 0 else rng.uniform(0.3, 2.0, 3)
+        if i % 4 == 1:
+            scale[rng.randint(3)] *= -1.0          # mirrored
+        return capi.mat4_from_trs(rng.uniform(-3, 3, 3), rng.uniform(0, 360, 3), scale)
+
+    n_inst = 24
+    scene = SH.BuiltScene(meshes, [(i % 3, 0, placement(i)) for i in range(n_inst)])
+    ctx = gpu_ctx_factory(64, 64)
+    scene.upload(ctx)
+    rays = np.concatenate([scenegen.random_rays(3000, seed=seed, radius=8.0, target_extent=3.5), scenegen.interior_rays(3000, seed=seed + 1, extent=3.5)])
+    nodes, idx = ctx.rebuild_tlas(scene.instances)
+    _check_tlas_structure(nodes, idx, scene.instances, _geometry_bounds(scene, scene.instances))
+    got = ctx.trace_batch(rays)
+    bf = scene.oracle().brute_closest(rays)
+    assert (bf["hitDistance"] < 1e29).mean() > 0.05
+    assert np.array_equal(got["hitDistance"].view(np.uint32), bf["hitDistance"].view(np.uint32))
+    # moved on the device: the refit keeps the tight boxes up to date
+    ids = np.arange(n_inst, dtype=np.uint32)
+    xfs = np.array([placement(i + 1) for i in range(n_inst)], dtype=np.float32)
+    ctx.set_instance_transforms(ids, xfs)
+    moved = scene.instances.copy()
+    for i, xf in zip(ids, xfs):
+        old = scene.instances[i]
+        moved[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), xf, scene.blas[int(old["bvhIdx"])][0][0])
+    refitted, _ = ctx.read_tlas(len(nodes), n_inst)
+    _check_tlas_structure(refitted, idx, moved, _geometry_bounds(scene, moved))
+    after = SH.BuiltScene.__new__(SH.BuiltScene)
+    after.__dict__.update(scene.__dict__)
+    after.instances = moved
+    after.tlas_nodes, after.tlas_idx = capi.tlas_build(moved)
+    bf = after.oracle().brute_closest(rays)
+    got = ctx.trace_batch(rays)
+    assert np.array_equal(got["hitDistance"].view(np.uint32), bf["hitDistance"].view(np.uint32))
+    # singular placements: the build, the refit and the traversal end
+    flat = np.array([capi.mat4_from_trs(rng.uniform(-3, 3, 3), rng.uniform(0, 360, 3), (1.0, 0.0, 1.5)) for _ in range(4)], dtype=np.float32)
+    ctx.set_instance_transforms(np.array([1, 5, 9, 13], np.uint32), flat)
+    assert len(ctx.trace_batch(rays)) == len(rays)
+    for k, i in enumerate((1, 5, 9, 13)):
+        old = moved[i]
+        moved[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), flat[k], scene.blas[int(old["bvhIdx"])][0][0])
+    ctx.rebuild_tlas(moved)
+    assert len(ctx.trace_batch(rays)) == len(rays)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("builder", [-1, 0, 16])
 def test_device_tlas_build_survives_bounds_that_are_not_numbers(gpu_ctx_factory, builder):
     """instances with NaN / infinite world bounds through nxhip_rebuild_tlas (all three device builders): it returns, every
