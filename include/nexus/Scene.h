@@ -42,7 +42,8 @@ public:
     void SetTlasRefit(bool enable) { m_TlasRefit = enable; }
     // Extension, off by default: leave the TLAS to the device.  Update() then builds no tree on the host when instances were
     // added or removed — PathTracer::UpdateDeviceScene has the device build it from the instances' world boxes
-    // (nxhip_rebuild_tlas: linear BVH, a millisecond where the reference's agglomerative clustering takes seconds) — and
+    // (nxhip_rebuild_tlas: the binned-SAH builder over the instance boxes, milliseconds where the reference's agglomerative
+    // clustering takes seconds, and a tree rays enter fewer instances of) — and
     // moved instances are refitted on the device as with SetTlasRefit.  GetTLAS() holds no tree in this mode.
     void SetDeviceTlasBuild(bool enable) { m_DeviceTlas = enable; tlasDirty = true; }
     bool UsesDeviceTlasBuild() const { return m_DeviceTlas; }

@@ -485,7 +485,7 @@ class Context:
             self.local_count = len(pm)
 
     def build_blas(self, tris):
-        """BLAS built on the device (LBVH + wide collapse); returns the BLAS id"""
+        """BLAS built on the device (binned SAH + SAH-DP collapse by default, see set_device_builder); returns the BLAS id"""
         t = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
         bid = C.c_int32(-1)
         self.L.nxhip_build_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
@@ -511,7 +511,7 @@ class Context:
         check(self.L.nxhip_release_queues(self.h), "nxhip_release_queues")
 
     def rebuild_tlas(self, instances):
-        """build the TLAS on the device (LBVH over the instances' world boxes) and install it; returns (nodes, instance index list)"""
+        """build the TLAS on the device (the BLAS builder over the instances' boxes) and install it; returns (nodes, instance index list)"""
         instances = np.ascontiguousarray(instances, dtype=pod.INST_DT)
         self.L.nxhip_rebuild_tlas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         check(self.L.nxhip_rebuild_tlas(self.h, _ptr(instances), len(instances)), "nxhip_rebuild_tlas")

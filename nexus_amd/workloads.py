@@ -83,7 +83,7 @@ class Workload:
         return int(sum(80 * len(b[0]) + 48 * len(b[1]) for b in self.blas) + 80 * len(self.tlas_nodes) + 80 * len(self.instances))
 
     def upload(self, ctx, device_bvh=False, device_tlas=False):
-        """device_bvh: build every BLAS on the GPU (nxhip_build_blas: LBVH + wide collapse) instead of uploading the host
+        """device_bvh: build every BLAS on the GPU (nxhip_build_blas: binned SAH + SAH-DP collapse) instead of uploading the host
         builder's; the instances' world bounds follow the BLAS root frame, so instances and TLAS are rebuilt for those roots."""
         ctx.clear_blas()
         ctx.clear_textures()
