@@ -638,7 +638,7 @@ def main():
         # a 1-GPU box's CPU share is 16 hardware threads
         stamp("cpu baseline (oracle on the host cores)")
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-        cb = cpu_baseline(sc, W, H, threads, 1 if big else 4, single_core=not big)
+        cb = cpu_baseline(sc, W, H, threads, 2 if big else 12, single_core=not big)  # about 10-15 s of CPU work on the box's 16 threads
         cb["value"] = round(cb["value"], 4)
         out["cpu_baseline"] = cb
 
