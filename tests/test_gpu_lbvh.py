@@ -133,6 +133,33 @@ def test_device_built_blas_traces_like_the_sah_build_and_brute_force(gpu_ctx_fac
     assert np.array_equal(occl, ref.trace_shadow_batch(rays[:5000], np.full(5000, 3.0, np.float32)))
 
 
+def test_two_device_builds_of_a_mesh_are_the_same_tree(gpu_ctx_factory):
+    """The top-down build hands out node numbers and level slots with atomics, but what it decides from — counts, min / max boxes,
+    scan positions — does not depend on their order: two builds of a mesh give trees that every ray walks the same way (same hit
+    records including equidistant ties, same numbers of nodes and triangles visited), which is what lets every rank of a tile
+    split build its own copy."""
+    tris = np.ascontiguousarray(scenegen.displaced_torus(160, 80, seed=6, major=0.6, minor=0.25, amp=0.05), dtype=pod.TRI_DT)
+    rays = np.concatenate([scenegen.random_rays(20000, seed=3, radius=4.0, target_extent=1.2), scenegen.interior_rays(20000, seed=4, extent=1.0)])
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    outs = []
+    for _ in range(2):
+        ctx = gpu_ctx_factory(32, 32)
+        bid = ctx.build_blas(tris)
+        nodes, idx = ctx.read_blas(bid, len(tris))
+        inst = np.array([capi.instance_init(bid, 0, ident, nodes[0])], dtype=pod.INST_DT)
+        tn, ti = capi.tlas_build(inst)
+        ctx.set_tlas(tn, ti, inst)
+        ctx.enable_trace_stats(True)
+        ctx.read_trace_stats(reset=True)
+        hits = ctx.trace_batch(rays)
+        st, _ = ctx.read_trace_stats(reset=True)
+        outs.append((len(nodes), sorted(idx.tolist()) == list(range(len(tris))), hits, st["nodes"], st["tris"]))
+    a, b = outs
+    assert a[0] == b[0] and a[1] and b[1]
+    assert SH.hit_records_equal(a[2], b[2])
+    assert (a[3], a[4]) == (b[3], b[4])
+
+
 @pytest.mark.parametrize("builder", [0, -1], ids=["radix", "top-down-sah"])
 def test_device_build_of_a_million_triangles_is_fast_and_valid(gpu_ctx_factory, builder):
     import time
