@@ -15,6 +15,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "nexus_fmath.h"
 #include "nexus_pod.h"
 
 #ifdef __cplusplus
@@ -272,6 +273,12 @@ int nxhip_bsdf_eval_batch(nxhip_ctx *ctx, const nx_material *material, const nx_
 /* kind as in nxhip_upload_texture (0 diffuse, 1 emissive, 2 hdr; textureId ignored for hdr); uv = 2*count floats,
  * rgba = 4*count floats (sRGB-decoded, bilinear, wrap addressing: what the shade kernels see). */
 int nxhip_tex2d_batch(nxhip_ctx *ctx, int kind, int textureId, const float *uv, uint32_t count, float *rgba);
+
+/* The transcendental functions of the shading path (include/nexus_fmath.h: the ONE text the kernels and the CPU oracle both
+ * compile — sin / cos / exp / log / pow / atan2 / asin replacing the libm calls of Random.cuh:119-121, Microfacet.cuh:18,75,
+ * PathTracer.cu:65-83, Utils.h:51-54) on host arrays: out[i] = nxf_apply(op, a[i], b[i]), op = NXF_OP_*; b may be NULL for the
+ * one-argument functions.  tests/test_fmath.py compares the device's results with the oracle's bit for bit. */
+int nxhip_fmath_batch(nxhip_ctx *ctx, int op, const double *a, const double *b, uint32_t count, double *out);
 
 /* Visit counters of the two trace kernels (algorithmic bytes for the roofline).  When enabled
  * the trace kernels run their counting variant; off by default. */

@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
-    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown",
+    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch",
 ]
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
@@ -130,6 +130,7 @@ def lib():
     L.nxhip_bsdf_sample_batch.argtypes = [vp, vp, vp, u32, vp]
     L.nxhip_bsdf_eval_batch.argtypes = [vp, vp, vp, u32, vp]
     L.nxhip_tex2d_batch.argtypes = [vp, C.c_int, C.c_int, vp, u32, vp]
+    L.nxhip_fmath_batch.argtypes = [vp, C.c_int, vp, vp, u32, vp]
     L.nxhip_enable_trace_stats.argtypes = [vp, C.c_int]
     L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
     L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
@@ -702,6 +703,14 @@ class Context:
         uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((len(uv), 4), dtype=np.float32)
         check(self.L.nxhip_tex2d_batch(self.h, {"diffuse": 0, "emissive": 1, "hdr": 2}[kind], int(texture_id), _ptr(uv), len(uv), _ptr(out)), "nxhip_tex2d_batch")
+        return out
+
+    def fmath_batch(self, op, a, b=None):
+        """include/nexus_fmath.h on the device: out[i] = nxf_apply(op, a[i], b[i]) (op: pod.NXF_OP_*)"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros(len(a), dtype=np.float64)
+        check(self.L.nxhip_fmath_batch(self.h, int(op), _ptr(a), None if bb is None else _ptr(bb), len(a), _ptr(out)), "nxhip_fmath_batch")
         return out
 
     def enable_trace_stats(self, on=True):

@@ -43,7 +43,7 @@ NXD float beckmann_d(float alpha, float mDotN)
 {
     const float alphaSq = alpha * alpha;
     const float cosThetaSq = mDotN * mDotN;
-    const float numerator = expf((cosThetaSq - 1.0f) / (alphaSq * cosThetaSq));
+    const float numerator = nxf_expf((cosThetaSq - 1.0f) / (alphaSq * cosThetaSq));
     const double denominator = kPiD * alphaSq * cosThetaSq * cosThetaSq;
     return (float)(numerator / denominator);
 }
@@ -68,11 +68,11 @@ NXD f3 sample_half_beckmann(float alpha, uint32_t& rng)
     const float a = alpha * 0.5f + alpha * 0.5f;
     const float ux = rng_next(rng);
     const float uy = rng_next(rng);
-    const float tanThetaSquared = -(a * a) * logf(1.0f - ux);
+    const float tanThetaSquared = -(a * a) * nxf_logf(1.0f - ux);
     const float phi = kTwoPi * uy;
     const float cosTheta = (float)(1.0 / sqrtf(1.0f + tanThetaSquared));
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-    return normalize3(mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta));
+    return normalize3(mk3(sinTheta * nxf_cosf(phi), sinTheta * nxf_sinf(phi), cosTheta));
 }
 NXD f3 reflect3(f3 i, f3 n) { return i - (n * 2.0f) * dot3(n, i); }
 NXD float rough_alpha(float wiz, float roughness) { return clampf((1.2f - 0.2f * sqrtf(fabsf(wiz))) * roughness * roughness, 1.0e-4f, 1.0f); }

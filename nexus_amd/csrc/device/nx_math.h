@@ -1,15 +1,18 @@
 // nx_math.h — device-side float3 / matrix / quaternion helpers (HIP, gfx950).
 //
-// Arithmetic convention (shared with the CPU oracle's orc_math.h so that results agree to the bit wherever
-// only + - * / sqrt fma are involved): the device code is compiled with -ffp-contract=off; dot3, cross3 and
+// Arithmetic convention (shared with the CPU oracle's orc_math.h so that results agree to the bit):
+// the device code is compiled with -ffp-contract=off; dot3, cross3 and
 // the row-major matrix transforms use explicit fmaf in the order written here; normalize(v) is
-// v * (1 / sqrtf(dot3(v,v))) with correctly rounded divide and sqrt (hipcc's default).
+// v * (1 / sqrtf(dot3(v,v))) with correctly rounded divide and sqrt (hipcc's default); the transcendental functions of
+// the shading path come from include/nexus_fmath.h (nxf_*), one text of IEEE operations compiled here and in the oracle.
 // Semantics follow the reference's helper_math derivative (/root/reference/Nexus/src/Utils/cuda_math.h:1143-1535),
 // Mat4 (Math/Mat4.h:142-230) and Cuda/Utils.cuh:47-74; nvcc contracts the same expressions into FMAs.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "nexus_fmath.h"
 
 namespace nxd {
 

@@ -52,8 +52,10 @@ NXD f3 cosine_hemisphere(uint32_t& rng)
     const float r2 = rng_next(rng);
     const float B = sqrtf(r2);
     const double phi = 2 * kPiD * r1;
-    const float x = (float)(cos(phi) * B);
-    const float y = (float)(sin(phi) * B);
+    double sinPhi, cosPhi;
+    nxf_sincos(phi, &sinPhi, &cosPhi);
+    const float x = (float)(cosPhi * B);
+    const float y = (float)(sinPhi * B);
     const float z = sqrtf(1 - r2);
     return mk3(x, y, z);
 }

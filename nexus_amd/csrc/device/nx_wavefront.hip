@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
 NXD f3 sample_background(const DeviceState* S, f3 d)
 {
     if (S->hdrMap.texels) {
-        const float theta = atan2f(d.z, d.x);
-        const float phi = asinf(d.y);
+        const float theta = nxf_atan2f(d.z, d.x);
+        const float phi = nxf_asinf(d.y);
         const float u = (float)((theta + kPiD) * kInvPi * 0.5);
         const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
         const float4 c = tex2d(S->hdrMap, S->srgbLut, u, v);
@@ -220,8 +220,8 @@ NXD f3 sample_background(const DeviceState* S, f3 d)
 // the texel a direction falls in, with (u, v) exactly as sample_background computes them
 NXD uint32_t env_texel(const DeviceState* S, f3 d)
 {
-    const float theta = atan2f(d.z, d.x);
-    const float phi = asinf(d.y);
+    const float theta = nxf_atan2f(d.z, d.x);
+    const float phi = nxf_asinf(d.y);
     const float u = (float)((theta + kPiD) * kInvPi * 0.5);
     const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
     const int W = (int)S->hdrMap.width, H = (int)S->hdrMap.height;
@@ -263,8 +263,8 @@ NXD f3 env_sample(const DeviceState* S, float r1, float r2)
     const float fx = (r2 - xlo) / (row[x] - xlo);
     const float u = ((float)x + fx) / (float)W, v = ((float)y + fy) / (float)H;
     const float phi = (1.0f - v) * 3.14159265f - 1.57079633f, theta = u * 6.28318531f - 3.14159265f;
-    const float c = cosf(phi);
-    return mk3(c * cosf(theta), sinf(phi), c * sinf(theta));
+    const float c = nxf_cosf(phi);
+    return mk3(c * nxf_cosf(theta), nxf_sinf(phi), c * nxf_sinf(theta));
 }
 
 // lights the NEE chooses among: the mesh lights, plus the environment when it is importance sampled
@@ -805,7 +805,7 @@ NXD uint32_t tonemap_rgba8(f3 c)
     for (int k = 0; k < 3; k++) {
         float x = v[k] * 0.6f;
         x = clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
-        x = (float)pow((double)x, 0.45454545454);
+        x = (float)nxf_pow((double)x, 0.45454545454);
         x = clampf(x, 0.0f, 1.0f);
         out |= (uint32_t)(uint8_t)(x * 255.0f) << (8 * k);
     }
@@ -890,6 +890,13 @@ __global__ void __launch_bounds__(kWideBlock) bsdf_hook_kernel(const nx_material
     }
 }
 
+// include/nexus_fmath.h on arrays (nxhip_fmath_batch, a test hook like the two above)
+__global__ void __launch_bounds__(kWideBlock) fmath_hook_kernel(const int op, const double* __restrict__ a, const double* __restrict__ b, const uint32_t count,
+                                                                 double* __restrict__ out)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) out[k] = nxf_apply(op, a[k], b ? b[k] : 0.0);
+}
+
 // (the texture descriptor comes by value: selecting one of S->diffuseMaps[i] / S->emissiveMaps[i] / S->hdrMap with a
 //  uniform three-way branch here was miscompiled by hipcc 7.2 — the third arm left the descriptor pointer unset)
 __global__ void __launch_bounds__(kWideBlock) tex2d_hook_kernel(const TextureDev t, const float* __restrict__ srgbLut, const float* __restrict__ uv,
@@ -919,5 +926,6 @@ const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }
 const void* compose_kernel_ptr() { return (const void*)compose_kernel; }
 const void* bsdf_hook_kernel_ptr() { return (const void*)bsdf_hook_kernel; }
 const void* tex2d_hook_kernel_ptr() { return (const void*)tex2d_hook_kernel; }
+const void* fmath_hook_kernel_ptr() { return (const void*)fmath_hook_kernel; }
 
 }  // namespace nxd

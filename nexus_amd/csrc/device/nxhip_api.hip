@@ -23,6 +23,7 @@ const void* generate_kernel_ptr();
 const void* accumulate_kernel_ptr();
 const void* compose_kernel_ptr();
 const void* bsdf_hook_kernel_ptr();
+const void* fmath_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
@@ -2115,6 +2116,31 @@ int nxhip_tex2d_batch(nxhip_ctx* c, int kind, int textureId, const float* uv, ui
     NX_HIP(hipLaunchKernel(tex2d_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
     NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(rgba, dOut.p, (size_t)count * 16, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
+int nxhip_fmath_batch(nxhip_ctx* c, int op, const double* a, const double* b, uint32_t count, double* out)
+{
+    NX_CHECK_CTX(c);
+    if (op < 0 || op >= NXF_OP_COUNT) return fail_invalid("nxhip_fmath_batch: op must be one of NXF_OP_*");
+    if ((!a || !out) && count) return fail_invalid("nxhip_fmath_batch: null buffer");
+    if (count == 0) return NXHIP_OK;
+    NX_HIP(hipSetDevice(c->device));
+    DevBuf dA, dB, dOut;
+    NX_ALLOC(dA, (size_t)count * 8);
+    NX_ALLOC(dOut, (size_t)count * 8);
+    NX_HIP(hipMemcpy(dA.p, a, (size_t)count * 8, hipMemcpyHostToDevice));
+    if (b) {
+        NX_ALLOC(dB, (size_t)count * 8);
+        NX_HIP(hipMemcpy(dB.p, b, (size_t)count * 8, hipMemcpyHostToDevice));
+    }
+    const double* pa = dA.as<double>();
+    const double* pb = b ? dB.as<double>() : nullptr;
+    double* po = dOut.as<double>();
+    void* args[5] = {(void*)&op, (void*)&pa, (void*)&pb, (void*)&count, (void*)&po};
+    NX_HIP(hipLaunchKernel(fmath_hook_kernel_ptr(), dim3(c->wideBlocks), dim3(kWideBlockThreads), args, 0, c->stream));
+    NX_SYNC_ALL(c);
+    NX_HIP(hipMemcpy(out, dOut.p, (size_t)count * 8, hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
 

@@ -158,6 +158,11 @@ int orc_bsdf_eval(const nx_material *m, const float wi[3], const float wo[3], fl
 /* Software stand-in for tex2D<float4> on an sRGB, wrap, bilinear, normalised-coordinate texture. */
 void orc_tex2d(const nx_texture_desc *t, float u, float v, float out[4]);
 
+/* The shared transcendental functions (include/nexus_fmath.h) on arrays: out[i] = nxf_apply(op, a[i], b[i]); op = NXF_OP_*;
+ * b may be NULL for the one-argument functions.  tests/test_fmath.py holds them against a 50-digit reference (CPU) and
+ * against the device's nxhip_fmath_batch bit for bit (GPU). */
+void orc_fmath_batch(int op, const double *a, const double *b, uint32_t n, double *out);
+
 /* ---------------------------------------------------------------- wavefront (orc_wavefront.c) */
 
 typedef struct orc_queue_sizes {

@@ -14,8 +14,9 @@
  *   - dot3, cross3 and the Mat4 transforms use explicit fmaf in the order written below (the
  *     reference's nvcc build contracts these into FMAs too; the exact grouping is ours);
  *   - normalize(v) = v * (1 / sqrtf(dot3(v,v))) with correctly rounded divide and sqrt;
- *   - transcendental functions (sin, cos, exp, log, pow, atan2, asin) come from the platform libm on
- *     each side and are only expected to agree to a few ulp.
+ *   - the transcendental functions of the shading path (sin, cos, exp, log, pow, atan2, asin) come from
+ *     include/nexus_fmath.h — one text compiled on both sides, IEEE operations only — so they too agree
+ *     bit for bit (round 4; before, libm here and ocml on the device differed by an ulp or two).
  */
 #ifndef ORC_MATH_H
 #define ORC_MATH_H
@@ -24,6 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../include/nexus_pod.h"
+#include "../include/nexus_fmath.h"
 
 typedef struct { float x, y, z; } f3;
 typedef struct { float x, y; } f2;

@@ -12,7 +12,8 @@
  * Where the reference promotes to double through `#define PI 3.14159265358979323846`
  * (Utils/Utils.h:7) or double literals, the same promotion is written out explicitly here.
  * C++ overload resolution picks the float overload for float arguments (sqrt, exp, log, cos, sin, pow,
- * fabs, atan2, asin); this C file therefore calls the f-suffixed functions in those places.
+ * fabs, atan2, asin); this C file therefore calls the f-suffixed functions in those places — the
+ * transcendental ones through include/nexus_fmath.h (nxf_*), the text the device code calls too.
  * Function-argument evaluation order for make_float2(Rand(), Rand()) is taken left to right.
  */
 #include "nexus_oracle.h"
@@ -71,8 +72,10 @@ f3 orc_cosine_hemisphere(uint32_t *rng)
     const float r2 = orc_rand(rng);
     const float B = sqrtf(r2);
     const double phi = 2 * ORC_PI * r1;
-    const float x = (float)(cos(phi) * B);
-    const float y = (float)(sin(phi) * B);
+    double sinPhi, cosPhi;
+    nxf_sincos(phi, &sinPhi, &cosPhi);
+    const float x = (float)(cosPhi * B);
+    const float y = (float)(sinPhi * B);
     const float z = sqrtf(1 - r2);
     return mk3(x, y, z);
 }
@@ -146,7 +149,7 @@ static float beckmann_d(float alpha, float mDotN)
 {
     const float alphaSq = alpha * alpha;
     const float cosThetaSq = mDotN * mDotN;
-    const float numerator = expf((cosThetaSq - 1.0f) / (alphaSq * cosThetaSq));
+    const float numerator = nxf_expf((cosThetaSq - 1.0f) / (alphaSq * cosThetaSq));
     const double denominator = ORC_PI * alphaSq * cosThetaSq * cosThetaSq;
     return (float)(numerator / denominator);
 }
@@ -176,11 +179,11 @@ static f3 sample_half_beckmann(float alpha, uint32_t *rng)
     const float a = alpha * 0.5f + alpha * 0.5f; /* dot(make_float2(alpha), make_float2(0.5f, 0.5f)) */
     const float ux = orc_rand(rng);
     const float uy = orc_rand(rng);
-    const float tanThetaSquared = -(a * a) * logf(1.0f - ux);
+    const float tanThetaSquared = -(a * a) * nxf_logf(1.0f - ux);
     const float phi = ORC_TWO_PI * uy;
     const float cosTheta = (float)(1.0 / sqrtf(1.0f + tanThetaSquared));
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-    return normalize3(mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta));
+    return normalize3(mk3(sinTheta * nxf_cosf(phi), sinTheta * nxf_sinf(phi), cosTheta));
 }
 
 static f3 reflect3(f3 i, f3 n) { return sub3(i, scale3(scale3(n, 2.0f), dot3(n, i))); } /* cuda_math.h:1472-1475 */
@@ -413,4 +416,10 @@ void orc_tex2d(const nx_texture_desc *t, float u, float v, float out[4])
 {
     const f4 r = orc_tex2d_f4(t, u, v);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+/* include/nexus_fmath.h on arrays (see nexus_oracle.h) */
+void orc_fmath_batch(int op, const double *a, const double *b, uint32_t n, double *out)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = nxf_apply(op, a[i], b ? b[i] : 0.0);
 }

@@ -112,8 +112,8 @@ void orc_wavefront_destroy(orc_wavefront *w)
 static f3 sample_background(const orc_scene *s, f3 d)
 {
     if (s->hdrMap) {
-        const float theta = atan2f(d.z, d.x);
-        const float phi = asinf(d.y);
+        const float theta = nxf_atan2f(d.z, d.x);
+        const float phi = nxf_asinf(d.y);
         const float u = (float)((theta + ORC_PI) * ORC_INV_PI * 0.5);
         const float v = (float)(1.0f - (phi + ORC_PI * 0.5f) * ORC_INV_PI);
         const f4 c = orc_tex2d_f4(s->hdrMap, u, v);
@@ -159,8 +159,8 @@ void orc_env_distribution(const nx_texture_desc *hdr, float *marginalCdf, float 
 /* (u, v) of a direction exactly as SampleBackground computes them, and the texel they fall in */
 static void env_texel(const orc_scene *s, f3 d, int *x, int *y)
 {
-    const float theta = atan2f(d.z, d.x);
-    const float phi = asinf(d.y);
+    const float theta = nxf_atan2f(d.z, d.x);
+    const float phi = nxf_asinf(d.y);
     const float u = (float)((theta + ORC_PI) * ORC_INV_PI * 0.5);
     const float v = (float)(1.0f - (phi + ORC_PI * 0.5f) * ORC_INV_PI);
     const int W = (int)s->hdrMap->width, H = (int)s->hdrMap->height;
@@ -201,8 +201,8 @@ static f3 env_sample(const orc_scene *s, float r1, float r2)
     const float fx = (r2 - xlo) / (row[x] - xlo);
     const float u = ((float)x + fx) / (float)W, v = ((float)y + fy) / (float)H;
     const float phi = (1.0f - v) * 3.14159265f - 1.57079633f, theta = u * 6.28318531f - 3.14159265f;
-    const float c = cosf(phi);
-    return mk3(c * cosf(theta), sinf(phi), c * sinf(theta));
+    const float c = nxf_cosf(phi);
+    return mk3(c * nxf_cosf(theta), nxf_sinf(phi), c * nxf_sinf(theta));
 }
 
 /* lights the NEE chooses among: the mesh lights, plus the environment when it is importance sampled */
@@ -229,6 +229,13 @@ static void generate(orc_wavefront *w)
         const f3 direction = normalize3(target);
         w->rayOrigin[index] = origin;
         w->lastPdf[index] = 1.0e10f;
+        /* A deliberate definition where the reference leaves a value undefined: pathState.radiance[pixel] is only ever WRITTEN by
+         * the bounce-1 logic (miss) or material kernel (hit) — PathTracer.cu:155-158, 387-390 — so a path whose first hit lands in
+         * a queue without a kernel (a CONDUCTOR: the kernel body is commented out, PathTracer.cu:475-478) keeps whatever the
+         * previous frame left there (uninitialised memory in frame 1) and AccumulateKernel averages that in.  Device and oracle
+         * both start every frame's path radiance at zero: such a path contributes nothing.  (Found in round 4 when frames became
+         * comparable bit for bit: 0.17 % of the material zoo's pixels in the reference-conductor mode.) */
+        w->radiance[index] = mk3s(0.0f);
         w->trOrigin[index] = origin;
         w->trDirection[index] = direction;
         w->trPixel[index] = index;
@@ -626,7 +633,7 @@ uint32_t orc_tonemap_rgba8(const float rgb[3])
     for (int c = 0; c < 3; c++) {
         float x = rgb[c] * 0.6f;
         x = clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
-        x = (float)pow((double)x, 0.45454545454);
+        x = (float)nxf_pow((double)x, 0.45454545454);
         x = clampf(x, 0.0f, 1.0f);
         out |= (uint32_t)(uint8_t)(x * 255.0f) << (8 * c);
     }

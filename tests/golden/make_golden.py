@@ -8,8 +8,9 @@ the reference ships no test vectors for this path, so the oracle itself stays "p
 
     python tests/golden/make_golden.py          # rewrites oracle_pins.npz next to this file
 
-Integer / bit-pattern data (BVH bytes, hit records, RNG streams) is compared exactly by the tests; radiance and queue
-sizes depend on libm's sin/cos/pow and are compared with the tolerances written in tests/test_golden.py.
+Everything is compared exactly by the tests (tests/test_golden.py): BVH bytes, hit records, RNG streams, and — since the
+transcendental functions became the shared text of include/nexus_fmath.h in round 4 — radiance, accumulation, RGBA8 and queue
+sizes too, on the CPU (oracle) and on the GPU (HIP path).
 """
 import hashlib
 import os

@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle.so")
 
 def build(force=False):
     srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h"))]
+    srcs += [os.path.join(_ORACLE_DIR, "..", "include", f) for f in ("nexus_pod.h", "nexus_fmath.h")]  # shared with the product
     stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _ORACLE_DIR, "-B", "liboracle.so"], check=True, capture_output=True)
@@ -105,6 +106,7 @@ def lib():
         L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_tex2d.argtypes = [C.POINTER(_TexDesc), C.c_float, C.c_float, C.c_void_p]
+        L.orc_fmath_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_wavefront_create.argtypes = [C.POINTER(_Scene), C.c_uint32, C.c_void_p, C.c_int, C.c_int]
         L.orc_wavefront_create.restype = C.c_void_p
         L.orc_wavefront_destroy.argtypes = [C.c_void_p]
@@ -122,6 +124,15 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def fmath_batch(op, a, b=None):
+    """include/nexus_fmath.h as the oracle compiles it: out[i] = nxf_apply(op, a[i], b[i])"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros(len(a), dtype=np.float64)
+    lib().orc_fmath_batch(int(op), _ptr(a), None if bb is None else _ptr(bb), len(a), _ptr(out))
+    return out
 
 
 def _copy_out(addr, count, dtype):

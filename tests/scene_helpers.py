@@ -122,6 +122,39 @@ def material_zoo_scene(width=96, height=64, path_length=5, hdr=True, textures=Tr
     return sc
 
 
+def frames_identical(got, want, what=""):
+    """Device frame against oracle frame, BIT FOR BIT (since round 4 both sides compile the same text for the transcendental
+    functions, include/nexus_fmath.h, so nothing is left to tolerate).  Always prints what was measured — pixels identical,
+    pixels within 1e-3, the first pixels that differ — so that a failing comparison says how far off it was."""
+    got = np.ascontiguousarray(got, dtype=np.float32).reshape(-1, 3)
+    want = np.ascontiguousarray(want, dtype=np.float32).reshape(-1, 3)
+    if got.shape != want.shape:
+        print("%s: shapes differ %r / %r" % (what, got.shape, want.shape))
+        return False
+    same = np.all(got.view(np.uint32) == want.view(np.uint32), axis=1)
+    n_same = int(same.sum())
+    if n_same != len(same):
+        bad = np.flatnonzero(~same)
+        print("%s: %d of %d pixels identical (%.6f), %.6f within 1e-3; first differing pixels %s: device %s, oracle %s" % (
+            what, n_same, len(same), n_same / len(same), image_agreement(got, want), bad[:4].tolist(), got[bad[:4]].tolist(), want[bad[:4]].tolist()))
+    return n_same == len(same)
+
+
+QUEUE_KEYS = ("traceSize", "traceShadowSize", "diffuseSize", "plasticSize", "dielectricSize", "conductorSize")
+
+
+def queue_sizes_identical(got, want, slots=None):
+    """Every queue size of every bounce equal (device read-back dict / oracle dict)."""
+    ok = True
+    for k in QUEUE_KEYS:
+        a, b = np.asarray(got[k])[:slots], np.asarray(want[k])[:slots]
+        if not np.array_equal(a, b):
+            first = int(np.flatnonzero(a != b)[0])
+            print("queue %s differs first at bounce %d: device %d, oracle %d" % (k, first, a[first], b[first]))
+            ok = False
+    return ok
+
+
 def image_agreement(got, want, rel=1e-3):
     """Fraction of pixels whose RGB all satisfy |got - want| <= rel * max(1, |want|)."""
     tol = rel * np.maximum(1.0, np.abs(want))

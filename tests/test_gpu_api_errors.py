@@ -112,7 +112,7 @@ def test_settings_modes_and_viewport_arguments(gpu_ctx_factory):
     ctx.accumulate()
     w = O.Wavefront(scene.oracle(), W * H, None, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_REFERENCE)
     w.render(1, threads=4)
-    assert SH.image_agreement(ctx.read_radiance(), w.radiance(), 1e-3) >= 0.995
+    assert SH.frames_identical(ctx.read_radiance(), w.radiance(), "after the refused calls")
 
 
 def test_contexts_are_independent_and_closing_is_idempotent(gpu_ctx_factory):

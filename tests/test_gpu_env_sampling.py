@@ -42,15 +42,14 @@ def test_env_sampling_frames_agree_with_the_oracle(gpu_ctx_factory, with_mesh_li
     scene.upload(ctx)
     for modes in ((pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED), (pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST)):
         ctx.set_modes(modes[0], modes[1], pod.CONDUCTOR_REFERENCE)
+        ctx.set_tail_bounce(0)  # the queue sizes of every bounce are compared below
         ctx.reset_frame_number()
         w = O.Wavefront(scene.oracle(), W * H, None, modes[0], pod.CONDUCTOR_REFERENCE)
         for f in (1, 2):
             ctx.render_frame()
             w.render(f)
-            assert SH.image_agreement(ctx.read_radiance(), w.radiance(), 1e-3) >= 0.99, (modes, f)
-        got, want = ctx.read_queue_sizes(), w.queue_sizes()
-        if modes[1] == pod.COMPACT_ORDERED:
-            assert abs(int(got["traceShadowSize"][1]) - int(want["traceShadowSize"][1])) <= 8  # an environment sample per shaded hit, few rejections
+            assert SH.frames_identical(ctx.read_radiance(), w.radiance(), "environment NEE, modes %r, frame %d" % (modes, f))
+        assert SH.queue_sizes_identical(ctx.read_queue_sizes(), w.queue_sizes(), 6)
 
 
 def test_env_sampling_keeps_the_expectation_and_cuts_the_noise(gpu_ctx_factory):

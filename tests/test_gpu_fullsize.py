@@ -12,8 +12,6 @@ from tests import scene_helpers as SH
 
 pytestmark = pytest.mark.gpu
 
-PIXEL_TOL = 1e-3
-
 
 def _subset(width, height, n, seed):
     return np.sort(np.random.RandomState(seed).choice(width * height, n, replace=False)).astype(np.uint32)
@@ -45,7 +43,7 @@ def _check_trace_level(ctx, scene, rays, brute=48):
     assert np.array_equal(got["hitDistance"][sub].view(np.uint32), bf["hitDistance"].view(np.uint32))
 
 
-def _check_frames(ctx, scene, width, height, n_pixels, frames, min_agree):
+def _check_frames(ctx, scene, width, height, n_pixels, frames):
     ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
     pm = _subset(width, height, n_pixels, seed=17)
     w = O.Wavefront(scene.oracle(), len(pm), pm, pod.RNG_PIXEL_KEYED, pod.CONDUCTOR_EXTENDED)
@@ -62,11 +60,11 @@ def _check_frames(ctx, scene, width, height, n_pixels, frames, min_agree):
         w.accumulate(f)
         want = w.radiance()
         assert want.max() > 0.0, "the pixel subset must see light"
-        agree = SH.image_agreement(rad[pm], want, PIXEL_TOL)
-        assert agree >= min_agree, (f, agree)
+        # bit for bit (round 4; until round 3: ">= 97-99 % of the subset within 1e-3", with the measured figure printed nowhere)
+        assert SH.frames_identical(rad[pm], want, "%d x %d frame %d, %d seeded pixels" % (width, height, f, n_pixels))
     acc = ctx.read_accumulation()
-    assert SH.image_agreement(acc[pm], w.accumulation(), PIXEL_TOL) >= min_agree
-    # primary rays see no transcendental function: the first trace queue is exact
+    assert SH.frames_identical(acc[pm], w.accumulation(), "accumulation")
+    assert np.array_equal(ctx.read_rgba8()[pm], w.rgba8())
     q = ctx.read_queue_sizes()
     assert q["traceSize"][0] == width * height
     # idempotence: the same frames again, bit for bit
@@ -83,7 +81,7 @@ def test_config2_one_million_triangles_1080p(gpu_ctx_factory):
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     _check_trace_level(ctx, scene, _camera_like_rays(scene, 200000, 3, extent=1.6, radius=6.0))
-    _check_frames(ctx, scene, W, H, n_pixels=8192, frames=2, min_agree=0.99)
+    _check_frames(ctx, scene, W, H, n_pixels=16384, frames=2)
 
 
 def test_config4_thousand_instances_dielectric_environment(gpu_ctx_factory):
@@ -93,7 +91,7 @@ def test_config4_thousand_instances_dielectric_environment(gpu_ctx_factory):
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     _check_trace_level(ctx, scene, _camera_like_rays(scene, 100000, 7, extent=8.0, radius=25.0), brute=8)
-    _check_frames(ctx, scene, W, H, n_pixels=4096, frames=2, min_agree=0.97)
+    _check_frames(ctx, scene, W, H, n_pixels=8192, frames=2)
 
 
 def test_config5_ten_million_triangles_4k_path16(gpu_ctx_factory):
@@ -103,7 +101,7 @@ def test_config5_ten_million_triangles_4k_path16(gpu_ctx_factory):
     ctx = gpu_ctx_factory(W, H)
     scene.upload(ctx)
     _check_trace_level(ctx, scene, _camera_like_rays(scene, 100000, 9, extent=5.0, radius=12.0), brute=4)
-    w = _check_frames(ctx, scene, W, H, n_pixels=4096, frames=1, min_agree=0.97)
+    w = _check_frames(ctx, scene, W, H, n_pixels=8192, frames=1)
     # every material queue is exercised at this size
     q = ctx.read_queue_sizes()
     for k in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize"):
