@@ -29,8 +29,12 @@ enum {
     NXHIP_ERR_INVALID = 1, /* bad argument / state */
     NXHIP_ERR_HIP = 2,     /* a HIP runtime call failed */
     NXHIP_ERR_NO_DEVICE = 3,
-    NXHIP_ERR_TRAVERSAL = 4 /* a trace kernel gave up on rays that made no progress (malformed BVH): reported by nxhip_sync and the read-backs */
+    NXHIP_ERR_TRAVERSAL = 4, /* a trace kernel gave up on rays that made no progress (malformed BVH): reported by nxhip_sync and the read-backs */
+    NXHIP_ERR_ABI = 5        /* caller and library (or the library's own translation units) disagree about a struct layout / the API version */
 };
+
+/* Bumped whenever an entry point changes its signature or meaning, or a struct of this header / nexus_pod.h its layout. */
+#define NXHIP_API_VERSION 4
 
 /* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
 const char *nxhip_last_error(void);
@@ -310,6 +314,45 @@ int nxhip_read_kernel_times(nxhip_ctx *ctx, nxhip_kernel_times *out, int reset);
 
 /* Build-time facts for tests: 1 if the library was compiled with device code for gfx950. */
 int nxhip_has_gfx950_code(void);
+
+/* ---- ABI stamp ---------------------------------------------------------------------------------------
+ * A library that does not match its caller — a stale build picked up through NEXUS_AMD_LIB / LD_LIBRARY_PATH, a header of
+ * another version — used to show as a GPU memory fault in the first launch (round 3: gpurun_out/r3_07).
+ * Now it is an error status before anything is launched.
+ *   nxhip_header_abi_stamp()  what THIS header says, compiled into the caller: API version + size and key offsets of every
+ *                             struct that crosses the boundary, FNV-1a hashed;
+ *   nxhip_abi_stamp()         the same function as compiled into the library;
+ *   nxhip_check_library(s)    NXHIP_OK if s equals the library's stamp AND every translation unit of the library was compiled
+ *                             with the same device-side layouts (DeviceState, Counters, InstTrav, record strides ...: a library
+ *                             linked from objects of different source states is refused), else NXHIP_ERR_ABI + message.
+ * nxhip_create performs the library-internal half by itself.  C / C++ callers: nxhip_check_library(nxhip_header_abi_stamp())
+ * once after loading; the Python binding does the equivalent with the sizes of its own ctypes / numpy mirrors. */
+uint64_t nxhip_abi_stamp(void);
+int nxhip_check_library(uint64_t callerStamp);
+
+static inline uint64_t nxhip_abi_mix(uint64_t h, uint64_t v)
+{
+    int i;
+    for (i = 0; i < 8; i++) { h = (h ^ (v & 0xffu)) * 0x100000001b3ull; v >>= 8; }
+    return h;
+}
+static inline uint64_t nxhip_header_abi_stamp(void)
+{
+    /* (the list the Python binding mirrors: nexus_amd/capi.py abi_words) */
+    const uint64_t w[] = {
+        NXHIP_API_VERSION, NX_PATH_MAX_LENGTH,
+        sizeof(nx_bvh8_node), offsetof(nx_bvh8_node, meta), sizeof(nx_triangle), offsetof(nx_triangle, texCoord0),
+        sizeof(nx_bvh_instance), offsetof(nx_bvh_instance, transform), offsetof(nx_bvh_instance, materialId),
+        sizeof(nx_material), offsetof(nx_material, emissive), offsetof(nx_material, type), sizeof(nx_light), offsetof(nx_light, type),
+        sizeof(nx_camera), offsetof(nx_camera, resolution), sizeof(nx_render_settings), offsetof(nx_render_settings, backgroundColor),
+        sizeof(nx_ray), sizeof(nx_hit), sizeof(nx_bsdf_query), sizeof(nx_bsdf_result), offsetof(nx_bsdf_result, rngOut),
+        sizeof(nxhip_queue_sizes), sizeof(nxhip_trace_stats), offsetof(nxhip_trace_stats, cycles), sizeof(nxhip_kernel_times), NXHIP_K_COUNT,
+    };
+    uint64_t h = 0xcbf29ce484222325ull;
+    size_t i;
+    for (i = 0; i < sizeof w / sizeof w[0]; i++) h = nxhip_abi_mix(h, w[i]);
+    return h;
+}
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
-    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch",
+    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library",
 ]
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
@@ -72,6 +72,46 @@ class KernelTimes(C.Structure):
 
 KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate")
 
+API_VERSION = 4  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
+
+
+def abi_words():
+    """The list nxhip_header_abi_stamp() hashes (include/nexus_hip.h), from THIS module's mirrors of the C structs: API version
+    and the size / key offsets of everything that crosses the boundary."""
+    off = lambda dt, name: dt.fields[name][1]  # noqa: E731
+    return [
+        API_VERSION, pod.PATH_MAX_LENGTH,
+        pod.NODE_DT.itemsize, off(pod.NODE_DT, "meta"), pod.TRI_DT.itemsize, off(pod.TRI_DT, "texCoord0"),
+        pod.INST_DT.itemsize, off(pod.INST_DT, "transform"), off(pod.INST_DT, "materialId"),
+        pod.MAT_DT.itemsize, off(pod.MAT_DT, "emissive"), off(pod.MAT_DT, "type"), pod.LIGHT_DT.itemsize, off(pod.LIGHT_DT, "type"),
+        pod.CAM_DT.itemsize, off(pod.CAM_DT, "resolution"), pod.SETTINGS_DT.itemsize, off(pod.SETTINGS_DT, "backgroundColor"),
+        pod.RAY_DT.itemsize, pod.HIT_DT.itemsize, pod.BSDF_QUERY_DT.itemsize, pod.BSDF_RESULT_DT.itemsize, off(pod.BSDF_RESULT_DT, "rngOut"),
+        C.sizeof(QueueSizes), C.sizeof(TraceStats), TraceStats.cycles.offset, C.sizeof(KernelTimes), len(KERNEL_CLASSES),
+    ]
+
+
+def abi_stamp(words=None):
+    """FNV-1a over the little-endian 8-byte words: nxhip_header_abi_stamp() as these bindings would compute it"""
+    h = 0xcbf29ce484222325
+    for w in (abi_words() if words is None else words):
+        for _ in range(8):
+            h = ((h ^ (w & 0xff)) * 0x100000001b3) & 0xffffffffffffffff
+            w >>= 8
+    return h
+
+
+def check_library(L, stamp=None):
+    """Refuse a library that does not match these bindings — a stale build reached through NEXUS_AMD_LIB, a library linked
+    from objects of different source states — with an error instead of a GPU fault in the first launch."""
+    if not hasattr(L, "nxhip_check_library"):
+        raise NexusError(f"{LIB_PATH} predates the ABI stamp (no nxhip_check_library): rebuild it with `make`")
+    L.nxhip_check_library.argtypes = [C.c_uint64]
+    L.nxhip_abi_stamp.restype = C.c_uint64
+    L.nxhip_last_error.restype = C.c_char_p
+    rc = L.nxhip_check_library(abi_stamp() if stamp is None else stamp)
+    if rc != 0:
+        raise NexusError("%s: %s" % (LIB_PATH, (L.nxhip_last_error() or b"").decode()))
+
 _lib = None
 
 
@@ -83,6 +123,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NexusError(f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); there is no fallback path")
     L = C.CDLL(LIB_PATH)
+    check_library(L)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
     L.nxhip_last_error.restype = C.c_char_p
     L.nxhip_create.argtypes = [C.c_int, u32, u32, vp, C.POINTER(vp)]

@@ -232,4 +232,31 @@ struct DeviceState {
     NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
 };
 
+// What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
+// them.  Every .hip file exports the value it was compiled with (layout_stamp_<unit>()); nxhip_create compares them, so a
+// library linked from objects of different source states — host code filling a DeviceState the kernels read with other
+// offsets: a wild device access in the first launch — is refused with NXHIP_ERR_ABI instead.
+constexpr uint64_t layout_mix(uint64_t h, uint64_t v)
+{
+    for (int i = 0; i < 8; i++) { h = (h ^ (v & 0xffu)) * 0x100000001b3ull; v >>= 8; }
+    return h;
+}
+constexpr uint64_t layout_stamp()
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    const uint64_t w[] = {
+        sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
+        offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats),
+        sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
+        offsetof(RegionCounters, shadowHead), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
+        sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),
+        sizeof(TextureDev), sizeof(TraceQueue), sizeof(ShadowQueue), sizeof(MaterialQueue), sizeof(FrameState), sizeof(TraceStatsDev),
+        (uint64_t)kNodeStride, (uint64_t)kTriStride, (uint64_t)kQueueShards, (uint64_t)kQueueShardSlack, (uint64_t)kRegionStride, (uint64_t)kMaxBounceSlots,
+        (uint64_t)kEnvGuide, (uint64_t)kMaterialTypeOffset, sizeof(nx_material), sizeof(nx_bvh_instance), sizeof(nx_triangle), sizeof(nx_light), sizeof(nx_camera),
+    };
+    for (uint64_t v : w) h = layout_mix(h, v);
+    return h;
+}
+
 }  // namespace nxd

@@ -1239,4 +1239,7 @@ int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n,
     return NXHIP_OK;
 }
 
+// the device-side layouts this translation unit was compiled with (nx_device.h layout_stamp; compared by nxhip_create)
+uint64_t layout_stamp_lbvh() { return layout_stamp(); }
+
 }  // namespace nxd

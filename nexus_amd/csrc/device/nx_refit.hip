@@ -199,4 +199,7 @@ __global__ void __launch_bounds__(kRefitBlock) tlas_refit_kernel(nx_bvh8_node* n
 const void* instance_transform_kernel_ptr() { return (const void*)instance_transform_kernel; }
 const void* tlas_refit_kernel_ptr() { return (const void*)tlas_refit_kernel; }
 
+// the device-side layouts this translation unit was compiled with (nx_device.h layout_stamp; compared by nxhip_create)
+uint64_t layout_stamp_refit() { return layout_stamp(); }
+
 }  // namespace nxd

@@ -414,4 +414,7 @@ const void* trace_kernel_ptr(bool anyHit, bool stats)
     return stats ? (const void*)trace_kernel<false, true> : (const void*)trace_kernel<false, false>;
 }
 
+// the device-side layouts this translation unit was compiled with (nx_device.h layout_stamp; compared by nxhip_create)
+uint64_t layout_stamp_trace() { return layout_stamp(); }
+
 }  // namespace nxd

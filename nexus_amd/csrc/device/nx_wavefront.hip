@@ -928,4 +928,7 @@ const void* bsdf_hook_kernel_ptr() { return (const void*)bsdf_hook_kernel; }
 const void* tex2d_hook_kernel_ptr() { return (const void*)tex2d_hook_kernel; }
 const void* fmath_hook_kernel_ptr() { return (const void*)fmath_hook_kernel; }
 
+// the device-side layouts this translation unit was compiled with (nx_device.h layout_stamp; compared by nxhip_create)
+uint64_t layout_stamp_wavefront() { return layout_stamp(); }
+
 }  // namespace nxd

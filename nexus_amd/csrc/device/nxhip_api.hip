@@ -22,6 +22,11 @@ const void* begin_frame_kernel_ptr();
 const void* generate_kernel_ptr();
 const void* accumulate_kernel_ptr();
 const void* compose_kernel_ptr();
+uint64_t layout_stamp_trace();
+uint64_t layout_stamp_wavefront();
+uint64_t layout_stamp_refit();
+uint64_t layout_stamp_lbvh();
+uint64_t layout_stamp_multigpu();
 const void* bsdf_hook_kernel_ptr();
 const void* fmath_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
@@ -95,6 +100,42 @@ static int fail_invalid(const char* msg)
     return NXHIP_ERR_INVALID;
 }
 static int fail_invalid(const std::string& msg) { return fail_invalid(msg.c_str()); }
+
+// Every translation unit of this library must have been compiled with the same device-side layouts (nx_device.h layout_stamp):
+// the host code here fills DeviceState / Counters / InstTrav blocks that the kernels of the other units read.
+static int check_layouts()
+{
+    const struct { const char* unit; uint64_t stamp; } units[] = {
+        {"nx_trace.hip", layout_stamp_trace()}, {"nx_wavefront.hip", layout_stamp_wavefront()}, {"nx_refit.hip", layout_stamp_refit()},
+        {"nx_lbvh.hip", layout_stamp_lbvh()}, {"nxhip_multigpu.hip", layout_stamp_multigpu()},
+    };
+    for (const auto& u : units) {
+        if (u.stamp != layout_stamp()) {
+            char buf[320];
+            std::snprintf(buf, sizeof buf, "libnexus_amd.so was linked from objects of different source states: %s was compiled with device layout stamp %016llx, "
+                          "nxhip_api.hip with %016llx (DeviceState / Counters / record strides differ) - rebuild the library from one tree (make clean && make)",
+                          u.unit, (unsigned long long)u.stamp, (unsigned long long)layout_stamp());
+            set_error(buf);
+            return NXHIP_ERR_ABI;
+        }
+    }
+    return NXHIP_OK;
+}
+
+uint64_t nxhip_abi_stamp(void) { return nxhip_header_abi_stamp(); }
+
+int nxhip_check_library(uint64_t callerStamp)
+{
+    if (callerStamp != nxhip_abi_stamp()) {
+        char buf[320];
+        std::snprintf(buf, sizeof buf, "ABI mismatch: the caller was built against a nexus_hip.h / nexus_pod.h with stamp %016llx, this library (API version %d) has %016llx - "
+                      "a stale or foreign libnexus_amd.so (NEXUS_AMD_LIB, LD_LIBRARY_PATH), or bindings of another version",
+                      (unsigned long long)callerStamp, NXHIP_API_VERSION, (unsigned long long)nxhip_abi_stamp());
+        set_error(buf);
+        return NXHIP_ERR_ABI;
+    }
+    return check_layouts();
+}
 
 // slot k of the context: 0 is the context itself, k >= 1 the extra in-flight passes
 static PassSlot* slot_at(nxhip_ctx* c, uint32_t k) { return k == 0 ? static_cast<PassSlot*>(c) : c->extra[k - 1].get(); }
@@ -316,6 +357,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
     *out = nullptr;
     if (width == 0 || height == 0) return fail_invalid("nxhip_create: zero-sized viewport");
     if ((uint64_t)width * height > 0x7fffffffull) return fail_invalid("nxhip_create: more than 2^31 pixels");
+    if (const int rcLayouts = check_layouts()) return rcLayouts;  // a library of mixed objects is refused before anything is launched
     if (nxhip_device_count() <= device || device < 0) {
         set_error("nxhip_create: no such HIP device");
         return NXHIP_ERR_NO_DEVICE;

@@ -89,6 +89,9 @@ int nccl_ok(int rc, const char* what)
 }
 
 }  // namespace
+// the device-side layouts this translation unit was compiled with (nx_device.h layout_stamp; compared by nxhip_create)
+uint64_t layout_stamp_multigpu() { return layout_stamp(); }
+
 }  // namespace nxd
 
 using namespace nxd;

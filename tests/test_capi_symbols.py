@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header, prefix):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^static inline .*?^}", "", text, flags=re.S | re.M)  # header-only helpers (nxhip_header_abi_stamp) are not exports
     return sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text)))
 
 
@@ -41,3 +42,34 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f in ("nx_math.h",), "%s mentions the oracle" % os.path.join(dirpath, f)
+
+
+def test_a_stale_or_foreign_library_is_an_error_status_not_a_device_fault():
+    """a library whose idea of the structs differs from its caller's (round 3: a variant .so driven through
+    NEXUS_AMD_LIB faulted the GPU in its first launch, gpurun_out/r3_07) must be refused before anything is launched.  The
+    bindings hash the size and key offsets of every struct that crosses the boundary (capi.abi_words, mirroring
+    nxhip_header_abi_stamp in include/nexus_hip.h); the library compares and also checks that all of its own translation
+    units were compiled with the same device-side layouts."""
+    import ctypes as C
+
+    import pytest
+
+    lib = capi.lib()
+    assert lib.nxhip_abi_stamp() == capi.abi_stamp()          # the Python mirrors describe the structs the library was built with
+    assert lib.nxhip_check_library(capi.abi_stamp()) == 0      # ... and the library's translation units agree among themselves
+    # a caller with another idea of ONE struct (a 64-byte material instead of 60): refused, with a message that says what to do
+    words = capi.abi_words()
+    words[words.index(60)] = 64
+    assert lib.nxhip_check_library(capi.abi_stamp(words)) == 5  # NXHIP_ERR_ABI
+    msg = lib.nxhip_last_error().decode()
+    assert "ABI mismatch" in msg and "stale or foreign" in msg
+    with pytest.raises(capi.NexusError, match="ABI mismatch"):
+        capi.check_library(lib, stamp=capi.abi_stamp(words))
+    # another API version alone is enough
+    assert lib.nxhip_check_library(capi.abi_stamp([capi.API_VERSION + 1] + capi.abi_words()[1:])) == 5
+    # a library without the entry point (built before round 4) is refused by the bindings as well
+    class Old:
+        pass
+    with pytest.raises(capi.NexusError, match="predates"):
+        capi.check_library(Old())
+    assert C.sizeof(C.c_uint64) == 8
