@@ -389,8 +389,10 @@ def main():
 
         def sync():
             torch.cuda.synchronize()
+            t_local = time.perf_counter()  # this rank's own work (rank 0: including the tiles it waited for) is done
             dist.barrier()
             torch.cuda.synchronize()
+            return t_local
     else:
         if args.pixel_order == "tiles":
             ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
@@ -407,6 +409,9 @@ def main():
 
         def sync():
             ctx.sync()
+            return time.perf_counter()
+
+    per_rank_ms = {}  # label -> per repetition, every rank's own time to the end of its work (before the closing barrier)
 
     def measure(steps, warmup, reps, size, label):
         """`reps` timed regions of exactly `steps` frames (pass sizes: schedule(steps, size)), after `warmup` untimed frames in
@@ -427,12 +432,18 @@ def main():
             t0 = time.perf_counter()
             for n in schedule(steps, size):
                 step(n)
-            sync()
+            t_local = sync()
             dt = time.perf_counter() - t0
             if dist_mode:
                 t = torch.tensor([dt], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
+                # every rank's own figure goes to rank 0 as well, so that a bad scaling curve can be read from ONE run: which rank
+                # was slow, and whether the ranks finished together (load balance of the tile split) or the root waited
+                mine = torch.tensor([(t_local - t0) * 1e3], dtype=torch.float64, device="cuda")
+                everyone = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(everyone, mine)
+                per_rank_ms.setdefault(label, []).append([round(float(x.item()), 3) for x in everyone])
             out.append(dt)
             stamp("%s: repetition %d of %d: %.3f ms" % (label, k + 1, reps, dt * 1e3))
         return out
@@ -497,6 +508,15 @@ def main():
         },
     }
 
+    if dist_mode and per_rank_ms.get("timed region"):
+        rows = per_rank_ms["timed region"]
+        med = [round(statistics.median(r[k] for r in rows), 3) for k in range(world)]
+        out["config"]["per_rank"] = {
+            "what": "each rank's own time for the K-frame region, in ms: from the common start to the end of its own work (render, accumulate, its side of the "
+                    "gather; rank 0: including the tiles it waited for and the compose), before the closing barrier; `rep_ms` is the slowest rank + barrier",
+            "rep_ms_by_rank": rows, "median_ms_by_rank": med, "slowest_rank": int(max(range(world), key=lambda k: med[k])),
+            "spread": round(max(med) / max(1e-9, min(med)), 4),
+            "gather_bytes_per_rank_and_pass": int(n_local * 16), "backend": backend}
     if emulated:
         out["emulated_rank"] = emulated
     if obj_check:

@@ -1,0 +1,44 @@
+"""bench.py's N > 1 code path over the real RCCL backend, on the one GPU of the box.
+
+The driver's scaling run is `torch.distributed.run --nproc-per-node N bench.py --gpus N` with the "nccl" (= RCCL) backend:
+process group with a device id, one explicit torch stream carrying kernels and collective, a zero-copy torch view of the
+context's accumulation, `dist.gather` of device tensors, compose on the root.  VERDICT r3: that path had last been executed in
+round 1 and rewritten twice since; the 2-rank rehearsal forces gloo.  Here it runs as a fresh child process at world size 1
+(NX_BENCH_FORCE_DIST=1: same code, the gather degenerates to a copy) and its image must equal the plain run's byte for byte."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--frames-per-pass", "2", "--passes-in-flight", "2"]], ids=["one-pass", "passes-in-flight"])
+def test_bench_through_torchrun_and_rccl_renders_the_plain_image(tmp_path, extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NX_BENCH_BACKEND", None)
+    common = ["--steps", "5", "--warmup", "2", "--reps", "2", "--width", "256", "--height", "160", "--no-cpu-baseline", "--no-roofline", "--no-obj-check"] + extra
+    plain, rccl = str(tmp_path / "plain.png"), str(tmp_path / "rccl.png")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--png", plain], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + ["--png", rccl]
+    r = subprocess.run(cmd, env=dict(env, NX_BENCH_FORCE_DIST="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert open(plain, "rb").read() == open(rccl, "rb").read()
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    # the line of a distributed run says how every rank did, not only the slowest
+    pr = line["config"]["per_rank"]
+    assert pr["backend"] == "nccl" and len(pr["rep_ms_by_rank"]) == 2 and len(pr["median_ms_by_rank"]) == 1 and pr["slowest_rank"] == 0
+    assert pr["gather_bytes_per_rank_and_pass"] == 256 * 160 * 16
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0

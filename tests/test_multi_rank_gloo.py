@@ -69,3 +69,9 @@ def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert open(one, "rb").read() == open(two, "rb").read()
+    # a distributed run reports every rank's own time, gathered to rank 0 (a bad scaling curve must be readable from one run)
+    import json
+
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    pr = line["config"]["per_rank"]
+    assert len(pr["median_ms_by_rank"]) == 2 and pr["slowest_rank"] in (0, 1) and pr["backend"] == "gloo" and line["n_gpus"] == 2
