@@ -126,6 +126,10 @@ void orc_trace_closest(const orc_scene *s, const nx_ray *rays, uint32_t n, nx_hi
 void orc_trace_any(const orc_scene *s, const nx_ray *rays, const float *tmax, uint32_t n, uint8_t *occluded,
                    orc_trace_stats *stats);
 /* Same as orc_trace_closest, rays split over nthreads pthreads (cpu_baseline leg). */
+/* Step log for the lane-scheduling simulator (tools/lane_sim.py): while set (calling thread only), every traced ray appends the
+ * kinds of the records it visits — 1 node, 2 triangle, 3 instance entry — and a closing 0. */
+void orc_trace_set_step_log(uint8_t *buf, uint64_t cap);
+uint64_t orc_trace_step_log_length(void);
 void orc_trace_closest_mt(const orc_scene *s, const nx_ray *rays, uint32_t n, nx_hit *hits, int nthreads);
 
 /* Ground truth: every instance x every triangle with the reference's Moeller-Trumbore

@@ -140,6 +140,14 @@ static int tri_trace(const nx_triangle *tri, const ray_t *r, float *tBest, float
     return 0;
 }
 
+/* Optional step log (tools/lane_sim.py: what a wave's lanes would be doing under different loop policies).  Per traced ray the
+ * kinds of the records it visits, in visiting order — 1 node, 2 triangle, 3 instance entry — closed by a 0.  Off unless set. */
+static __thread uint8_t *g_stepLog = NULL;
+static __thread uint64_t g_stepLogCap = 0, g_stepLogLen = 0;
+void orc_trace_set_step_log(uint8_t *buf, uint64_t cap) { g_stepLog = buf; g_stepLogCap = cap; g_stepLogLen = 0; }
+uint64_t orc_trace_step_log_length(void) { return g_stepLogLen; }
+static inline void log_step(uint8_t kind) { if (g_stepLog && g_stepLogLen < g_stepLogCap) g_stepLog[g_stepLogLen++] = kind; }
+
 static int clz32(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 static int popc32(uint32_t x) { return __builtin_popcount(x); }
 
@@ -180,6 +188,7 @@ static int trace_one(const orc_scene *s, f3 org, f3 dir, int anyHit, float tmaxI
             nodeEntry.x = ie[0]; nodeEntry.y = ie[1];
             triangleEntry.x = te[0]; triangleEntry.y = te[1];
             nNodes++;
+            log_step(1);
         } else {
             triangleEntry = nodeEntry;
             nodeEntry.x = 0; nodeEntry.y = 0;
@@ -204,12 +213,14 @@ static int trace_one(const orc_scene *s, f3 org, f3 dir, int anyHit, float tmaxI
                 ray.direction = mat_vec(&inst->invTransform, ray.direction);
                 ray.invDirection = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
                 nInst++;
+                log_step(3);
                 break;
             }
             const int triangleOffset = 31 - clz32(triangleEntry.y);
             triangleEntry.y &= ~(1u << triangleOffset);
             const uint32_t triangleIdx = bvh->triIdx[triangleEntry.x + (uint32_t)triangleOffset];
             nTris++;
+            log_step(2);
             if (anyHit) {
                 float t = hitDistance, u, v; /* ShadowTrace: t > 0 && t < hitDistance, Triangle.cuh:89-118 */
                 if (tri_trace(&bvh->tris[triangleIdx], &ray, &t, &u, &v)) { occluded = 1; break; }
@@ -233,6 +244,7 @@ static int trace_one(const orc_scene *s, f3 org, f3 dir, int anyHit, float tmaxI
             nodeEntry = stack[--stackPtr];
         }
     }
+    log_step(0);
     if (hit) {
         hit->hitDistance = hitDistance;
         hit->u = hu; hit->v = hv;
