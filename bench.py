@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--no-obj-check", action="store_true", help="config 2: skip the .obj round trip.  By default the mesh is written as a Wavefront .obj, read back with the "
                                                                 "product's OBJLoader and required to equal the in-memory triangles the BVH was built from (untimed, ~16 s; "
                                                                 "configs[1] says 'single 1M-triangle .obj mesh')")
+    ap.add_argument("--no-reference-mode", action="store_true",
+                    help="skip the second measurement: the same timed region with the REFERENCE's semantics — random numbers keyed by queue slot, slots handed out in "
+                         "serial order (grid-wide ordered compaction), no conductor kernel — reported as config.reference_mode beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -481,6 +484,26 @@ def main():
         ctx.set_frames_per_pass(S)
         ctx.set_passes_in_flight(max(R, 1))
 
+    # ---- the same region with the reference's own semantics (PathTracer.cu:143, 326, 475-478; Random.cuh:79-82): the headline
+    # runs pixel-keyed random numbers, racing slot allocation and the extended conductor kernel; these two lines say what the
+    # serial slot order costs on the whole chip (`ordered`: same work as the headline) and what the reference's exact
+    # configuration renders at (`reference`: conductor hits end unshaded, as the reference's commented-out kernel leaves them)
+    reference_mode = None
+    if not args.no_reference_mode and not dist_mode:
+        reference_mode = {"what": "the timed region again (median of 3 repetitions) with random numbers keyed by queue slot and slots in the reference's serial order "
+                                  "(NX_RNG_REFERENCE_SLOT, NX_COMPACT_ORDERED: tiles by ticket + decoupled look-back on all CUs); `reference` also drops the conductor kernel "
+                                  "(NX_CONDUCTOR_REFERENCE), i.e. less work per frame than the headline; `ordered` keeps it (same work)"}
+        for key, conductor in (("ordered", pod.CONDUCTOR_EXTENDED), ("reference", pod.CONDUCTOR_REFERENCE)):
+            sync()
+            ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, conductor)
+            rs = measure(args.steps, min(args.warmup, S), 3, S, "%s mode" % key)
+            med = statistics.median(rs)
+            reference_mode[key] = {"value": round(W * H * args.steps / med / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(med / args.steps * 1e3, 4),
+                                   "rep_ms": [round(x * 1e3, 3) for x in rs], "vs_headline": round(elapsed / med, 4)}
+        sync()
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+        ctx.reset_frame_number()
+
     value = W * H * args.steps / elapsed / 1e6
     out = {
         "metric": "Msamples/sec (rays traced/sec) at 1080p, 8-bounce, 1M-tri BVH8; 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
@@ -499,7 +522,7 @@ def main():
             "workload": workload_name,
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, per-rank accumulation, one RCCL gather of accumulated tiles per pass" % (world, TILE_ROWS),
             "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of up to %d frames" % S,
-            "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order,
+            "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
             "pass_sizes": schedule(args.steps), "frames_rendered_by_the_timed_loop": frames_rendered[0],
@@ -517,6 +540,8 @@ def main():
             "rep_ms_by_rank": rows, "median_ms_by_rank": med, "slowest_rank": int(max(range(world), key=lambda k: med[k])),
             "spread": round(max(med) / max(1e-9, min(med)), 4),
             "gather_bytes_per_rank_and_pass": int(n_local * 16), "backend": backend}
+    if reference_mode:
+        out["config"]["reference_mode"] = reference_mode
     if emulated:
         out["emulated_rank"] = emulated
     if obj_check:

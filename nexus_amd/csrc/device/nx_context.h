@@ -77,6 +77,8 @@ struct PassSlot {
     DevBuf shRayO, shRayD, shRadiance;
     DevBuf mqHit[4], mqDirInst[4], mqTp[4];
     DevBuf counters, frame, dState;
+    DevBuf scanStatus;        // ordered compaction: tile status words (allocated with the queues)
+    uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
     size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
     // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in
     // nxhip_api.hip: a small pass, a large pass and a pass among several in flight are different graphs).  A pass of another

@@ -57,6 +57,8 @@ static_assert(sizeof(nx_material) == 60 && offsetof(nx_material, type) == kMater
 constexpr int kEnvGuide = 64;   // buckets of the environment sampler's cdf search guides
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxBounceSlots = NX_PATH_MAX_LENGTH;
+constexpr int kScanKinds = 5;   // kernels that hand out queue slots: logic + the four material kernels
+constexpr int kScanWords = 4;   // status words per tile of such a kernel: one per queue it appends to (logic 4, material 2)
 
 struct BlasDev {
     const NX_G uint4* nodes;
@@ -151,10 +153,12 @@ constexpr int kRegionStride = (int)(sizeof(RegionCounters) / sizeof(int32_t));  
 
 struct Counters {
     RegionCounters region[kQueueShards];
-    // ordered-compaction running bases (single-workgroup mode)
-    int32_t orderedBase[8];
+    int32_t orderedBase[8];  // (unused since the ordered compaction became grid-wide; kept so that the words behind it stay where they were)
     int32_t tailHead;      // paths of the tail kernel's queue handed out so far
     int32_t pad_[3];
+    // ordered compaction (nx_wavefront.hip OrderedScan): tiles of a logic / material launch handed out so far, one word per
+    // launch of a pass — kernel kind (0 logic, 1 + NX_MAT_* material) x bounce
+    int32_t scanTicket[kScanKinds][kMaxBounceSlots];
 };
 
 struct FrameState {
@@ -162,8 +166,15 @@ struct FrameState {
     int32_t pixelQueryPixel;     // -1: none (D_PixelQuery, PathTracer.cuh:54-58)
     int32_t pixelQueryInstance;
     uint32_t errorWord;          // kErrTraversalStalled: set by a trace kernel that abandoned rays (see kStallLimit), read and cleared by nxhip_sync
+    uint32_t scanEpoch;          // number of this pass among the passes of its slot (begin_frame_kernel's argument): tags the tile status words of the ordered compaction
+    uint32_t pad_[3];
 };
 constexpr uint32_t kErrTraversalStalled = 1u;
+constexpr uint32_t kErrScanStalled = 2u;  // a workgroup of the ordered compaction gave up waiting for a predecessor tile (never seen; the guard turns a hang into a status)
+// Ordered compaction, status word of a tile and queue: {tag = launch serial << 2 | state, value}.  The launch serial (pass epoch,
+// bounce, kernel kind) makes words of earlier launches read as "not there yet", so the array is never cleared between launches.
+constexpr uint32_t kScanEpochLimit = 1u << 20;  // pass epochs 1 .. limit - 1; the host clears the status arrays when it wraps
+constexpr uint32_t kScanAggregate = 1u, kScanPrefix = 2u;
 // A wave of a trace kernel that has stayed in its traversal loop for this many iterations (about a second) without coming
 // through its refill point — i.e. with rays that do not finish — gives up on them:
 // the rays end as misses / unoccluded, the error word is set and nxhip_sync reports NXHIP_ERR_TRAVERSAL.  A ray of a well-formed
@@ -230,6 +241,7 @@ struct DeviceState {
     NX_G Counters* counters;
     NX_G FrameState* frame;
     NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
+    NX_G unsigned long long* scanStatus;  // [tiles of the largest queue][kScanWords]: ordered compaction (nx_wavefront.hip OrderedScan)
 };
 
 // What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
@@ -247,7 +259,8 @@ constexpr uint64_t layout_stamp()
     const uint64_t w[] = {
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
-        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
+        (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
         sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),

@@ -69,6 +69,13 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 #pragma unroll
     for (int k = 0; k < kXcds; k++) size += regionRays[k * kRegionStride];
     if (size <= 0) return;
+    // The eight fetch heads walk one SHARD of the queue each: the queue's regions — or, when the queue is kept in one region
+    // (ordered compaction: the reference's serial slot order), eight 64-aligned pieces of it, so that such a pass still runs on
+    // all eight XCDs (until round 4 it ran on the one whose workgroups call region 0 home).
+    const bool oneRegion = S->queueShards == 1u;
+    const int piece = (int)dense_piece((uint32_t)size, (uint32_t)kXcds);
+    const auto shard_begin = [&](const int k) { return oneRegion ? k * piece : k * cap; };
+    const auto shard_rays = [&](const int k) { return oneRegion ? max(0, min(piece, size - k * piece)) : (int)regionRays[k * kRegionStride]; };
     NX_G int* heads = ANY_HIT ? &C->region[0].shadowHead[bounce] : &C->region[0].traceHead[bounce];
     GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
     GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     const int homeShard = blockIdx.x & (kXcds - 1);
-    const int homeRays = regionRays[homeShard * kRegionStride];
+    const int homeRays = shard_rays(homeShard);
     // this wave's rank among the waves that call this shard home
     const int rankInShard = (int)(blockIdx.x >> 3) * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
     // A wave the queue does not need leaves without touching a fetch head.  The grid is sized for the largest queue; on a
@@ -162,8 +169,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     if (exhausted) break;
                     // one returning atomic reserves kReserve rays of `shard` (the head counts rays handed out)
                     const int leader = __ffsll((long long)needMask) - 1;
-                    const int shardBegin = shard * cap;
-                    const int shardEnd = shardBegin + regionRays[shard * kRegionStride];
+                    const int shardBegin = shard_begin(shard);
+                    const int shardEnd = shardBegin + shard_rays(shard);
                     int base = 0;
                     if (lane == leader) base = atomicAdd(&heads[shard * kRegionStride], reserve);
                     base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
@@ -176,7 +183,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         int left = 0;
                         if (lane < kXcds) {
                             const int taken = __hip_atomic_load(&heads[lane * kRegionStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            left = max(0, regionRays[lane * kRegionStride] - taken);
+                            left = max(0, shard_rays(lane) - taken);
                         }
                         int best = 0, bestLeft = 0;
 #pragma unroll

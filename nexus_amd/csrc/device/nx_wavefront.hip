@@ -6,10 +6,10 @@
 //   * persistent grid-stride launches (<= 2048 workgroups of 256) instead of N/64+1 blocks that mostly exit:
 //     late bounces with few live paths cost a launch, not tens of thousands of empty workgroups;
 //   * float4-packed SoA queues: every lane moves 16 B per access, fully coalesced;
-//   * queue slots are handed out once per wave (ballot + popcount rank + one atomic) — NX_COMPACT_FAST — or by an
-//     ordered block-wide scan in a single 1024-thread workgroup — NX_COMPACT_ORDERED, which reproduces the
-//     reference's serial slot order exactly (ascending thread index, material kernels in graph order) and is
-//     what the parity tests use; the shading math is the same code in both modes;
+//   * queue slots are handed out once per workgroup (ballots + popcount ranks + one atomic) — NX_COMPACT_FAST — or by a
+//     grid-wide ordered scan (tiles by ticket, decoupled look-back) — NX_COMPACT_ORDERED, which reproduces the
+//     reference's serial slot order exactly (ascending thread index, material kernels in graph order) on all CUs and
+//     is what the parity tests use; the shading math is the same code in both modes;
 //   * a path's shadow-ray and continuation-ray payloads are built in registers and written after the slot
 //     allocation, outside divergent control flow;
 //   * the frame number lives on the device and is advanced by begin_frame_kernel, so a frame is one
@@ -33,50 +33,130 @@ constexpr int kWideBlock = 256;     // generate / accumulate
 #endif
 constexpr int kLogicBlock = NX_LOGIC_BLOCK;   // one slot atomic per block-sized tile of items
 constexpr int kShadeBlock = NX_SHADE_BLOCK;
-constexpr int kOrderedBlock = 1024;  // single-workgroup ordered mode
 
 // ------------------------------------------------------------------------------------------------------
 // slot allocation: K queues at once, one round of workgroup-wide cooperation per tile.
 //   FAST    : per-wave ballots -> per-workgroup totals in LDS -> ONE atomicAdd per workgroup and counter (a single
 //             global counter sustains only ~88 returning atomics per microsecond on MI355X, so per-wave atomics
-//             serialise a 2M-item pass; per-workgroup ones do not).
-//   ORDERED : a single workgroup whose running bases live in LDS; slots follow ascending item index, i.e. the
-//             reference's serial order.
+//             serialise a 2M-item pass; per-workgroup ones do not).  Slot order = order of the atomics: racy, like the
+//             reference's per-thread atomicAdd (PathTracer.cu:143, 326).
+//   ORDERED : the reference's SERIAL slot order — ascending item index within a kernel, the material kernels of a bounce
+//             continuing each other's queues in graph order (PathTracer.cpp:114-124) — on the whole chip.  Tiles are handed
+//             out by ticket (so a tile's predecessors are always held by running workgroups), and a tile's base slot is the
+//             sum of its predecessors' counts, found by decoupled look-back: every tile publishes its count, then reads
+//             the status words of the tiles before it 64 at a time until it meets one that already knows its inclusive
+//             prefix, and publishes its own.  Tile 0 starts from the counter word (what the previous kernel of the chain
+//             left there), the last tile stores the new total.  Round 1-3 did this in ONE 1024-thread workgroup.
 // Must be called by every thread of the workgroup (uniform control flow).
 
-constexpr int kMaxWavesPerBlock = kOrderedBlock / kWave;
+constexpr int kMaxWavesPerBlock = 1024 / kWave;
+
+NXD unsigned long long scan_word(uint32_t serial, uint32_t state, int value) { return ((unsigned long long)((serial << 2) | state) << 32) | (unsigned long long)(uint32_t)value; }
+NXD int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 template <bool ORDERED, int K>
 struct SlotAllocator {
     int* sWave;  // [K][kMaxWavesPerBlock] per-wave counts of the current tile
     int* sBase;  // [K] base slot of the current tile
-    int* sRun;   // [K] ORDERED: running bases
-    int* counters[K];
+    int* sTile;  // ORDERED: the ticket of the current tile
+    int* counter0;  // the K counter words are counter0 + k * counterStep (an address computation, not an array of pointers: an
+    int counterStep;  // array indexed by anything but a constant makes the allocator a private-memory object in LDS or scratch)
+    NX_G unsigned long long* status;  // ORDERED: tile status words, [tile][kScanWords]
+    NX_G int* ticket;
+    NX_G FrameState* frame;
+    uint32_t serial;
+    int size, lastTile;
 
-    NXD void init(int* const (&ctr)[K])
+    // `kind`: 0 logic, 1 + NX_MAT_* material kernel; `items`: size of the launch's input queue
+    NXD void init(const DeviceState* S, int* const first, const int step, const int kind, const int bounce, const int items)
     {
         __shared__ int wave[K * kMaxWavesPerBlock];
         __shared__ int base[K];
-        __shared__ int run[K];
+        __shared__ int tile;
         sWave = wave;
         sBase = base;
-        sRun = run;
-#pragma unroll
-        for (int k = 0; k < K; k++) counters[k] = ctr[k];
+        sTile = &tile;
+        counter0 = first;
+        counterStep = step;
+        size = items;
+        lastTile = (items + (int)blockDim.x - 1) / (int)blockDim.x - 1;
         if (ORDERED) {
-            if (threadIdx.x < K) run[threadIdx.x] = *ctr[threadIdx.x];
+            status = S->scanStatus;
+            ticket = &S->counters->scanTicket[kind][bounce];
+            frame = S->frame;
+            serial = S->frame->scanEpoch * 1024u + (uint32_t)bounce * 8u + (uint32_t)kind;
         }
-        __syncthreads();
     }
-    NXD void finish()
+    NXD int* counter_of(const int k) const
     {
-        __syncthreads();
-        if (ORDERED) {
-            if (threadIdx.x < K) *counters[threadIdx.x] = sRun[threadIdx.x];
-        }
+        return counter0 + k * counterStep;
     }
-    // `region`: the queue region this tile appends to (uniform over the workgroup); counters[] point at region 0's words
-    NXD void alloc(const bool (&want)[K], int (&slot)[K], const int region = 0)
+    // first item of the workgroup's first / next tile (>= size: none left)
+    NXD int first_tile() { return ORDERED ? take() : (int)(blockIdx.x * blockDim.x); }
+    NXD int next_tile(const int tile) { return ORDERED ? take() : tile + (int)(gridDim.x * blockDim.x); }
+    NXD int take()
+    {
+        __syncthreads();  // the previous tile's readers are done with sTile
+        if (threadIdx.x == 0) *sTile = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int t = *sTile;
+        return t > lastTile ? size : t * (int)blockDim.x;
+    }
+
+    // ORDERED, one wave per queue: the slots taken by all tiles before tile t of this launch (and by the kernels before it in
+    // the chain), and this tile's count published for its successors
+    NXD int look_back(const int k, const int t, const int total)
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        NX_G unsigned long long* const st = status + k;
+        if (t == 0) {
+            const int base = *counter_of(k);
+            if (lane == 0) __hip_atomic_store(&st[0], scan_word(serial, kScanPrefix, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return base;
+        }
+        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanAggregate, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0, nearest = t - 1;
+        uint32_t spins = 0u;
+        for (;;) {
+            const int j = nearest - lane;  // lane 0 looks at the nearest predecessor not summed yet
+            uint32_t tag = (serial << 2) | kScanPrefix;  // (tiles "before tile 0" never decide: tile 0 itself is a prefix)
+            int value = 0;
+            if (j >= 0) {
+                const unsigned long long w = __hip_atomic_load(&st[(size_t)j * kScanWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tag = (uint32_t)(w >> 32);
+                value = (int)(uint32_t)w;
+            }
+            const bool ready = (tag >> 2) == serial && (tag & 3u) != 0u;
+            const unsigned long long notReady = __ballot(!ready), prefixes = __ballot(ready && (tag & 3u) == kScanPrefix);
+            const int firstNot = notReady ? __ffsll((long long)notReady) - 1 : kWave;
+            const int firstPrefix = prefixes ? __ffsll((long long)prefixes) - 1 : kWave;
+            if (firstPrefix < firstNot) {  // every tile between here and a known prefix has published its count
+                excl += wave_sum(lane <= firstPrefix ? value : 0);
+                break;
+            }
+            // counts in front of the first tile that has not published yet are final: take them, then look again from there
+            excl += wave_sum(lane < firstNot ? value : 0);
+            nearest -= firstNot;
+            if (firstNot < kWave) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 20)) {  // (about a second; see kErrScanStalled)
+                    if (lane == 0) atomicOr(&frame->errorWord, kErrScanStalled);
+                    break;
+                }
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanPrefix, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return excl;
+    }
+
+    // `tile`: first item of the tile (what first_tile / next_tile returned); `region`: the queue region this tile appends to
+    // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words
+    NXD void alloc(const bool (&want)[K], int (&slot)[K], const int tile, const int region = 0)
     {
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
         const int nWaves = blockDim.x / kWave;
@@ -88,22 +168,27 @@ struct SlotAllocator {
             if (lane == 0) sWave[k * kMaxWavesPerBlock + wave] = __popcll(mask[k]);
         }
         __syncthreads();
-        if (threadIdx.x < K) {
+        if (ORDERED) {
+            if (wave < K) {  // (a workgroup has at least K waves: 256 threads, K <= 4)
+                const int total = wave_sum(lane < nWaves ? sWave[wave * kMaxWavesPerBlock + lane] : 0);
+                const int t = tile / (int)blockDim.x;
+                const int excl = look_back(wave, t, total);
+                if (lane == 0) {
+                    sBase[wave] = excl;
+                    if (t == lastTile) *counter_of(wave) = excl + total;
+                }
+            }
+        } else if (threadIdx.x < K) {
             int total = 0;
             for (int w = 0; w < nWaves; w++) total += sWave[threadIdx.x * kMaxWavesPerBlock + w];
-            if (ORDERED) {
-                sBase[threadIdx.x] = sRun[threadIdx.x];
-                sRun[threadIdx.x] += total;
-            } else {
-                int* const word = counters[threadIdx.x] + region * kRegionStride;
-                sBase[threadIdx.x] = total ? atomicAdd(word, total) : 0;
+            int* const word = counter_of((int)threadIdx.x) + region * kRegionStride;
+            sBase[threadIdx.x] = total ? atomicAdd(word, total) : 0;
 #ifdef NX_EXTRA_ATOMICS
-                // experiment: are the logic / material kernels bound by the returning atomics on their queue
-                // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
-                for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
-                    if (total && atomicAdd(word, 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
+            // experiment: are the logic / material kernels bound by the returning atomics on their queue
+            // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
+            for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
+                if (total && atomicAdd(word, 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
 #endif
-            }
         }
         __syncthreads();
 #pragma unroll
@@ -142,7 +227,7 @@ NXD uint32_t seed_for(const DeviceState* S, uint32_t slot, uint32_t pathIdx, uin
 // every counter, traceSize[0] = localCount * frames (GenerateKernel's thread 0 in the reference, PathTracer.cu:112-113; the
 // memset of PathTracer.cpp:263; the frame counter of PathTracer.cpp:250).
 
-__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __restrict__ S, const uint32_t frames, const uint32_t frameLast)
+__global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __restrict__ S, const uint32_t frames, const uint32_t frameLast, const uint32_t scanEpoch)
 {
     int* c = reinterpret_cast<int*>(S->counters);
     constexpr int n = (int)(sizeof(Counters) / sizeof(int));
@@ -152,6 +237,7 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __
         S->framesPerPass = frames;
         S->pathCount = S->localCount * frames;
         S->frame->frameNumber = frameLast;
+        S->frame->scanEpoch = scanEpoch;
     }
     if (threadIdx.x < kQueueShards) {
         // the primary rays: path i goes to region i / piece (generate_kernel)
@@ -329,7 +415,7 @@ template <bool ORDERED>
 #ifndef NX_LOGIC_WAVES
 #define NX_LOGIC_WAVES 8
 #endif
-__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGIC_WAVES) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
@@ -339,12 +425,10 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
     if ((int)(blockIdx.x * blockDim.x) >= size) return;
     const uint32_t frame = S->frame->frameNumber;
     SlotAllocator<ORDERED, 4> slots;
-    RegionCounters* const rc = &C->region[0];
-    int* const ctr[4] = {&rc->materialSize[0][bounce], &rc->materialSize[1][bounce], &rc->materialSize[2][bounce], &rc->materialSize[3][bounce]};
-    slots.init(ctr);
+    // queue k of this kernel: the material queue of type k
+    slots.init(S, &C->region[0].materialSize[0][bounce], kMaxBounceSlots, 0, bounce, size);
     const ProducerRegions out = producer_regions(S, size, (int)blockDim.x);
-    const int stride = gridDim.x * blockDim.x;
-    for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
+    for (int tile = slots.first_tile(); tile < size; tile = slots.next_tile(tile)) {
         const int index = tile + (int)threadIdx.x;
         int type = -1;
         float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0), tpOut = make_float4(0, 0, 0, 0);
@@ -380,7 +464,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
         const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
         int slot[4];
         const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
-        slots.alloc(want, slot, region);
+        slots.alloc(want, slot, tile, region);
         if (type >= 0) {
             const MaterialQueue mq = S->material[type];
             const int sl = regionBase + (type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3])));
@@ -391,7 +475,6 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kLogicBlock, NX_LOGI
             if (bounce != 1) mq.tp[sl] = tpOut;  // the path's throughput after Russian roulette and its last pdf go with it
         }
     }
-    slots.finish();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -595,7 +678,7 @@ template <int TYPE, bool ORDERED>
 #ifndef NX_SHADE_WAVES
 #define NX_SHADE_WAVES 5
 #endif
-__global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].materialSize[TYPE][bounce], S->queueShardCap);
@@ -604,11 +687,10 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
     const uint32_t frame = S->frame->frameNumber;
     const MaterialQueue mq = S->material[TYPE];
     SlotAllocator<ORDERED, 2> slots;  // 0: shadow requests, 1: continuation rays
-    int* const ctr[2] = {&C->region[0].traceShadowSize[bounce], &C->region[0].traceSize[bounce]};
-    slots.init(ctr);
+    static_assert(offsetof(RegionCounters, traceSize) + kMaxBounceSlots * sizeof(int32_t) == offsetof(RegionCounters, traceShadowSize), "traceShadowSize follows traceSize");
+    slots.init(S, &C->region[0].traceShadowSize[bounce], -kMaxBounceSlots, 1 + TYPE, bounce, size);
     const ProducerRegions out = producer_regions(S, size, (int)blockDim.x);
-    const int stride = gridDim.x * blockDim.x;
-    for (int tile = blockIdx.x * blockDim.x; tile < size; tile += stride) {
+    for (int tile = slots.first_tile(); tile < size; tile = slots.next_tile(tile)) {
         const int requestIdx = tile + (int)threadIdx.x;
         bool wantShadow = false, wantTrace = false, updatePath = false;
         ShadowPayload sh;
@@ -641,7 +723,7 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
         const bool want[2] = {wantShadow, wantTrace};
         int slot[2];
         const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
-        slots.alloc(want, slot, region);
+        slots.alloc(want, slot, tile, region);
         const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
@@ -656,7 +738,6 @@ __global__ void __launch_bounds__(ORDERED ? kOrderedBlock : kShadeBlock, NX_SHAD
             S->trace.tp[traceSlot] = updatePath ? make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf) : tpdf;
         }
     }
-    slots.finish();
 }
 
 // ------------------------------------------------------------------------------------------------------

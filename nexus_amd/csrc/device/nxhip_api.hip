@@ -72,7 +72,6 @@ constexpr int kWideBlockThreads = 256;
 #endif
 constexpr int kLogicBlockThreads = NX_LOGIC_BLOCK;
 constexpr int kShadeBlockThreads = NX_SHADE_BLOCK;
-constexpr int kOrderedBlockThreads = 1024;
 constexpr int kHookBounceSlot = NX_PATH_MAX_LENGTH - 1;  // queue-size slot used by the batch test hooks
 
 }  // namespace nxd
@@ -181,6 +180,7 @@ static void invalidate_graph(nxhip_ctx* c)
 // may run over it; a queue buffer holds kQueueShards regions.
 static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) / (kQueueShards * 64)) * 64 + kQueueShardSlack; }
 static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
+static size_t scan_status_tiles(size_t n) { return n / (size_t)std::min(kLogicBlockThreads, kShadeBlockThreads) + 2; }
 
 // The device-state block of a slot: the scene part of the host mirror plus the slot's own queues, counters and frame words.
 static void compose_view(nxhip_ctx* c, PassSlot* s)
@@ -196,7 +196,8 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     }
     v.counters = s->counters.as<Counters>();
     v.frame = s->frame.as<FrameState>();
-    // queue regions: eight, or one spanning the buffer when a single workgroup hands out slots in the reference's serial order
+    v.scanStatus = s->scanStatus.as<unsigned long long>();
+    // queue regions: eight, or one spanning the buffer when slots are handed out in the reference's serial order
     const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
     v.queueShards = ordered ? 1u : (uint32_t)kQueueShards;
     v.queueShardCap = (uint32_t)(ordered ? queue_buffer_slots(c->queueCapacity) : queue_region_cap(c->queueCapacity));
@@ -230,10 +231,18 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     DevBuf fresh[kCount];
     for (int i = 0; i < kCount; i++)  // the first two are per path, the rest are queues (regions + slack)
         if (!fresh[i].alloc((i < 2 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    // ordered compaction: status words of the tiles of the largest possible launch (a queue never holds more than n items;
+    // tiles of the smaller of the two workgroup sizes), zeroed once — tag 0 is never a launch's serial
+    DevBuf freshStatus;
+    const size_t statusBytes = scan_status_tiles(n) * kScanWords * sizeof(unsigned long long);
+    if (!freshStatus.alloc(statusBytes)) return NXHIP_ERR_HIP;
+    NX_HIP(hipMemset(freshStatus.p, 0, statusBytes));
     NX_HIP(hipMemset(fresh[0].p, 0, n * 16));  // radiance
     NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
+    q->scanStatus = std::move(freshStatus);
+    q->scanEpoch = 0;
     q->pathCapacity = n;
     if (q == static_cast<PassSlot*>(c)) {
         c->radianceBoundCapacity = 0;
@@ -255,6 +264,7 @@ static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
                             &q->mqHit[0], &q->mqDirInst[0], &q->mqTp[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqTp[1], &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2],
                             &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3]};
     for (DevBuf* b : bufs) b->release();
+    q->scanStatus.release();
     q->pathCapacity = 0;
     if (q == static_cast<PassSlot*>(c)) {
         DeviceState& h = c->h;
@@ -383,7 +393,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             !c->traceStats.alloc(2 * sizeof(TraceStatsDev)) || !c->srgbLut.alloc(256 * sizeof(float))) { rc = NXHIP_ERR_HIP; break; }
         (void)hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream);
         (void)hipMemsetAsync(c->traceStats.p, 0, 2 * sizeof(TraceStatsDev), c->stream);
-        FrameState fs{0u, -1, -1, 0u};
+        FrameState fs{0u, -1, -1, 0u, 0u, {0u, 0u, 0u}};
         (void)hipMemcpyAsync(c->frame.p, &fs, sizeof fs, hipMemcpyHostToDevice, c->stream);
         float lut[256];
         for (int i = 0; i < 256; i++) {
@@ -492,6 +502,10 @@ static int check_device_errors(nxhip_ctx* c)
             NX_HIP(hipMemcpy(word, &zero, 4, hipMemcpyHostToDevice));
         }
         any |= w;
+    }
+    if (any & kErrScanStalled) {
+        set_error("a workgroup of the ordered compaction gave up waiting for the tile before it (internal error)");
+        return NXHIP_ERR_HIP;
     }
     if (any & kErrTraversalStalled) {
         set_error("a trace kernel abandoned rays that made no progress for millions of iterations: the uploaded or device-built BVH is not a tree");
@@ -1299,7 +1313,14 @@ Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceS
 int launch_begin_frame(nxhip_ctx* c, PassSlot* q, uint32_t frames, uint32_t frameLast)
 {
     DeviceState* S = q->dState.as<DeviceState>();
-    void* args[3] = {(void*)&S, (void*)&frames, (void*)&frameLast};
+    // the pass's number among the passes of this slot tags the tile status words of the ordered compaction (nx_device.h
+    // kScanEpochLimit); when it wraps, the words of the previous round of numbers are cleared, in stream order
+    if (++q->scanEpoch >= kScanEpochLimit) {
+        if (q->scanStatus.p) NX_HIP(hipMemsetAsync(q->scanStatus.p, 0, q->scanStatus.bytes, q->stream));
+        q->scanEpoch = 1;
+    }
+    const uint32_t epoch = q->scanEpoch;
+    void* args[4] = {(void*)&S, (void*)&frames, (void*)&frameLast, (void*)&epoch};
     NX_HIP(hipLaunchKernel(begin_frame_kernel_ptr(), dim3(1), dim3(kWideBlockThreads), args, 0, q->stream));
     (void)c;
     return NXHIP_OK;
@@ -1388,8 +1409,9 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     // (grids of the producer kernels stay multiples of the queue regions: harmless, and what a round-robin tile-to-region mapping
     //  would need)
     auto whole_regions = [](int g) { return (g + kQueueShards - 1) / kQueueShards * kQueueShards; };
-    const int og = ordered ? 1 : whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = ordered ? kOrderedBlockThreads : kShadeBlockThreads;
-    const int lg = ordered ? 1 : whole_regions(c->logicBlocksPerCU * c->numCUs), lb = ordered ? kOrderedBlockThreads : kLogicBlockThreads;
+    // (ordered compaction: the same grids — tiles are handed out by ticket and their slots found by look-back, nx_wavefront.hip)
+    const int og = whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = kShadeBlockThreads;
+    const int lg = whole_regions(c->logicBlocksPerCU * c->numCUs), lb = kLogicBlockThreads;
     const int tailFrom = tail_bounce(c);
     for (int bounce = 1; bounce <= pathLength; bounce++) {
         if (bounce == tailFrom) {  // the rest of the pass in one launch
@@ -1695,7 +1717,7 @@ try {
             return NXHIP_ERR_HIP;
         }
         NX_HIP(hipMemset(q->counters.p, 0, sizeof(Counters)));
-        FrameState fs{0u, -1, -1, 0u};
+        FrameState fs{0u, -1, -1, 0u, 0u, {0u, 0u, 0u}};
         NX_HIP(hipMemcpy(q->frame.p, &fs, sizeof fs, hipMemcpyHostToDevice));
         c->extra.push_back(std::move(q));  // (its queues are allocated when it first renders: ensure_slot_queues)
     }

@@ -84,6 +84,39 @@ def test_config2_one_million_triangles_1080p(gpu_ctx_factory):
     _check_frames(ctx, scene, W, H, n_pixels=16384, frames=2)
 
 
+def test_config2_reference_semantics_on_the_whole_chip(gpu_ctx_factory):
+    """configs[1] with the reference's own semantics — random numbers keyed by queue slot, slots in serial order, no conductor
+    kernel (PathTracer.cu:143, 326, 475-478; Random.cuh:79-82) — at full size: 2 M paths are some 8 000 tiles of the
+    grid-wide ordered compaction (tickets + decoupled look-back, nx_wavefront.hip), every one of whose slots decides which
+    random numbers a path draws next.  The oracle renders the whole frame serially; radiance and every queue size of every
+    bounce must be equal."""
+    W, H = 1920, 1080
+    scene = CS.config2(W, H)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, pod.CONDUCTOR_REFERENCE)
+    ctx.set_tail_bounce(0)
+    w = O.Wavefront(scene.oracle(), W * H, None, pod.RNG_REFERENCE_SLOT, pod.CONDUCTOR_REFERENCE)
+    ctx.reset_frame_number()
+    for f in (1, 2):
+        ctx.render_frame()
+        ctx.accumulate()
+        w.render(f, threads=8)
+        w.accumulate(f)
+        assert SH.frames_identical(ctx.read_radiance(), w.radiance(), "reference semantics, 1080p frame %d" % f)
+        assert SH.queue_sizes_identical(ctx.read_queue_sizes(), w.queue_sizes(), int(scene.settings["pathLength"]) + 2)
+    assert np.array_equal(ctx.read_rgba8(), w.rgba8())
+    # extended conductor, still slot-keyed and ordered: the material kernels now chain through four queues' worth of slots
+    ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, pod.CONDUCTOR_EXTENDED)
+    ctx.set_tail_bounce(0)
+    w = O.Wavefront(scene.oracle(), W * H, None, pod.RNG_REFERENCE_SLOT, pod.CONDUCTOR_EXTENDED)
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    w.render(1, threads=8)
+    assert SH.frames_identical(ctx.read_radiance(), w.radiance(), "slot-keyed, ordered, extended conductor, 1080p")
+    assert SH.queue_sizes_identical(ctx.read_queue_sizes(), w.queue_sizes(), int(scene.settings["pathLength"]) + 2)
+
+
 def test_config4_thousand_instances_dielectric_environment(gpu_ctx_factory):
     W, H = 1920, 1080
     scene = CS.config4(W, H)

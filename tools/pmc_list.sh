@@ -1,4 +1,5 @@
 #!/bin/bash
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-24}  # (see tools/profile_round.sh)
 # rocprofv3 --pmc passes from a list file (one pass per line); usage: tools/pmc_list.sh <outdir> <listfile> [bench args]
 out=$1; list=$2; shift; shift
 mkdir -p $out
@@ -7,7 +8,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $line --output-format csv -d $out/pass$i -- python bench.py "$@" --no-cpu-baseline --no-roofline > $out/pass$i.json 2> $out/pass$i.err
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $line --output-format csv -d $out/pass$i -- python bench.py "$@" --no-cpu-baseline --no-roofline --no-reference-mode > $out/pass$i.json 2> $out/pass$i.err
   rc=$?
   echo "pass$i ($line) exit=$rc"
   [ $rc -ne 0 ] && exit $rc

@@ -8,9 +8,13 @@ tag=$1; cfg=$2; frames=$3; shift 3
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 [ -d "$root" ] || { echo "no repo root"; exit 2; }
 cd /tmp && export TMPDIR=/tmp && cd "$root"
+# bench.py asks for 24 hardware queues with os.environ.setdefault "before the process first touches HIP" — under rocprofv3 the
+# profiler's preloaded library has initialised the GPU before Python starts, so the setting has to be in the environment already
+# (otherwise profiled runs with passes in flight get the runtime's 4 queues and do not show the schedule the plain bench measures)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-24}
 O=gpurun_out/prof_$tag; mkdir -p $O
 timeout -k 10 600 python bench.py --config $cfg "$@" > $O/bench_line.json 2> $O/bench_line.err || { tail -5 $O/bench_line.err; exit 1; }
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check > $O/bench_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check --no-reference-mode > $O/bench_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python tools/level_timeline.py $O/stats 2 > $O/pass_timeline.txt 2>/dev/null
 i=0
@@ -18,7 +22,7 @@ dirs=""
 while read -r ctrs; do
   [ -z "$ctrs" ] && continue
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check --no-roofline > $O/pmc$i.json 2> $O/pmc$i.err
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -- python bench.py --config $cfg "$@" --reps 1 --no-cpu-baseline --no-obj-check --no-roofline --no-reference-mode > $O/pmc$i.json 2> $O/pmc$i.err
   rc=$?; echo "pmc pass $i ($ctrs) rc=$rc"
   [ $rc -ne 0 ] && { tail -5 $O/pmc$i.err; exit 1; }
   python tools/pmc_sum.py $O/pmc$i > $O/pmc$i.summary.txt
