@@ -47,6 +47,7 @@ struct DevBuf {
 
 struct BlasHost {
     DevBuf nodes, isect, tris, triIdx;
+    DevBuf shadeTris;  // kShadeTriStride != 96: the triangles again, one per stride (what BlasDev::tris then points at; `tris` stays the packed array the builders read)
     uint32_t nodeCount = 0, triCount = 0;
     uint4 root[5] = {};      // host copy of node 0 (embedded in every InstTrav record of this BLAS), read back on first use
     bool rootKnown = false;
@@ -129,6 +130,9 @@ struct nxhip_ctx : nxd::PassSlot {
     nxd::DevBuf tlasNodes, tlasInstIdx, instTrav, instances;
     std::vector<nx_bvh_instance> hostInstances;
     std::vector<nx_material> hostMaterials;  // kept for the cross-table index check before a render
+    std::vector<nx_material> hostMaterialsDev;  // the device copy (derived flag byte included), for the instances' shading records
+    nxd::DevBuf shadeInst;        // [instanceCount] ShadeInst (nx_device.h): rebuilt before a render when an instance, BLAS or material table changed
+    bool shadeInstDirty = true;
     std::vector<nx_light> hostLights;
     std::vector<uint32_t> hostInstIdx;  // TLAS leaf order
     nxd::DevBuf materials, lights;

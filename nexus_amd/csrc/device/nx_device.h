@@ -47,6 +47,13 @@ namespace nxd {
 #ifndef NX_TRI_STRIDE
 #define NX_TRI_STRIDE 3
 #endif
+// Stride of the SHADING triangles (nx_triangle, 96 B of payload) in bytes.  96: the array as uploaded — a record then spans 1.5
+// 128-byte lines on average.  128: every record on a line of its own (+33 % memory for that array).
+#ifndef NX_SHADE_TRI_STRIDE
+#define NX_SHADE_TRI_STRIDE 96
+#endif
+constexpr int kShadeTriStride = NX_SHADE_TRI_STRIDE;
+static_assert(kShadeTriStride >= (int)sizeof(nx_triangle) && kShadeTriStride % 16 == 0, "shading triangle stride");
 constexpr int kNodeStride = NX_NODE_STRIDE;
 constexpr int kTriStride = NX_TRI_STRIDE;
 
@@ -63,12 +70,13 @@ constexpr int kScanWords = 4;   // status words per tile of such a kernel: one p
 struct BlasDev {
     const NX_G uint4* nodes;
     const NX_G float4* isect;
-    const NX_G nx_triangle* tris;
+    const NX_G nx_triangle* tris;   // shading triangles, kShadeTriStride bytes apart (shade_tri below)
     const NX_G uint32_t* triIdx;
     uint32_t nodeCount, triCount;
     uint32_t pad_[2];
 };
 static_assert(sizeof(BlasDev) == 48, "BlasDev layout");
+inline __device__ const NX_G nx_triangle* shade_tri(const NX_G nx_triangle* tris, uint32_t k) { return (const NX_G nx_triangle*)((const NX_G char*)tris + (size_t)k * (size_t)kShadeTriStride); }
 
 // Traversal record of one TLAS leaf, stored in TLAS *leaf order* (entry k belongs to tlasInstIdx[k]) so that entering an
 // instance is one fetch with no index indirection: inverse transform rows, the BLAS arrays, the instance id, the BLAS root.
@@ -97,6 +105,22 @@ inline __host__ __device__ bool rows_are_identity(const float* m)
     }
     return same;
 }
+
+// Shading record of one instance, in instance order: everything the logic and material kernels need of an instance behind ONE
+// dependent load — the reference follows instance -> BVH descriptor -> triangle array and instance -> material (PathTracer.cu:
+// 329-347), four dependent round trips for a kernel whose time is the sum of its round trips.  Built by the host from the
+// instance, BLAS and material tables (nxhip_api.hip refresh_shade_inst) whenever one of them changes; the device-side
+// transform update (nx_refit.hip) keeps the two matrices current.  Same values as the tables: nothing is recomputed.
+struct __attribute__((aligned(16))) ShadeInst {
+    float transform[12];     // rows 0..2 of nx_bvh_instance::transform
+    float invTransform[12];  // rows 0..2 of nx_bvh_instance::invTransform
+    const NX_G nx_triangle* tris;  // BlasDev::tris of the instance's BLAS (kShadeTriStride apart)
+    uint32_t triCount;
+    int32_t materialId;
+    nx_material material;    // the device copy (derived flag byte behind `type` included: kMaterialFlagOffset)
+    uint32_t pad_;
+};
+static_assert(sizeof(ShadeInst) == 176 && offsetof(ShadeInst, material) == 112, "ShadeInst layout");
 
 struct TextureDev {
     const NX_G uint32_t* texels;  // RGBA8, row 0 first
@@ -199,6 +223,7 @@ struct DeviceState {
     const NX_G uint32_t* tlasInstIdx;
     const NX_G InstTrav* instTrav;
     const NX_G nx_bvh_instance* instances;
+    const NX_G ShadeInst* shadeInst;   // [instanceCount], see ShadeInst
     const NX_G BlasDev* blas;
     const NX_G nx_material* materials;
     const NX_G nx_light* lights;
@@ -263,9 +288,9 @@ constexpr uint64_t layout_stamp()
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
-        sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),
+        sizeof(ShadeInst), offsetof(ShadeInst, tris), offsetof(ShadeInst, material), offsetof(DeviceState, shadeInst), sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),
         sizeof(TextureDev), sizeof(TraceQueue), sizeof(ShadowQueue), sizeof(MaterialQueue), sizeof(FrameState), sizeof(TraceStatsDev),
-        (uint64_t)kNodeStride, (uint64_t)kTriStride, (uint64_t)kQueueShards, (uint64_t)kQueueShardSlack, (uint64_t)kRegionStride, (uint64_t)kMaxBounceSlots,
+        (uint64_t)kNodeStride, (uint64_t)kTriStride, (uint64_t)kShadeTriStride, (uint64_t)kQueueShards, (uint64_t)kQueueShardSlack, (uint64_t)kRegionStride, (uint64_t)kMaxBounceSlots,
         (uint64_t)kEnvGuide, (uint64_t)kMaterialTypeOffset, sizeof(nx_material), sizeof(nx_bvh_instance), sizeof(nx_triangle), sizeof(nx_light), sizeof(nx_camera),
     };
     for (uint64_t v : w) h = layout_mix(h, v);

@@ -23,7 +23,8 @@ struct f2 { float x, y; };
 
 NXD f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 NXD f3 mk3(float s) { return f3{s, s, s}; }
-NXD f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+template <class P>  // (generic or global-address-space pointer to three floats)
+NXD f3 ld3(P p) { return f3{p[0], p[1], p[2]}; }
 NXD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 NXD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 NXD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
@@ -49,18 +50,21 @@ NXD f3 mat_point(float4 r0, float4 r1, float4 r2, f3 v)
     return f3{fmaf(r0.z, v.z, fmaf(r0.y, v.y, r0.x * v.x)) + r0.w, fmaf(r1.z, v.z, fmaf(r1.y, v.y, r1.x * v.x)) + r1.w,
               fmaf(r2.z, v.z, fmaf(r2.y, v.y, r2.x * v.x)) + r2.w};
 }
-// 16-float row-major matrix in memory
-NXD f3 mat_vec(const float* c, f3 v)
+// 16-float row-major matrix in memory (P: a generic or a global-address-space pointer to its floats)
+template <class P>
+NXD f3 mat_vec(P c, f3 v)
 {
     return f3{fmaf(c[2], v.z, fmaf(c[1], v.y, c[0] * v.x)), fmaf(c[6], v.z, fmaf(c[5], v.y, c[4] * v.x)), fmaf(c[10], v.z, fmaf(c[9], v.y, c[8] * v.x))};
 }
-NXD f3 mat_point(const float* c, f3 v)
+template <class P>
+NXD f3 mat_point(P c, f3 v)
 {
     return f3{fmaf(c[2], v.z, fmaf(c[1], v.y, c[0] * v.x)) + c[3], fmaf(c[6], v.z, fmaf(c[5], v.y, c[4] * v.x)) + c[7],
               fmaf(c[10], v.z, fmaf(c[9], v.y, c[8] * v.x)) + c[11]};
 }
 // (3x3 block of M)^T * v — normals through invTransform.Transposed()
-NXD f3 mat_vec_transposed(const float* c, f3 v)
+template <class P>
+NXD f3 mat_vec_transposed(P c, f3 v)
 {
     return f3{fmaf(c[8], v.z, fmaf(c[4], v.y, c[0] * v.x)), fmaf(c[9], v.z, fmaf(c[5], v.y, c[1] * v.x)), fmaf(c[10], v.z, fmaf(c[6], v.y, c[2] * v.x))};
 }
@@ -88,7 +92,8 @@ NXD f3 bary3(f3 t0, f3 t1, f3 t2, float u, float v)
     const float w = 1.0f - u - v;
     return (t1 * u + t2 * v) + t0 * w;
 }
-NXD f2 bary2(const float* t0, const float* t1, const float* t2, float u, float v)
+template <class P>
+NXD f2 bary2(P t0, P t1, P t2, float u, float v)
 {
     const float w = 1.0f - u - v;
     return f2{u * t1[0] + v * t2[0] + w * t0[0], u * t1[1] + v * t2[1] + w * t0[1]};

@@ -66,8 +66,10 @@ NXD void mat4_invert(const float* m, float* out)
 //  differently from the host stub, which is compiled without it)
 __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceState* __restrict__ S, nx_bvh_instance* instancesArg, InstTrav* travArg,
                                                                  const uint32_t* __restrict__ leafOfInstance, const uint32_t* __restrict__ ids,
-                                                                 const float* __restrict__ transforms, const uint32_t count, InstBox* __restrict__ tightBoxes)
+                                                                 const float* __restrict__ transforms, const uint32_t count, InstBox* __restrict__ tightBoxes,
+                                                                 ShadeInst* shadeInstArg)
 {
+    NX_G ShadeInst* shadeInst = (NX_G ShadeInst*)shadeInstArg;  // nullptr: the host rebuilds the shading records before the next render
     NX_G nx_bvh_instance* instances = (NX_G nx_bvh_instance*)instancesArg;
     NX_G InstTrav* trav = (NX_G InstTrav*)travArg;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
@@ -92,6 +94,8 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
             box_grow(wb, p, p);
         }
         for (int i = 0; i < 16; i++) { inst->transform.cell[i] = m[i]; inst->invTransform.cell[i] = inv[i]; }
+        if (shadeInst)
+            for (int i = 0; i < 12; i++) { shadeInst[id].transform[i] = m[i]; shadeInst[id].invTransform[i] = inv[i]; }
         for (int a = 0; a < 3; a++) { inst->boundsMin[a] = wb.lo[a]; inst->boundsMax[a] = wb.hi[a]; }
         if (tightBoxes && kNodeStride == 5) {  // a TLAS built on the device keeps its tighter boxes (nx_instbox.h) through the refit
             InstBox tb;

@@ -386,11 +386,11 @@ NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame,
             survived = true;
             throughputOut = throughput / probability;
             inst = hitInst();
-            const int materialId = S->instances[inst].materialId;
             // type and, behind it, the flag nxhip_set_materials derived: the material can emit (an emissive hit weighs itself
             // against the light sampler by the distance from the path's previous vertex) or let a path pass through (which
-            // keeps the path state, PathTracer.cu:372-386) — see keep_previous_vertex below
-            const uint32_t typeAndFlag = *(const NX_G uint32_t*)((const NX_G char*)&S->materials[materialId] + kMaterialTypeOffset);
+            // keeps the path state, PathTracer.cu:372-386) — see keep_previous_vertex below.  Read from the instance's shading
+            // record (one dependent load; the reference's instance -> material is two)
+            const uint32_t typeAndFlag = *(const NX_G uint32_t*)((const NX_G char*)&S->shadeInst[inst].material + kMaterialTypeOffset);
             type = (int)(int8_t)(typeAndFlag & 0xffu);
             if (type < 0 || type > 3) type = -1;
             needsPrevVertex = ((typeAndFlag >> 8) & 1u) != 0u;
@@ -528,14 +528,15 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
     }
     const nx_light light = S->lights[pick];
     if (light.type != NX_LIGHT_MESH) return false;
-    const nx_bvh_instance* inst = &S->instances[light.mesh.meshId];
-    const BlasDev* bvh = &S->blas[inst->bvhIdx];
-    const uint32_t triangleIdx = uniform_index(bvh->triCount, rng);
+    // the light's instance: its shading record (transform, triangles, material behind one load)
+    const NX_G ShadeInst* inst = &S->shadeInst[light.mesh.meshId];
+    const uint32_t lightTriCount = inst->triCount;
+    const uint32_t triangleIdx = uniform_index(lightTriCount, rng);
     const f2 uv = uniform_triangle(rng);
-    const nx_triangle* tri = &bvh->tris[triangleIdx];
+    const NX_G nx_triangle* tri = shade_tri(inst->tris, triangleIdx);
     const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
-    const float* T = inst->transform.cell;
-    const float* IT = inst->invTransform.cell;
+    const NX_G float* T = inst->transform;
+    const NX_G float* IT = inst->invTransform;
 
     f3 p = mat_point(T, bary3(tp0, tp1, tp2, uv.x, uv.y));
     const f3 lightGNormal = normalize3(mat_vec_transposed(IT, cross3(tp1 - tp0, tp2 - tp0)));
@@ -556,11 +557,11 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
     const float cosThetaO = fabsf(dot3(lightNormal, out.direction));
     const float dSquared = dot3(toLight, toLight);
     const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
-    float lightPdf = 1.0f / ((float)(nLights * bvh->triCount) * area);
+    float lightPdf = 1.0f / ((float)(nLights * lightTriCount) * area);
     lightPdf *= dSquared / cosThetaO;
     if (!pdf_valid(lightPdf)) return false;
 
-    const nx_material* lightMaterial = &S->materials[inst->materialId];
+    const NX_G nx_material* lightMaterial = &inst->material;
     f3 sampleThroughput;
     float bsdfPdf;
     if (!Bsdf<TYPE>::eval(mp, wi, wo, sampleThroughput, bsdfPdf)) return false;
@@ -594,13 +595,12 @@ NXD void shade_path(const DeviceState* S, const int bounce, const uint32_t frame
     f3 throughput = mk3(tpdf.x, tpdf.y, tpdf.z);
     uint32_t rng = seed_for(S, seedSlot, pixelIdx, (uint32_t)bounce, 1u, frame);
 
-    const nx_bvh_instance* inst = &S->instances[instanceIdx];
-    const BlasDev* bvh = &S->blas[inst->bvhIdx];
-    const nx_triangle* tri = &bvh->tris[triIdx];
-    const nx_material material = S->materials[inst->materialId];
+    const NX_G ShadeInst* inst = &S->shadeInst[instanceIdx];
+    const NX_G nx_triangle* tri = shade_tri(inst->tris, triIdx);
+    const nx_material material = inst->material;
     MatParams mp = load_params(material);
-    const float* T = inst->transform.cell;
-    const float* IT = inst->invTransform.cell;
+    const NX_G float* T = inst->transform;
+    const NX_G float* IT = inst->invTransform;
     const f3 tp0 = ld3(tri->pos0), tp1 = ld3(tri->pos1), tp2 = ld3(tri->pos2);
 
     const f3 p = mat_point(T, bary3(tp0, tp1, tp2, hu, hv));
@@ -625,7 +625,7 @@ NXD void shade_path(const DeviceState* S, const int bounce, const uint32_t frame
             const float4 ro = prevOrigin();
             const float dSquared = squaref(length3(p - mk3(ro.x, ro.y, ro.z)));
             const float area = tri_area(mat_point(T, tp0), mat_point(T, tp1), mat_point(T, tp2));
-            float lightPdf = 1.0f / ((float)(nee_light_count(S) * bvh->triCount) * area);
+            float lightPdf = 1.0f / ((float)(nee_light_count(S) * inst->triCount) * area);
             lightPdf *= dSquared / cosThetaO;
             if (!pdf_valid(lightPdf)) weight = 0.0f;
             else weight = power_heuristic(lastPdf, lightPdf);

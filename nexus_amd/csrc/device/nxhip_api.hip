@@ -558,6 +558,17 @@ static std::vector<uint4> pad_nodes(const nx_bvh8_node* nodes, uint32_t nodeCoun
     return out;
 }
 
+// The shading copy of a BLAS's triangles when they are kept one per kShadeTriStride bytes (nx_device.h): a strided device copy
+// of the packed array.
+static int make_shade_tris(BlasHost& b)
+{
+    if (kShadeTriStride == (int)sizeof(nx_triangle)) return NXHIP_OK;
+    NX_ALLOC(b.shadeTris, (size_t)b.triCount * kShadeTriStride);
+    NX_HIP(hipMemset(b.shadeTris.p, 0, (size_t)b.triCount * kShadeTriStride));
+    NX_HIP(hipMemcpy2D(b.shadeTris.p, kShadeTriStride, b.tris.p, sizeof(nx_triangle), sizeof(nx_triangle), b.triCount, hipMemcpyDeviceToDevice));
+    return NXHIP_OK;
+}
+
 static int refresh_blas_table(nxhip_ctx* c)
 {
     std::vector<BlasDev> table(std::max<size_t>(1, c->blas.size()));
@@ -566,7 +577,7 @@ static int refresh_blas_table(nxhip_ctx* c)
         const BlasHost& b = c->blas[i];
         table[i].nodes = b.nodes.as<uint4>();
         table[i].isect = b.isect.as<float4>();
-        table[i].tris = b.tris.as<nx_triangle>();
+        table[i].tris = kShadeTriStride == (int)sizeof(nx_triangle) ? b.tris.as<nx_triangle>() : b.shadeTris.as<nx_triangle>();
         table[i].triIdx = b.triIdx.as<uint32_t>();
         table[i].nodeCount = b.nodeCount;
         table[i].triCount = b.triCount;
@@ -576,6 +587,38 @@ static int refresh_blas_table(nxhip_ctx* c)
     NX_HIP(hipMemcpy(c->blasTable.p, table.data(), table.size() * sizeof(BlasDev), hipMemcpyHostToDevice));
     c->h.blas = c->blasTable.as<BlasDev>();
     c->stateDirty = true;
+    c->shadeInstDirty = true;  // (the records hold the BLASes' triangle arrays)
+    return NXHIP_OK;
+}
+
+// The shading records of the instances (nx_device.h ShadeInst) from the instance, BLAS and material tables.  Called before a
+// render when one of them has changed (shadeInstDirty); the cross-table indices have been checked by then (check_scene_ready).
+// The matrices come from the DEVICE's instance table: nxhip_set_instance_transforms computes the inverses there.
+static int refresh_shade_inst(nxhip_ctx* c)
+{
+    const size_t n = c->hostInstances.size();
+    std::vector<nx_bvh_instance> inst(n);
+    NX_SYNC_ALL(c);
+    if (n) NX_HIP(hipMemcpy(inst.data(), c->instances.p, n * sizeof(nx_bvh_instance), hipMemcpyDeviceToHost));
+    std::vector<ShadeInst> rec(std::max<size_t>(1, n));
+    std::memset(rec.data(), 0, rec.size() * sizeof(ShadeInst));
+    for (size_t i = 0; i < n; i++) {
+        const nx_bvh_instance& in = inst[i];
+        if (in.bvhIdx >= c->blas.size()) return fail_invalid("instance refers to a BLAS id that has not been uploaded");
+        if (in.materialId < 0 || (size_t)in.materialId >= c->hostMaterialsDev.size()) return fail_invalid("an instance refers to a material id that has not been set");
+        const BlasHost& b = c->blas[in.bvhIdx];
+        std::memcpy(rec[i].transform, in.transform.cell, sizeof rec[i].transform);
+        std::memcpy(rec[i].invTransform, in.invTransform.cell, sizeof rec[i].invTransform);
+        rec[i].tris = kShadeTriStride == (int)sizeof(nx_triangle) ? b.tris.as<nx_triangle>() : b.shadeTris.as<nx_triangle>();
+        rec[i].triCount = b.triCount;
+        rec[i].materialId = in.materialId;
+        rec[i].material = c->hostMaterialsDev[(size_t)in.materialId];
+    }
+    NX_ALLOC(c->shadeInst, rec.size() * sizeof(ShadeInst));
+    NX_HIP(hipMemcpy(c->shadeInst.p, rec.data(), rec.size() * sizeof(ShadeInst), hipMemcpyHostToDevice));
+    c->h.shadeInst = c->shadeInst.as<ShadeInst>();
+    c->stateDirty = true;
+    c->shadeInstDirty = false;
     return NXHIP_OK;
 }
 
@@ -681,6 +724,7 @@ try {
     NX_HIP(hipMemcpy(b.isect.p, isect.data(), isect.size() * sizeof(float4), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(b.tris.p, tris, (size_t)triCount * sizeof(nx_triangle), hipMemcpyHostToDevice));
     NX_HIP(hipMemcpy(b.triIdx.p, triIdx, (size_t)triCount * 4, hipMemcpyHostToDevice));
+    if (const int rcs = make_shade_tris(b)) return rcs;
     c->blas.push_back(std::move(b));
     if (blasId) *blasId = (int32_t)c->blas.size() - 1;
     return refresh_blas_table(c);
@@ -707,6 +751,7 @@ try {
     NX_ALLOC(b.nodes, (size_t)nodeCount * sizeof(nx_bvh8_node));  // the builder's array is sized for the worst case
     NX_HIP(hipMemcpy(b.nodes.p, wide.p, (size_t)nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToDevice));
     b.nodeCount = nodeCount;
+    if (const int rcs = make_shade_tris(b)) return rcs;
     c->blas.push_back(std::move(b));
     if (blasId) *blasId = (int32_t)c->blas.size() - 1;
     return refresh_blas_table(c);
@@ -807,6 +852,7 @@ try {
     c->h.instances = c->instances.as<nx_bvh_instance>();
     c->h.instanceCount = instanceCount;
     c->stateDirty = true;
+    c->shadeInstDirty = true;
     {
         // schedule of the device-side refit (nxhip_set_instance_transforms): node indices grouped by depth, deepest first
         std::vector<uint32_t> depth(nodeCount, 0u);
@@ -910,7 +956,9 @@ try {
         const uint32_t* ids = c->refitIds.as<uint32_t>();
         const float* mats = c->refitMatrices.as<float>();
         void* tight = c->tlasTightBoxes.p;
-        void* args[8] = {(void*)&S, (void*)&inst, (void*)&trav, (void*)&leafOf, (void*)&ids, (void*)&mats, (void*)&count, (void*)&tight};
+        // (the shading records follow the matrices when they are current; a stale set is rebuilt from the device's instance table)
+        ShadeInst* shadeInst = c->shadeInstDirty ? nullptr : c->shadeInst.as<ShadeInst>();
+        void* args[9] = {(void*)&S, (void*)&inst, (void*)&trav, (void*)&leafOf, (void*)&ids, (void*)&mats, (void*)&count, (void*)&tight, (void*)&shadeInst};
         const unsigned grid = std::min<unsigned>((count + 255u) / 256u, (unsigned)c->wideBlocks);
         NX_HIP(hipLaunchKernel(instance_transform_kernel_ptr(), dim3(grid), dim3(256), args, 0, c->stream));
     }
@@ -986,7 +1034,9 @@ try {
     }
     NX_HIP(hipMemcpy(c->materials.p, dev.data(), (size_t)count * sizeof(nx_material), hipMemcpyHostToDevice));
     c->h.materials = c->materials.as<nx_material>();
+    c->hostMaterialsDev = dev;
     c->stateDirty = true;
+    c->shadeInstDirty = true;  // (the records hold a copy of their instance's material)
     uint32_t mask = 0u;
     for (const nx_material& m : dev)
         if (m.type >= 0 && m.type <= 3) mask |= 1u << m.type;
@@ -1563,6 +1613,10 @@ try {
     NX_HIP(hipSetDevice(c->device));
     int rc = check_scene_ready(c);
     if (rc != NXHIP_OK) return rc;
+    if (c->shadeInstDirty) {
+        rc = refresh_shade_inst(c);
+        if (rc != NXHIP_OK) return rc;
+    }
     rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
     // the slot this pass renders in: round robin over the passes in flight (one slot: everything on the context's stream,
