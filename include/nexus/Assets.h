@@ -81,6 +81,13 @@ public:
     // new BVH will have in GetBVHs().
     using BlasBuilder = std::function<BVH8(const std::vector<Triangle>& triangles, size_t index)>;
     void SetBlasBuilder(BlasBuilder builder) { m_BlasBuilder = std::move(builder); }
+    // The BVHs of all meshes of a file at once (OBJLoader::LoadOBJ; the reference calls CreateBVH per aiMesh,
+    // Assets/OBJLoader.cpp:213-239): returns the id of the first, the others follow.  With a batch builder installed
+    // (PathTracer::SetDeviceBlasBuild: nxhip_build_blas_batch, one device build for the whole file) they are built together,
+    // otherwise one by one through CreateBVH.  `firstIndex` is the id the first new BVH will have.
+    using BlasBatchBuilder = std::function<std::vector<BVH8>(const std::vector<std::vector<Triangle>>& meshes, size_t firstIndex)>;
+    void SetBlasBatchBuilder(BlasBatchBuilder builder) { m_BlasBatchBuilder = std::move(builder); }
+    int32_t CreateBVHs(const std::vector<std::vector<Triangle>>& meshes);
     int32_t AddMesh(Mesh&& mesh);
     void AddMaterial();
     int AddMaterial(const Material& material);
@@ -108,6 +115,7 @@ private:
     std::vector<BVH8> m_Bvhs;
     std::vector<Mesh> m_Meshes;
     BlasBuilder m_BlasBuilder;
+    BlasBatchBuilder m_BlasBatchBuilder;
 };
 
 }  // namespace nexus

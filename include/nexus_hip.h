@@ -68,6 +68,20 @@ int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCo
  * profiles/r03_builder_quality.txt.  A valid, conservative CWBVH whose node bytes differ from the host builder's (another
  * tree); hit records are the same up to equidistant ties.  Returns the BLAS id like nxhip_upload_blas. */
 int nxhip_build_blas(nxhip_ctx *ctx, const nx_triangle *tris, uint32_t triCount, int32_t *blasId);
+/* The BLASes of `meshCount` meshes in ONE device build.  The reference creates one BVH8 per aiMesh of a file
+ * (Assets/OBJLoader.cpp:213-239 -> AssetManager::AddMesh -> CreateBVH, Assets/AssetManager.cpp:23-37: a glTF scene is hundreds
+ * or thousands of small meshes); built one by one on the device each of them pays the build's ~25 level synchronisations and
+ * its allocations.  Here the meshes are a forest over the concatenated triangles — per-mesh Morton order, one root segment per
+ * mesh, then the level loops of nxhip_build_blas (binning, split, partition; cost table; collapse) over all meshes at once — and
+ * the BLASes share four pooled allocations.  Each tree is the tree nxhip_build_blas(tris[m], triCounts[m]) builds (same
+ * decisions from the same counts, boxes and orders; node numbering differs as between two single builds).  blasIds[m] (may be
+ * NULL) = the id of mesh m; ids are consecutive.  With another builder selected (nxhip_set_device_builder) the meshes are built
+ * one by one.  1 000 meshes of 1 000 triangles: see profiles/r04_blas_batch.txt. */
+int nxhip_build_blas_batch(nxhip_ctx *ctx, const nx_triangle *const *tris, const uint32_t *triCounts, uint32_t meshCount, int32_t *blasIds);
+/* nxhip_read_blas for `count` consecutive BLAS ids: nodes and primitive indices concatenated in id order (either may be NULL),
+ * nodeCounts[k] = nodes of BLAS firstBlasId + k.  One transfer each when the range comes from one nxhip_build_blas_batch call. */
+int nxhip_read_blas_batch(nxhip_ctx *ctx, int32_t firstBlasId, uint32_t count, nx_bvh8_node *nodes, uint32_t nodeCapacity, uint32_t *nodeCounts,
+                          uint32_t *primIdx, uint32_t primCapacity);
 /* Which binary tree the device builders (nxhip_build_blas, nxhip_rebuild_tlas) collapse into 8-wide nodes.
  * NXHIP_BUILDER_SAH (default): the top-down binned SAH build described above.  0: the binary radix tree of the 63-bit
  * Morton codes (LBVH: sort + one launch; 21 ms per million triangles).  clusteringRadius > 0: parallel locally-ordered

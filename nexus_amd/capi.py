@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
-    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library",
+    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch",
 ]
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
@@ -533,6 +533,32 @@ class Context:
         self.L.nxhip_build_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
         check(self.L.nxhip_build_blas(self.h, _ptr(t), len(t), C.byref(bid)), "nxhip_build_blas")
         return int(bid.value)
+
+    def build_blas_batch(self, meshes):
+        """the BLASes of several meshes in one device build (nxhip_build_blas_batch); returns their ids (consecutive)"""
+        arrays = [np.ascontiguousarray(m, dtype=pod.TRI_DT) for m in meshes]
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        counts = np.array([len(a) for a in arrays], dtype=np.uint32)
+        ids = np.full(len(arrays), -1, dtype=np.int32)
+        self.L.nxhip_build_blas_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        check(self.L.nxhip_build_blas_batch(self.h, ptrs, _ptr(counts), len(arrays), _ptr(ids)), "nxhip_build_blas_batch")
+        return [int(i) for i in ids]
+
+    def read_blas_batch(self, first_id, tri_counts):
+        """nodes and primitive index lists of consecutive BLAS ids: [(nodes, idx), ...]"""
+        count = len(tri_counts)
+        self.L.nxhip_read_blas_batch.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        node_counts = np.zeros(count, dtype=np.uint32)
+        check(self.L.nxhip_read_blas_batch(self.h, first_id, count, None, 0, _ptr(node_counts), None, 0), "nxhip_read_blas_batch")
+        nodes = np.zeros(int(node_counts.sum()), dtype=pod.NODE_DT)
+        idx = np.zeros(int(np.sum(tri_counts)), dtype=np.uint32)
+        check(self.L.nxhip_read_blas_batch(self.h, first_id, count, _ptr(nodes), len(nodes), _ptr(node_counts), _ptr(idx), len(idx)), "nxhip_read_blas_batch")
+        out, na, pa = [], 0, 0
+        for k in range(count):
+            out.append((nodes[na:na + int(node_counts[k])], idx[pa:pa + int(tri_counts[k])]))
+            na += int(node_counts[k])
+            pa += int(tri_counts[k])
+        return out
 
     def read_blas(self, blas_id, tri_count):
         self.L.nxhip_read_blas.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]

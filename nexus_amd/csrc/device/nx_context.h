@@ -20,28 +20,41 @@ bool hip_ok(hipError_t e, const char* what, const char* file, int line);
         if (!::nxd::hip_ok((call), #call, __FILE__, __LINE__)) return NXHIP_ERR_HIP; \
     } while (0)
 
-// Owning device allocation.
+// Owning device allocation — or, with `pool` set, a VIEW of a range of one that several buffers share (the BLASes of one
+// nxhip_build_blas_batch call live in four pooled allocations instead of 4 000: a thousand hipMalloc calls alone would cost
+// more than the build).  The pool is freed when its last view goes.
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    std::shared_ptr<DevBuf> pool;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), pool(std::move(o.pool)) { o.p = nullptr; o.bytes = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept
     {
-        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; pool = std::move(o.pool); o.p = nullptr; o.bytes = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (pool) pool.reset();
+        else if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }
     // (Re)allocate; contents undefined.  Returns false on failure (error string set).
     bool alloc(size_t n);
+    // `n` bytes at `offset` of a shared allocation
+    static DevBuf view(const std::shared_ptr<DevBuf>& of, size_t offset, size_t n)
+    {
+        DevBuf v;
+        v.p = static_cast<char*>(of->p) + offset;
+        v.bytes = n;
+        v.pool = of;
+        return v;
+    }
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -150,6 +163,9 @@ struct nxhip_ctx : nxd::PassSlot {
     // paths / queues
     nxd::DevBuf pixelMap, accumulation, rgba8;
     nxd::DevBuf traceStats;
+    void* hostStaging = nullptr;   // pinned host buffer for large uploads (nxhip_build_blas_batch), grown on demand, freed with the context
+    size_t hostStagingBytes = 0;
+    hipEvent_t stagingDone[2] = {nullptr, nullptr};  // one per half of the staging buffer: its last transfer has completed
 
     int deviceBuilderRadius = -1;  // nxhip_build_blas / nxhip_rebuild_tlas: -1 = top-down binned SAH (NXHIP_BUILDER_SAH), 0 = radix tree (LBVH), > 0 = neighbour search radius of the clustering builder
     uint32_t frameNumber = 0;  // host mirror of FrameState.frameNumber

@@ -14,6 +14,8 @@
 // (a different tree): hits are identical, traversal visits more nodes (quality is the price of the build speed).
 #include <string.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -745,8 +747,9 @@ __global__ void __launch_bounds__(kBlock) sah_leaves_kernel(const Box3* __restri
 __device__ __forceinline__ Eval eval_of(const Bvh2& t, const int n, const int node, const int i, const bool fresh)
 {
     if (node >= n - 1) return Eval{half_area(t.box[node]) * t.primCost, kDecLeaf, 0, 0, 0};  // one primitive: a leaf slot whatever i
+    // (fresh: written by another thread of this launch — a device-scope load, which does not stop at this XCD's L2)
     const unsigned long long* p = reinterpret_cast<const unsigned long long*>(&t.eval[(size_t)node * 7 + i]);
-    const unsigned long long w = fresh ? *reinterpret_cast<const volatile unsigned long long*>(p) : *p;
+    const unsigned long long w = fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
     Eval e;
     memcpy(&e, &w, 8);
     return e;
@@ -757,10 +760,12 @@ __global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         int node = t.parent[(n - 1) + k];
         while (node >= 0) {
-            __threadfence();  // (as fit_kernel: this thread's entries are visible before its arrival is)
+            // This thread's entries must be visible before its arrival is.  They are written with device-scope stores (below:
+            // written through to where every XCD sees them), so waiting for them to complete is enough; the reader fetches them
+            // with device-scope loads (eval_of).  The generic form — __threadfence() on either side, i.e. a write-back and an
+            // invalidate of the XCD's whole L2 per node visit — made this kernel 7 ms per million primitives (round 4: 1.x ms).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (atomicAdd(&t.arrived[node], 1) == 0) break;
-            __threadfence();
             const int l = t.left[node], r = t.right[node];
             float lc[7], rc[7];
             for (int i = 0; i < 7; i++) {
@@ -792,7 +797,11 @@ __global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
                     e[i] = best < e[i - 1].cost ? Eval{best, kDecDistribute, (int8_t)bl, (int8_t)br, 0} : e[i - 1];
                 }
             }
-            for (int i = 0; i < 7; i++) t.eval[(size_t)node * 7 + i] = e[i];
+            for (int i = 0; i < 7; i++) {
+                unsigned long long w;
+                memcpy(&w, &e[i], 8);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(&t.eval[(size_t)node * 7 + i]), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             node = t.parent[node];
         }
     }
@@ -802,6 +811,16 @@ __global__ void __launch_bounds__(kBlock) cost_kernel(const int n, Bvh2 t)
 struct WorkItem {
     int bvh2Node;   // root of the BVH2 subtree this BVH8 node covers (internal node id)
     uint32_t outNode;
+    uint32_t mesh;  // batched build: the mesh the node belongs to (its own node numbers, primitive list and counters)
+};
+// One mesh of a batched build (lbvh_build_batch): its primitives are positions [first, first + count) of the concatenated arrays,
+// its wide nodes are written to nodes[first + k] (k < count: a mesh never has more wide nodes than primitives), its primitive
+// list to primIdx[first ...] with mesh-local indices.  big: its rank among the meshes that go through the tree build (= the
+// binary-tree node that is its root), -1: at most eight primitives, a single node (small_mesh_node).
+struct BatchMesh {
+    uint32_t first, count;
+    int big;
+    uint32_t pad_;
 };
 
 __device__ __forceinline__ uint32_t quantize(float v)  // nexus::collapse Quantize
@@ -821,12 +840,18 @@ __device__ __forceinline__ bool is_inner(const Bvh2& t, const int n, const int c
     return false;
 }
 
+// meshCounters: per mesh {nodes used, prims used}; workCounter: work items of the next level.  meshes == nullptr: one mesh, whose
+// arrays start at 0 and whose node capacity is nodeCapacity.
 __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, const int n, const uint32_t* __restrict__ order, const WorkItem* __restrict__ work,
-                                                                const uint32_t workCount, WorkItem* __restrict__ nextWork, uint32_t* __restrict__ counters /* [0] nodes used, [1] prims used, [2] next work count */,
-                                                                nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx, const uint32_t nodeCapacity)
+                                                                const uint32_t workCount, WorkItem* __restrict__ nextWork, uint32_t* __restrict__ meshCounters,
+                                                                uint32_t* __restrict__ workCounter, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx,
+                                                                const uint32_t nodeCapacity, const BatchMesh* __restrict__ meshes)
 {
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < workCount; w += gridDim.x * blockDim.x) {
         const WorkItem item = work[w];
+        const uint32_t mesh = meshes ? item.mesh : 0u;
+        const uint32_t meshFirst = meshes ? meshes[mesh].first : 0u, meshCapacity = meshes ? meshes[mesh].count : nodeCapacity;
+        uint32_t* const counters = meshCounters + 2 * (size_t)mesh;
         int child[8];
         int count = 0;
         if (t.eval) {
@@ -912,8 +937,8 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
         }
         const uint32_t childBase = innerCount ? atomicAdd(&counters[0], innerCount) : 0u;
         const uint32_t primBase = primCount ? atomicAdd(&counters[1], primCount) : 0u;
-        if (innerCount && childBase + innerCount > nodeCapacity) continue;  // cannot happen: capacity covers the worst case
-        const uint32_t workBase = innerCount ? atomicAdd(&counters[2], innerCount) : 0u;
+        if (innerCount && childBase + innerCount > meshCapacity) continue;  // cannot happen: capacity covers the worst case
+        const uint32_t workBase = innerCount ? atomicAdd(workCounter, innerCount) : 0u;
 
         nx_bvh8_node node;
         node = nx_bvh8_node{};
@@ -945,7 +970,7 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
             if (is_inner(t, n, c)) {
                 node.meta[s] = (uint8_t)(0x20 | (24 + s));
                 node.imask |= (uint8_t)(1u << s);
-                nextWork[workBase + innerSeen] = WorkItem{c, childBase + innerSeen};
+                nextWork[workBase + innerSeen] = WorkItem{c, childBase + innerSeen, mesh};
                 innerSeen++;
             } else {
                 // the (at most three) primitives under this child, left to right: a subtree of at most two internal nodes
@@ -962,20 +987,19 @@ __global__ void __launch_bounds__(kBlock) collapse_level_kernel(const Bvh2 t, co
                 uint32_t unary = 0;
                 for (int j = 0; j < tris; j++) {
                     unary |= 1u << (j + 5);
-                    primIdx[primBase + primSeen + (uint32_t)j] = order[leaves[j]];
+                    primIdx[meshFirst + primBase + primSeen + (uint32_t)j] = order[leaves[j]] - meshFirst;
                 }
                 node.meta[s] = (uint8_t)(unary | primSeen);
                 primSeen += (uint32_t)tris;
             }
         }
-        nodes[item.outNode] = node;
+        nodes[meshFirst + item.outNode] = node;
     }
 }
 
 // tiny inputs: a root whose children are the triangles themselves (fewer than 2 internal BVH2 nodes to speak of)
-__global__ void small_mesh_kernel(const Box3* __restrict__ triBox, const int n, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx)
+__device__ void small_mesh_node(const Box3* __restrict__ triBox, const int n, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Box3 nb;
     for (int a = 0; a < 3; a++) { nb.lo[a] = 1e30f; nb.hi[a] = -1e30f; }
     for (int k = 0; k < n; k++)
@@ -1005,13 +1029,161 @@ __global__ void small_mesh_kernel(const Box3* __restrict__ triBox, const int n, 
     }
     nodes[0] = node;
 }
+__global__ void small_mesh_kernel(const Box3* __restrict__ triBox, const int n, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    small_mesh_node(triBox, n, nodes, primIdx);
+}
+
+// ---- 5b. the kernels only a BATCHED build needs (lbvh_build_batch): M meshes as one forest over the concatenated primitives.
+// Everything between the Morton codes and the collapse is the single build's kernels unchanged — they work on segments of a
+// position range and on node numbers, and a forest is M root segments and M roots instead of one.
+
+// block m: every position of mesh m learns its mesh and its root segment (-1: a small mesh, not part of the tree build)
+__global__ void __launch_bounds__(kBlock) batch_fill_kernel(const BatchMesh* __restrict__ meshes, int* __restrict__ meshOf, int* __restrict__ segOf)
+{
+    const BatchMesh m = meshes[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < m.count; k += blockDim.x) {
+        meshOf[m.first + k] = (int)blockIdx.x;
+        segOf[m.first + k] = m.big;
+    }
+}
+
+// tri_bounds_kernel + box_union_kernel per mesh: bounds[12 m ...] = centroid bounds (6 words), box (6 words), float_ordered
+__global__ void __launch_bounds__(kBlock) tri_bounds_batch_kernel(const nx_triangle* __restrict__ tris, const uint32_t n, const int* __restrict__ meshOf, Box3* __restrict__ triBox,
+                                                                  uint32_t* __restrict__ bounds)
+{
+    for (uint32_t tile = blockIdx.x * blockDim.x; tile < n; tile += gridDim.x * blockDim.x) {
+        const uint32_t i = tile + threadIdx.x;
+        const bool valid = i < n;
+        float lo[6], hi[6];  // [0..2] centroid, [3..5] box
+        int m = -1;
+        if (valid) {
+            const nx_triangle t = tris[i];
+            m = meshOf[i];
+            Box3 b;
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] = fminf(fminf(t.pos0[a], t.pos1[a]), t.pos2[a]);
+                b.hi[a] = fmaxf(fmaxf(t.pos0[a], t.pos1[a]), t.pos2[a]);
+                lo[a] = hi[a] = 0.5f * (b.lo[a] + b.hi[a]);
+                lo[3 + a] = b.lo[a];
+                hi[3 + a] = b.hi[a];
+            }
+            triBox[i] = b;
+        } else {
+            for (int a = 0; a < 6; a++) { lo[a] = 1e30f; hi[a] = -1e30f; }
+        }
+        // one set of atomics per wave where the wave's triangles share a mesh
+        const unsigned long long validMask = __ballot(valid);
+        if (validMask == 0ull) continue;
+        const int leader = __ffsll((long long)validMask) - 1;
+        const int m0 = __shfl(m, leader);
+        if (__ballot(valid && m != m0) == 0ull) {
+            for (int a = 0; a < 6; a++) {
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+                    hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+                }
+            }
+            if ((int)(threadIdx.x & 63) == leader) {
+                uint32_t* dst = bounds + 12 * (size_t)m0;
+                for (int a = 0; a < 3; a++) {
+                    atomicMin(&dst[a], float_ordered(lo[a]));
+                    atomicMax(&dst[3 + a], float_ordered(hi[a]));
+                    atomicMin(&dst[6 + a], float_ordered(lo[3 + a]));
+                    atomicMax(&dst[9 + a], float_ordered(hi[3 + a]));
+                }
+            }
+        } else if (valid) {
+            uint32_t* dst = bounds + 12 * (size_t)m;
+            for (int a = 0; a < 3; a++) {
+                atomicMin(&dst[a], float_ordered(lo[a]));
+                atomicMax(&dst[3 + a], float_ordered(hi[a]));
+                atomicMin(&dst[6 + a], float_ordered(lo[3 + a]));
+                atomicMax(&dst[9 + a], float_ordered(hi[3 + a]));
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(kBlock) bounds_init_batch_kernel(uint32_t* __restrict__ bounds, const uint32_t meshCount)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < 12 * meshCount; k += gridDim.x * blockDim.x) bounds[k] = ((k % 6) < 3) ? 0xffffffffu : 0u;
+}
+
+// morton_kernel with every mesh's own centroid bounds
+__global__ void __launch_bounds__(kBlock) morton_batch_kernel(const Box3* __restrict__ triBox, const uint32_t n, const int* __restrict__ meshOf, const uint32_t* __restrict__ bounds,
+                                                              unsigned long long* __restrict__ codes, uint32_t* __restrict__ order)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t* sb = bounds + 12 * (size_t)meshOf[i];
+        const Box3 b = triBox[i];
+        uint32_t q[3];
+        for (int a = 0; a < 3; a++) {
+            const float lo = ordered_float(sb[a]);
+            const float ext = ordered_float(sb[3 + a]) - lo;
+            const float inv = ext > 0.0f ? 2097151.0f / ext : 0.0f;
+            q[a] = (uint32_t)fminf(fmaxf((0.5f * (b.lo[a] + b.hi[a]) - lo) * inv, 0.0f), 2097151.0f);
+        }
+        codes[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+        order[i] = i;
+    }
+}
+// second sort key: the mesh of the primitive at each position of the code-sorted order
+__global__ void __launch_bounds__(kBlock) mesh_key_kernel(const uint32_t* __restrict__ order, const int* __restrict__ meshOf, const uint32_t n, uint32_t* __restrict__ key)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) key[i] = (uint32_t)meshOf[order[i]];
+}
+
+// sah_root_kernel for every mesh of the forest: root segment `big`, binary-tree root `big`; small meshes: their single node
+__global__ void __launch_bounds__(kBlock) batch_roots_kernel(const BatchMesh* __restrict__ meshes, const uint32_t meshCount, const uint32_t* __restrict__ bounds,
+                                                             const Box3* __restrict__ triBox, Bvh2 t, SahSeg* __restrict__ segs, WorkItem* __restrict__ work,
+                                                             uint32_t* __restrict__ meshCounters, nx_bvh8_node* __restrict__ nodes, uint32_t* __restrict__ primIdx)
+{
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < meshCount; m += gridDim.x * blockDim.x) {
+        const BatchMesh bm = meshes[m];
+        if (bm.big < 0) {
+            // (triBox is still in input order here: position first + k is triangle k of the mesh)
+            small_mesh_node(triBox + bm.first, (int)bm.count, nodes + bm.first, primIdx + bm.first);
+            meshCounters[2 * (size_t)m] = 1u;
+            meshCounters[2 * (size_t)m + 1] = bm.count;
+            continue;
+        }
+        const uint32_t* sb = bounds + 12 * (size_t)m;
+        SahSeg sg{};
+        sg.first = (int)bm.first; sg.count = (int)bm.count; sg.node = bm.big;
+        for (int k = 0; k < 6; k++) sg.cb[k] = sb[k];
+        sg.child[0] = sg.child[1] = -1;
+        segs[bm.big] = sg;
+        Box3 b;
+        for (int a = 0; a < 3; a++) { b.lo[a] = ordered_float(sb[6 + a]); b.hi[a] = ordered_float(sb[9 + a]); }
+        t.box[bm.big] = b;
+        t.count[bm.big] = (int)bm.count;
+        t.parent[bm.big] = -1;
+        work[bm.big] = WorkItem{bm.big, 0u, m};
+        meshCounters[2 * (size_t)m] = 1u;      // node 0 is the root
+        meshCounters[2 * (size_t)m + 1] = 0u;
+    }
+}
+
+// the used nodes of every mesh from their staging places (nodes[first ...]) to their final, densely packed ones
+__global__ void __launch_bounds__(kBlock) batch_pack_nodes_kernel(const BatchMesh* __restrict__ meshes, const uint32_t* __restrict__ nodePrefix, const uint32_t* __restrict__ meshCounters,
+                                                                  const uint4* __restrict__ staging, uint4* __restrict__ packed)
+{
+    const uint32_t m = blockIdx.x;
+    const size_t chunks = 5 * (size_t)meshCounters[2 * (size_t)m];
+    const uint4* src = staging + 5 * (size_t)meshes[m].first;
+    uint4* dst = packed + 5 * (size_t)nodePrefix[m];
+    for (size_t k = threadIdx.x; k < chunks; k += blockDim.x) dst[k] = src[k];
+}
 
 // ---- 6. the traversal kernels' leaf-ordered intersection stream {p0 | id}, {e0}, {e1} (nxhip_upload_blas builds it on the host)
-__global__ void __launch_bounds__(kBlock) isect_kernel(const nx_triangle* __restrict__ tris, const uint32_t* __restrict__ primIdx, const uint32_t n, float4* __restrict__ isect)
+// (batched build: position k belongs to mesh meshOf[k], whose triangles start at meshes[...].first; the index stays mesh-local)
+__global__ void __launch_bounds__(kBlock) isect_kernel(const nx_triangle* __restrict__ tris, const uint32_t* __restrict__ primIdx, const uint32_t n, float4* __restrict__ isect,
+                                                       const int* __restrict__ meshOf, const BatchMesh* __restrict__ meshes)
 {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint32_t id = primIdx[k];
-        const nx_triangle t = tris[id];
+        const nx_triangle t = tris[(meshOf ? meshes[meshOf[k]].first : 0u) + id];
         isect[(size_t)kTriStride * k + 0] = make_float4(t.pos0[0], t.pos0[1], t.pos0[2], __uint_as_float(id));
         isect[(size_t)kTriStride * k + 1] = make_float4(t.pos1[0] - t.pos0[0], t.pos1[1] - t.pos0[1], t.pos1[2] - t.pos0[2], 0.0f);
         isect[(size_t)kTriStride * k + 2] = make_float4(t.pos2[0] - t.pos0[0], t.pos2[1] - t.pos0[1], t.pos2[2] - t.pos0[2], 0.0f);
@@ -1021,6 +1193,116 @@ __global__ void __launch_bounds__(kBlock) isect_kernel(const nx_triangle* __rest
 int grid_for(uint32_t n, int cus) { return (int)std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)(8 * cus)); }
 
 }  // namespace
+
+// Buffers of the top-down SAH build (4d) for n primitives in `roots` trees, and its level loop: from the root segments in
+// ws.segsA / ws.segOfA (sah_root_kernel, or batch_roots_kernel + batch_fill_kernel for a forest) and the primitives in idsA, to
+// the finished binary trees; *idsOut = the final order (position -> primitive).  Binary-tree nodes 0 .. roots - 1 are the roots.
+// Temporaries of one build carved out of ONE allocation (a batched build has some forty of them: forty hipFree calls, each a
+// device synchronisation, cost more than the build's kernels).  Used in two passes over the same list of take() calls: the first
+// (no block yet) only adds up the sizes, reserve() allocates, the second hands out the ranges.
+struct Arena {
+    std::shared_ptr<DevBuf> block;
+    size_t used = 0;
+    bool take(DevBuf& b, size_t bytes)
+    {
+        const size_t at = (used + 255) & ~(size_t)255;
+        used = at + std::max<size_t>(bytes, 16);
+        if (block) {
+            if (used > block->bytes) return false;
+            b = DevBuf::view(block, at, std::max<size_t>(bytes, 16));
+        }
+        return true;
+    }
+    bool reserve()
+    {
+        block = std::make_shared<DevBuf>();
+        const bool ok = block->alloc(used + 256);
+        used = 0;
+        return ok;
+    }
+};
+
+struct SahWorkspace {
+    DevBuf segOfA, segOfB, flag, scan, scanTemp, segsA, segsB, small, ctr, bins;
+    size_t maxSegs = 0, scanBytes = 0;
+    uint32_t nodesMade = 0;  // internal nodes of the finished trees (roots included)
+    // (arena == nullptr: buffers of their own)
+    bool alloc(uint32_t n, uint32_t roots, Arena* arena = nullptr)
+    {
+        maxSegs = (size_t)n / (kSahSmall + 1) + roots + 2;
+        const size_t binWords = (size_t)3 * kSahBins * kSahBinWords;
+        if (scanBytes == 0 && !hip_ok(rocprim::exclusive_scan(nullptr, scanBytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), nullptr), "rocprim::exclusive_scan", __FILE__, __LINE__))
+            return false;
+        auto get = [&](DevBuf& b, size_t bytes) { return arena ? arena->take(b, bytes) : b.alloc(bytes); };
+        return get(segOfA, (size_t)n * 4) && get(segOfB, (size_t)n * 4) && get(flag, (size_t)n * 4) && get(scan, (size_t)n * 4) && get(segsA, maxSegs * sizeof(SahSeg)) &&
+               get(segsB, maxSegs * sizeof(SahSeg)) && get(small, ((size_t)n / 2 + 2) * sizeof(SahSmall)) && get(ctr, sizeof(SahCounters)) && get(bins, maxSegs * binWords * 4) &&
+               get(scanTemp, std::max<size_t>(scanBytes, 16));
+    }
+};
+
+static int sah_levels(nxhip_ctx* c, const DevBuf& triBox, const uint32_t n, Bvh2 t, SahWorkspace& ws, int* idsA, int* idsB, const uint32_t roots, int** idsOut)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    const size_t binWords = (size_t)3 * kSahBins * kSahBinWords;
+    const SahCounters ctrInit{roots, 0u, 0u, 0u};  // the roots hold the first node numbers
+    NX_HIP(hipMemcpyAsync(ws.ctr.p, &ctrInit, sizeof ctrInit, hipMemcpyHostToDevice, st));
+    NX_HIP(hipStreamSynchronize(st));  // (ctrInit is a local: the copy has left it)
+    int *ids = idsA, *idsNext = idsB, *segOf = ws.segOfA.as<int>(), *segOfNext = ws.segOfB.as<int>();
+    SahSeg *segs = ws.segsA.as<SahSeg>(), *segsNext = ws.segsB.as<SahSeg>();
+    uint32_t segCount = roots, expectedNodes = 0;
+    SahCounters h{};
+    for (int level = 0; segCount > 0; level++) {
+        if (level > 4096 || segCount > ws.maxSegs) {
+            set_error("lbvh_build: the top-down build does not terminate");
+            return NXHIP_ERR_INVALID;
+        }
+        sah_bins_init_kernel<<<grid_for((uint32_t)std::min<size_t>(segCount * binWords, 0x7fffffffu), cus), kBlock, 0, st>>>(ws.bins.as<uint32_t>(), segCount * binWords);
+        sah_bin_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, ws.bins.as<uint32_t>());
+        sah_split_kernel<<<grid_for(segCount, cus), kBlock, 0, st>>>(segs, segCount, ws.bins.as<uint32_t>(), (int)n, t, segsNext, ws.small.as<SahSmall>(), ws.ctr.as<SahCounters>());
+        sah_flag_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, ws.flag.as<int>());
+        NX_HIP(rocprim::exclusive_scan(ws.scanTemp.p, ws.scanBytes, ws.flag.as<int>(), ws.scan.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
+        sah_scatter_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, ws.flag.as<int>(), ws.scan.as<int>(), idsNext, segOfNext, segsNext);
+        NX_HIP(hipMemcpyAsync(&h, ws.ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+        NX_HIP(hipStreamSynchronize(st));
+        segCount = h.nextCount;
+        NX_HIP(hipMemsetAsync(&ws.ctr.as<SahCounters>()->nextCount, 0, 4, st));
+        std::swap(ids, idsNext);
+        std::swap(segOf, segOfNext);
+        std::swap(segs, segsNext);
+    }
+    if (h.smallCount) sah_small_kernel<<<(int)std::min<uint32_t>((h.smallCount + 63) / 64, (uint32_t)(64 * cus)), 64, 0, st>>>(triBox.as<Box3>(), ids, ws.small.as<SahSmall>(), h.smallCount, (int)n, t, ws.ctr.as<SahCounters>());
+    sah_leaves_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, (int)n, t);
+    NX_HIP(hipMemcpyAsync(&h, ws.ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
+    NX_HIP(hipStreamSynchronize(st));
+    (void)expectedNodes;
+    *idsOut = ids;
+    ws.nodesMade = h.nodes;
+    return NXHIP_OK;
+}
+
+// The collapse's level loop: `workCount` work items (the roots) in workA, one launch per level of wide nodes.
+static int collapse_levels(nxhip_ctx* c, const Bvh2& t, const uint32_t n, const uint32_t* leafOrder, WorkItem* workA, WorkItem* workB, uint32_t workCount, uint32_t* meshCounters,
+                           uint32_t* workCounter, nx_bvh8_node* nodes, uint32_t* primIdx, const uint32_t nodeCapacity, const BatchMesh* meshes)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    WorkItem *cur = workA, *nxt = workB;
+    for (int level = 0; workCount > 0; level++) {
+        if (level > 128) {
+            set_error("lbvh_build: the collapse does not terminate");
+            return NXHIP_ERR_INVALID;
+        }
+        collapse_level_kernel<<<grid_for(workCount, cus), kBlock, 0, st>>>(t, (int)n, leafOrder, cur, workCount, nxt, meshCounters, workCounter, nodes, primIdx, nodeCapacity, meshes);
+        uint32_t next = 0;
+        NX_HIP(hipMemcpyAsync(&next, workCounter, 4, hipMemcpyDeviceToHost, st));
+        NX_HIP(hipStreamSynchronize(st));
+        workCount = next;
+        NX_HIP(hipMemsetAsync(workCounter, 0, 4, st));
+        std::swap(cur, nxt);
+    }
+    return NXHIP_OK;
+}
 
 // The build from primitive boxes on: Morton codes, sort, radix tree, bounds, collapse.  `triBox` / `bounds` (centroid bounds,
 // ordered-uint encoded) are on the device and filled by a kernel already queued on the stream.  primIdx: n entries.
@@ -1052,51 +1334,20 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     DevBuf sahIdsA, sahIdsB;
     if (plocRadius < 0) {
         // top-down binned SAH (4d), level by level
-        const size_t maxSegs = (size_t)n / (kSahSmall + 1) + 2, binWords = (size_t)3 * kSahBins * kSahBinWords;
-        DevBuf segOfA, segOfB, flag, scan, scanTemp, segsA, segsB, small, ctr, bins, rootBox;
-        if (!sahIdsA.alloc((size_t)n * 4) || !sahIdsB.alloc((size_t)n * 4) || !segOfA.alloc((size_t)n * 4) || !segOfB.alloc((size_t)n * 4) || !flag.alloc((size_t)n * 4) ||
-            !scan.alloc((size_t)n * 4) || !segsA.alloc(maxSegs * sizeof(SahSeg)) || !segsB.alloc(maxSegs * sizeof(SahSeg)) || !small.alloc(((size_t)n / 2 + 2) * sizeof(SahSmall)) ||
-            !ctr.alloc(sizeof(SahCounters)) || !bins.alloc(maxSegs * binWords * 4) || !rootBox.alloc(6 * 4)) return NXHIP_ERR_HIP;
-        size_t scanBytes = 0;
-        NX_HIP(rocprim::exclusive_scan(nullptr, scanBytes, flag.as<int>(), scan.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
-        if (!scanTemp.alloc(std::max<size_t>(scanBytes, 16))) return NXHIP_ERR_HIP;
+        SahWorkspace ws;
+        if (!sahIdsA.alloc((size_t)n * 4) || !sahIdsB.alloc((size_t)n * 4) || !ws.alloc(n, 1)) return NXHIP_ERR_HIP;
+        DevBuf rootBox;
+        if (!rootBox.alloc(6 * 4)) return NXHIP_ERR_HIP;
         const uint32_t boxInit[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-        const SahCounters ctrInit{1u, 0u, 0u, 0u};
         NX_HIP(hipMemcpyAsync(rootBox.p, boxInit, sizeof boxInit, hipMemcpyHostToDevice, st));
-        NX_HIP(hipMemcpyAsync(ctr.p, &ctrInit, sizeof ctrInit, hipMemcpyHostToDevice, st));
         NX_HIP(hipMemcpyAsync(sahIdsA.p, orderSorted.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));  // start from the Morton order: neighbours in memory are neighbours in space
         box_union_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), n, rootBox.as<uint32_t>());
-        int *ids = sahIdsA.as<int>(), *idsNext = sahIdsB.as<int>(), *segOf = segOfA.as<int>(), *segOfNext = segOfB.as<int>();
-        SahSeg *segs = segsA.as<SahSeg>(), *segsNext = segsB.as<SahSeg>();
-        sah_root_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(bounds.as<uint32_t>(), rootBox.as<uint32_t>(), (int)n, t, segs, segOf);
-        uint32_t segCount = 1;
-        SahCounters h{};
-        for (int level = 0; segCount > 0; level++) {
-            if (level > 4096 || segCount > maxSegs) {
-                set_error("lbvh_build: the top-down build does not terminate");
-                return NXHIP_ERR_INVALID;
-            }
-            sah_bins_init_kernel<<<grid_for((uint32_t)std::min<size_t>(segCount * binWords, 0x7fffffffu), cus), kBlock, 0, st>>>(bins.as<uint32_t>(), segCount * binWords);
-            sah_bin_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, bins.as<uint32_t>());
-            sah_split_kernel<<<grid_for(segCount, cus), kBlock, 0, st>>>(segs, segCount, bins.as<uint32_t>(), (int)n, t, segsNext, small.as<SahSmall>(), ctr.as<SahCounters>());
-            sah_flag_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, flag.as<int>());
-            NX_HIP(rocprim::exclusive_scan(scanTemp.p, scanBytes, flag.as<int>(), scan.as<int>(), 0, (size_t)n, rocprim::plus<int>(), st));
-            sah_scatter_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, segOf, (int)n, segs, flag.as<int>(), scan.as<int>(), idsNext, segOfNext, segsNext);
-            NX_HIP(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
-            NX_HIP(hipStreamSynchronize(st));
-            segCount = h.nextCount;
-            const uint32_t zero = 0;
-            NX_HIP(hipMemcpyAsync(&ctr.as<SahCounters>()->nextCount, &zero, 4, hipMemcpyHostToDevice, st));
-            std::swap(ids, idsNext);
-            std::swap(segOf, segOfNext);
-            std::swap(segs, segsNext);
-        }
-        if (h.smallCount) sah_small_kernel<<<(int)std::min<uint32_t>((h.smallCount + 63) / 64, (uint32_t)(64 * cus)), 64, 0, st>>>(triBox.as<Box3>(), ids, small.as<SahSmall>(), h.smallCount, (int)n, t, ctr.as<SahCounters>());
-        sah_leaves_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), ids, (int)n, t);
-        NX_HIP(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, st));
-        NX_HIP(hipStreamSynchronize(st));
-        if (h.nodes != n - 1) {
-            set_error("lbvh_build: the top-down build made " + std::to_string(h.nodes) + " internal nodes for " + std::to_string(n) + " primitives");
+        sah_root_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(bounds.as<uint32_t>(), rootBox.as<uint32_t>(), (int)n, t, ws.segsA.as<SahSeg>(), ws.segOfA.as<int>());
+        int* ids = nullptr;
+        const int rcLevels = sah_levels(c, triBox, n, t, ws, sahIdsA.as<int>(), sahIdsB.as<int>(), 1u, &ids);
+        if (rcLevels != NXHIP_OK) return rcLevels;
+        if (ws.nodesMade != n - 1) {
+            set_error("lbvh_build: the top-down build made " + std::to_string(ws.nodesMade) + " internal nodes for " + std::to_string(n) + " primitives");
             return NXHIP_ERR_INVALID;
         }
         leafOrder = reinterpret_cast<const uint32_t*>(ids);
@@ -1160,34 +1411,21 @@ static int lbvh_from_boxes(nxhip_ctx* c, const DevBuf& triBox, const DevBuf& bou
     if (!nodes.alloc((size_t)nodeCapacity * sizeof(nx_bvh8_node)) || !workA.alloc((size_t)nodeCapacity * sizeof(WorkItem)) || !workB.alloc((size_t)nodeCapacity * sizeof(WorkItem)) ||
         !counters.alloc(3 * 4)) return NXHIP_ERR_HIP;
     {
-        const uint32_t init[3] = {1u, 0u, 0u};  // node 0 is the root
-        const WorkItem root{0, 0u};
+        static const uint32_t init[3] = {1u, 0u, 0u};  // node 0 is the root
+        static const WorkItem root{0, 0u, 0u};
         NX_HIP(hipMemcpyAsync(counters.p, init, sizeof init, hipMemcpyHostToDevice, st));
         NX_HIP(hipMemcpyAsync(workA.p, &root, sizeof root, hipMemcpyHostToDevice, st));
     }
-    uint32_t workCount = 1;
-    WorkItem* cur = workA.as<WorkItem>();
-    WorkItem* nxt = workB.as<WorkItem>();
-    for (int level = 0; workCount > 0; level++) {
-        if (level > 128) {
-            set_error("lbvh_build: the collapse does not terminate");
-            return NXHIP_ERR_INVALID;
-        }
-        collapse_level_kernel<<<grid_for(workCount, cus), kBlock, 0, st>>>(t, (int)n, leafOrder, cur, workCount, nxt, counters.as<uint32_t>(), nodes.as<nx_bvh8_node>(),
-                                                                           primIdx.as<uint32_t>(), nodeCapacity);
-        uint32_t h[3];
-        NX_HIP(hipMemcpyAsync(h, counters.p, sizeof h, hipMemcpyDeviceToHost, st));
-        NX_HIP(hipStreamSynchronize(st));
-        if (h[0] > nodeCapacity) {
-            set_error("lbvh_build: node capacity exceeded");
-            return NXHIP_ERR_INVALID;
-        }
-        workCount = h[2];
-        *nodeCount = h[0];
-        const uint32_t zero = 0;
-        NX_HIP(hipMemcpyAsync(counters.as<uint32_t>() + 2, &zero, 4, hipMemcpyHostToDevice, st));
-        std::swap(cur, nxt);
+    const int rcCollapse = collapse_levels(c, t, n, leafOrder, workA.as<WorkItem>(), workB.as<WorkItem>(), 1u, counters.as<uint32_t>(), counters.as<uint32_t>() + 2, nodes.as<nx_bvh8_node>(),
+                                           primIdx.as<uint32_t>(), nodeCapacity, nullptr);
+    if (rcCollapse != NXHIP_OK) return rcCollapse;
+    uint32_t used = 0;
+    NX_HIP(hipMemcpy(&used, counters.p, 4, hipMemcpyDeviceToHost));
+    if (used > nodeCapacity) {
+        set_error("lbvh_build: node capacity exceeded");
+        return NXHIP_ERR_INVALID;
     }
+    *nodeCount = used;
     return NXHIP_OK;
 }
 
@@ -1207,7 +1445,7 @@ int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadiu
         if (const char* e = std::getenv("NX_BLAS_PRIM_COST")) primCost = (float)std::atof(e);  // sweeps only
     const int rc = lbvh_from_boxes(c, triBox, bounds, n, plocRadius, primCost, nodes, primIdx, nodeCount);
     if (rc != NXHIP_OK) return rc;
-    isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>());
+    isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>(), nullptr, nullptr);
     NX_HIP(hipStreamSynchronize(st));
     NX_HIP(hipGetLastError());
     return NXHIP_OK;
@@ -1236,6 +1474,133 @@ int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n,
     if (rc != NXHIP_OK) return rc;
     NX_HIP(hipStreamSynchronize(st));
     NX_HIP(hipGetLastError());
+    return NXHIP_OK;
+}
+
+// M meshes in ONE build (nxhip_build_blas_batch).  The reference makes one BVH8 per aiMesh (Assets/OBJLoader.cpp:213-239,
+// Assets/AssetManager.cpp:23-37): a glTF scene is thousands of small meshes, and one build per mesh pays its ~25 level
+// synchronisations and its allocations every time.  Here the meshes are a FOREST over the concatenated triangles: per-mesh
+// centroid bounds and Morton codes, a stable sort by code and then by mesh (each mesh keeps the order its own build would start
+// from), one root segment and one root per mesh, and then the single build's level loops — binning, split, partition; cost
+// table; collapse — over all meshes at once: the level count is the deepest mesh's, not the sum.  Meshes of at most eight
+// triangles are a single node, as in the single build.  Every mesh gets its own node numbers and its own primitive list
+// (mesh-local indices).  What comes back: pooled arrays — nodes (packed, mesh after mesh), primIdx and isect (positions of the
+// concatenation) — and per mesh the first node and the node count.  Top-down SAH only (the default builder).
+int lbvh_build_batch(nxhip_ctx* c, const nx_triangle* dTris, const std::vector<uint32_t>& counts, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, std::vector<uint32_t>& nodeFirst,
+                     std::vector<uint32_t>& nodeCounts)
+{
+    hipStream_t st = c->stream;
+    const int cus = std::max(1, c->numCUs);
+    const bool timing = std::getenv("NX_TUNING_KNOBS") && std::atoi(std::getenv("NX_TUNING_KNOBS")) == 1 && std::getenv("NX_BATCH_TIMING");
+    auto tLap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[lbvh_build_batch]       %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tLap).count());
+        tLap = t1;
+    };
+    const uint32_t M = (uint32_t)counts.size();
+    std::vector<BatchMesh> meshes(M);
+    uint64_t total = 0;
+    uint32_t big = 0;
+    for (uint32_t m = 0; m < M; m++) {
+        meshes[m] = BatchMesh{(uint32_t)total, counts[m], counts[m] > 8u ? (int)big++ : -1, 0u};
+        total += counts[m];
+    }
+    if (total > 0x7fffffffull) {
+        set_error("nxhip_build_blas_batch: more than 2^31 triangles in one batch");
+        return NXHIP_ERR_INVALID;
+    }
+    const uint32_t n = (uint32_t)total;
+    DevBuf dMeshes, meshOf, triBox, bounds, staging, meshCounters, workCounter;
+    DevBuf codes, codesSorted, order, orderSorted, meshKey, meshKeySorted, idsA, idsB, sortTemp;
+    DevBuf left, right, parent, count, box, arrived, evals, workA, workB, prefix;
+    SahWorkspace ws;
+    int meshBits = 1;
+    while ((1ull << meshBits) < (unsigned long long)M) meshBits++;
+    size_t tempA = 0, tempB = 0;
+    NX_HIP(rocprim::radix_sort_pairs(nullptr, tempA, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, st));
+    NX_HIP(rocprim::radix_sort_pairs(nullptr, tempB, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, meshBits, st));
+    const size_t inner = (size_t)std::max(n, 2u) - 1, all = 2 * (size_t)std::max(n, 2u) - 1;
+    // every temporary of the build from one allocation (Arena): sizes first, then the ranges
+    Arena arena;
+    auto layout = [&]() {
+        return arena.take(dMeshes, (size_t)M * sizeof(BatchMesh)) && arena.take(meshOf, (size_t)n * 4) && arena.take(triBox, (size_t)n * sizeof(Box3)) && arena.take(bounds, (size_t)M * 12 * 4) &&
+               arena.take(staging, (size_t)n * sizeof(nx_bvh8_node)) && arena.take(meshCounters, (size_t)M * 2 * 4) && arena.take(workCounter, 4) && ws.alloc(n, std::max(1u, big), &arena) &&
+               arena.take(codes, (size_t)n * 8) && arena.take(codesSorted, (size_t)n * 8) && arena.take(order, (size_t)n * 4) && arena.take(orderSorted, (size_t)n * 4) &&
+               arena.take(meshKey, (size_t)n * 4) && arena.take(meshKeySorted, (size_t)n * 4) && arena.take(idsA, (size_t)n * 4) && arena.take(idsB, (size_t)n * 4) &&
+               arena.take(sortTemp, std::max<size_t>(std::max(tempA, tempB), 16)) && arena.take(left, inner * 4) && arena.take(right, inner * 4) && arena.take(parent, all * 4) &&
+               arena.take(count, inner * 4) && arena.take(box, all * sizeof(Box3)) && arena.take(arrived, inner * 4) && arena.take(evals, inner * 7 * sizeof(Eval)) &&
+               arena.take(workA, (size_t)n * sizeof(WorkItem)) && arena.take(workB, (size_t)n * sizeof(WorkItem)) && arena.take(prefix, (size_t)M * 4);
+    };
+    if (!layout() || !arena.reserve() || !layout()) return NXHIP_ERR_HIP;
+    if (!primIdx.alloc((size_t)n * 4) || !isect.alloc((size_t)n * kTriStride * sizeof(float4))) return NXHIP_ERR_HIP;
+    lap("allocations (1)");
+    NX_HIP(hipMemcpyAsync(dMeshes.p, meshes.data(), (size_t)M * sizeof(BatchMesh), hipMemcpyHostToDevice, st));  // (`meshes` outlives the synchronisations below)
+    batch_fill_kernel<<<M, kBlock, 0, st>>>(dMeshes.as<BatchMesh>(), meshOf.as<int>(), ws.segOfA.as<int>());
+    bounds_init_batch_kernel<<<grid_for(12 * M, cus), kBlock, 0, st>>>(bounds.as<uint32_t>(), M);
+    tri_bounds_batch_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, n, meshOf.as<int>(), triBox.as<Box3>(), bounds.as<uint32_t>());
+
+    lap("boxes and bounds");
+    // the order every mesh's own build would start from: its triangles by Morton code (a stable sort by code, then by mesh)
+    morton_batch_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(triBox.as<Box3>(), n, meshOf.as<int>(), bounds.as<uint32_t>(), codes.as<unsigned long long>(), order.as<uint32_t>());
+    NX_HIP(rocprim::radix_sort_pairs(sortTemp.p, tempA, codes.as<unsigned long long>(), codesSorted.as<unsigned long long>(), order.as<uint32_t>(), orderSorted.as<uint32_t>(), n, 0, 63, st));
+    mesh_key_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(orderSorted.as<uint32_t>(), meshOf.as<int>(), n, meshKey.as<uint32_t>());
+    NX_HIP(rocprim::radix_sort_pairs(sortTemp.p, tempB, meshKey.as<uint32_t>(), meshKeySorted.as<uint32_t>(), orderSorted.as<uint32_t>(), idsA.as<uint32_t>(), n, 0, meshBits, st));
+
+    lap("Morton codes, two sorts (+ allocations)");
+    // the forest
+    Bvh2 t{left.as<int>(), right.as<int>(), parent.as<int>(), nullptr, nullptr, count.as<int>(), box.as<Box3>(), arrived.as<int>(), evals.as<Eval>(), kCostPrim};
+    NX_HIP(hipMemsetAsync(parent.p, 0xff, all * 4, st));  // -1: the triangles of small meshes hang under no tree
+    NX_HIP(hipMemsetAsync(workCounter.p, 0, 4, st));
+    batch_roots_kernel<<<grid_for(M, cus), kBlock, 0, st>>>(dMeshes.as<BatchMesh>(), M, bounds.as<uint32_t>(), triBox.as<Box3>(), t, ws.segsA.as<SahSeg>(), workA.as<WorkItem>(),
+                                                            meshCounters.as<uint32_t>(), staging.as<nx_bvh8_node>(), primIdx.as<uint32_t>());
+    uint64_t bigPrims = 0;
+    for (const BatchMesh& m : meshes) bigPrims += m.big >= 0 ? m.count : 0u;
+    lap("roots (+ allocations)");
+    if (big) {
+        int* ids = nullptr;
+        int rc = sah_levels(c, triBox, n, t, ws, idsA.as<int>(), idsB.as<int>(), big, &ids);
+        if (rc != NXHIP_OK) return rc;
+        lap("binary trees: SAH levels");
+        if ((uint64_t)ws.nodesMade != bigPrims - big) {
+            set_error("nxhip_build_blas_batch: the top-down build made " + std::to_string(ws.nodesMade) + " internal nodes for " + std::to_string(bigPrims) + " triangles in " + std::to_string(big) + " meshes");
+            return NXHIP_ERR_INVALID;
+        }
+        NX_HIP(hipMemsetAsync(arrived.p, 0, inner * 4, st));
+        cost_kernel<<<grid_for(n, cus), kBlock, 0, st>>>((int)n, t);
+        lap("cost table");
+        rc = collapse_levels(c, t, n, reinterpret_cast<const uint32_t*>(ids), workA.as<WorkItem>(), workB.as<WorkItem>(), big, meshCounters.as<uint32_t>(), workCounter.as<uint32_t>(),
+                             staging.as<nx_bvh8_node>(), primIdx.as<uint32_t>(), 0u, dMeshes.as<BatchMesh>());
+        if (rc != NXHIP_OK) return rc;
+        lap("collapse levels");
+    }
+    isect_kernel<<<grid_for(n, cus), kBlock, 0, st>>>(dTris, primIdx.as<uint32_t>(), n, isect.as<float4>(), meshOf.as<int>(), dMeshes.as<BatchMesh>());
+
+    // pack the nodes: every mesh's used nodes, mesh after mesh
+    std::vector<uint32_t> ctr((size_t)M * 2);
+    NX_HIP(hipMemcpyAsync(ctr.data(), meshCounters.p, ctr.size() * 4, hipMemcpyDeviceToHost, st));
+    NX_HIP(hipStreamSynchronize(st));
+    nodeFirst.assign(M, 0u);
+    nodeCounts.assign(M, 0u);
+    uint64_t nodeTotal = 0;
+    for (uint32_t m = 0; m < M; m++) {
+        if (ctr[2 * (size_t)m] > counts[m] || ctr[2 * (size_t)m + 1] != counts[m]) {
+            set_error("nxhip_build_blas_batch: mesh " + std::to_string(m) + " came out with " + std::to_string(ctr[2 * (size_t)m]) + " nodes and " + std::to_string(ctr[2 * (size_t)m + 1]) + " of its " +
+                      std::to_string(counts[m]) + " triangles");
+            return NXHIP_ERR_INVALID;
+        }
+        nodeFirst[m] = (uint32_t)nodeTotal;
+        nodeCounts[m] = ctr[2 * (size_t)m];
+        nodeTotal += nodeCounts[m];
+    }
+    if (!nodes.alloc((size_t)nodeTotal * sizeof(nx_bvh8_node))) return NXHIP_ERR_HIP;
+    NX_HIP(hipMemcpyAsync(prefix.p, nodeFirst.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+    batch_pack_nodes_kernel<<<M, kBlock, 0, st>>>(dMeshes.as<BatchMesh>(), prefix.as<uint32_t>(), meshCounters.as<uint32_t>(), staging.as<uint4>(), nodes.as<uint4>());
+    NX_HIP(hipStreamSynchronize(st));
+    NX_HIP(hipGetLastError());
+    lap("intersection stream, node packing");
     return NXHIP_OK;
 }
 

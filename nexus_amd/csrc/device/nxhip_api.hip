@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,6 +34,8 @@ const void* tex2d_hook_kernel_ptr();
 const void* instance_transform_kernel_ptr();
 const void* tlas_refit_kernel_ptr();
 int lbvh_build(nxhip_ctx* c, const nx_triangle* dTris, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, uint32_t* nodeCount);
+int lbvh_build_batch(nxhip_ctx* c, const nx_triangle* dTris, const std::vector<uint32_t>& counts, DevBuf& nodes, DevBuf& primIdx, DevBuf& isect, std::vector<uint32_t>& nodeFirst,
+                     std::vector<uint32_t>& nodeCounts);
 int lbvh_build_tlas(nxhip_ctx* c, const nx_bvh_instance* dInstances, uint32_t n, int plocRadius, DevBuf& nodes, DevBuf& primIdx, DevBuf& box, bool* boxesAreTight, uint32_t* nodeCount);
 
 static thread_local std::string g_lastError;
@@ -485,6 +488,9 @@ void nxhip_destroy(nxhip_ctx* c)
     }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->hostStaging) (void)hipHostFree(c->hostStaging);
+    for (hipEvent_t e : c->stagingDone)
+        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -758,6 +764,159 @@ try {
 } catch (const std::exception& e) {  // nothing may unwind through the C boundary
     set_error(std::string("nxhip_build_blas: ") + e.what());
     return NXHIP_ERR_INVALID;
+}
+
+int nxhip_build_blas_batch(nxhip_ctx* c, const nx_triangle* const* tris, const uint32_t* triCounts, uint32_t meshCount, int32_t* blasIds)
+try {
+    NX_CHECK_CTX(c);
+    if (!tris || !triCounts || meshCount == 0) return fail_invalid("nxhip_build_blas_batch: empty input");
+    if (kNodeStride != 5) return fail_invalid("nxhip_build_blas_batch: built with padded node records");
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < meshCount; m++) {
+        if (!tris[m] || triCounts[m] == 0) return fail_invalid("nxhip_build_blas_batch: a mesh without triangles");
+        total += triCounts[m];
+    }
+    if (total > 0x7fffffffull) return fail_invalid("nxhip_build_blas_batch: more than 2^31 triangles in one batch");
+    if (c->deviceBuilderRadius != NXHIP_BUILDER_SAH || meshCount == 1) {
+        // the other builders (radix tree, clustering) have no forest form: one build per mesh
+        for (uint32_t m = 0; m < meshCount; m++) {
+            int32_t id = -1;
+            const int rc = nxhip_build_blas(c, tris[m], triCounts[m], &id);
+            if (rc != NXHIP_OK) return rc;
+            if (blasIds) blasIds[m] = id;
+        }
+        return NXHIP_OK;
+    }
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    // NX_TUNING_KNOBS=1 NX_BATCH_TIMING=1: where the call's time goes, to stderr (tools / tests only)
+    const bool timing = std::getenv("NX_TUNING_KNOBS") && std::atoi(std::getenv("NX_TUNING_KNOBS")) == 1 && std::getenv("NX_BATCH_TIMING");
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t0) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t1 = now();
+        std::fprintf(stderr, "[nxhip_build_blas_batch] %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    auto tLap = now();
+    // the triangles of all meshes, concatenated, through a pinned staging buffer the context keeps (one transfer instead of one
+    // per mesh)
+    const size_t bytes = (size_t)total * sizeof(nx_triangle);
+    constexpr size_t kHalf = (size_t)16 << 20;  // two halves of a 32 MiB pinned buffer, allocated once per context: a staging buffer
+                                                // as large as the batch would cost more to pin than the transfer takes
+    if (!c->hostStaging) {
+        NX_HIP(hipHostMalloc(&c->hostStaging, 2 * kHalf, hipHostMallocDefault));
+        c->hostStagingBytes = 2 * kHalf;
+        NX_HIP(hipEventCreateWithFlags(&c->stagingDone[0], hipEventDisableTiming));
+        NX_HIP(hipEventCreateWithFlags(&c->stagingDone[1], hipEventDisableTiming));
+    }
+    std::vector<uint32_t> counts(triCounts, triCounts + meshCount);
+    auto trisPool = std::make_shared<DevBuf>();
+    auto nodesPool = std::make_shared<DevBuf>(), idxPool = std::make_shared<DevBuf>(), isectPool = std::make_shared<DevBuf>();
+    if (!trisPool->alloc(bytes)) return NXHIP_ERR_HIP;
+    {
+        // the meshes as one byte stream through the two halves: while one half is on its way to the device the other is filled
+        size_t sent = 0, inHalf = 0;
+        int half = 0;
+        bool used[2] = {false, false};
+        char* const base = static_cast<char*>(c->hostStaging);
+        auto flush = [&]() -> int {
+            if (inHalf == 0) return NXHIP_OK;
+            NX_HIP(hipMemcpyAsync(static_cast<char*>(trisPool->p) + sent, base + (size_t)half * kHalf, inHalf, hipMemcpyHostToDevice, c->stream));
+            NX_HIP(hipEventRecord(c->stagingDone[half], c->stream));
+            used[half] = true;
+            sent += inHalf;
+            inHalf = 0;
+            half ^= 1;
+            if (used[half]) NX_HIP(hipEventSynchronize(c->stagingDone[half]));  // the half about to be refilled has left
+            return NXHIP_OK;
+        };
+        for (uint32_t m = 0; m < meshCount; m++) {
+            const char* src = reinterpret_cast<const char*>(tris[m]);
+            size_t left = (size_t)counts[m] * sizeof(nx_triangle);
+            while (left) {
+                const size_t take = std::min(left, kHalf - inHalf);
+                std::memcpy(base + (size_t)half * kHalf + inHalf, src, take);
+                inHalf += take;
+                src += take;
+                left -= take;
+                if (inHalf == kHalf)
+                    if (const int rcf = flush()) return rcf;
+            }
+        }
+        if (const int rcf = flush()) return rcf;
+    }
+    std::vector<uint32_t> nodeFirst, nodeCounts;
+    lap("triangles through pinned staging", tLap);
+    const int rc = lbvh_build_batch(c, trisPool->as<nx_triangle>(), counts, *nodesPool, *idxPool, *isectPool, nodeFirst, nodeCounts);
+    if (rc != NXHIP_OK) return rc;
+    lap("device build", tLap);
+    // every mesh's root node, for the instance records (refresh_inst_trav would otherwise fetch them one by one)
+    std::vector<nx_bvh8_node> allNodes(nodesPool->bytes / sizeof(nx_bvh8_node));
+    NX_HIP(hipMemcpy(allNodes.data(), nodesPool->p, allNodes.size() * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+    size_t first = 0;
+    for (uint32_t m = 0; m < meshCount; m++) {
+        BlasHost b;
+        b.triCount = counts[m];
+        b.nodeCount = nodeCounts[m];
+        b.nodes = DevBuf::view(nodesPool, (size_t)nodeFirst[m] * sizeof(nx_bvh8_node), (size_t)nodeCounts[m] * sizeof(nx_bvh8_node));
+        b.isect = DevBuf::view(isectPool, first * kTriStride * sizeof(float4), (size_t)counts[m] * kTriStride * sizeof(float4));
+        b.tris = DevBuf::view(trisPool, first * sizeof(nx_triangle), (size_t)counts[m] * sizeof(nx_triangle));
+        b.triIdx = DevBuf::view(idxPool, first * 4, (size_t)counts[m] * 4);
+        std::memcpy(b.root, &allNodes[nodeFirst[m]], sizeof b.root);
+        b.rootKnown = true;
+        if (const int rcs = make_shade_tris(b)) return rcs;
+        c->blas.push_back(std::move(b));
+        if (blasIds) blasIds[m] = (int32_t)c->blas.size() - 1;
+        first += counts[m];
+    }
+    lap("roots read back, BLAS records", tLap);
+    const int rcTable = refresh_blas_table(c);
+    lap("BLAS table", tLap);
+    return rcTable;
+} catch (const std::exception& e) {  // nothing may unwind through the C boundary
+    set_error(std::string("nxhip_build_blas_batch: ") + e.what());
+    return NXHIP_ERR_INVALID;
+}
+
+int nxhip_read_blas_batch(nxhip_ctx* c, int32_t firstBlasId, uint32_t count, nx_bvh8_node* nodes, uint32_t nodeCapacity, uint32_t* nodeCounts, uint32_t* primIdx, uint32_t primCapacity)
+{
+    NX_CHECK_CTX(c);
+    if (firstBlasId < 0 || (size_t)firstBlasId + count > c->blas.size()) return fail_invalid("nxhip_read_blas_batch: no such BLAS range");
+    if (count == 0) return NXHIP_OK;
+    if (kNodeStride != 5) return fail_invalid("nxhip_read_blas_batch: built with padded node records");
+    uint64_t nodeTotal = 0, primTotal = 0;
+    bool oneRun = true;  // the BLASes of one nxhip_build_blas_batch call lie back to back in their pools: one copy each for nodes and indices
+    for (uint32_t k = 0; k < count; k++) {
+        const BlasHost& b = c->blas[(size_t)firstBlasId + k];
+        if (nodeCounts) nodeCounts[k] = b.nodeCount;
+        if (k) {
+            const BlasHost& a = c->blas[(size_t)firstBlasId + k - 1];
+            oneRun = oneRun && a.nodes.pool && a.nodes.pool == b.nodes.pool && static_cast<char*>(a.nodes.p) + a.nodes.bytes == b.nodes.p &&
+                     a.triIdx.pool == b.triIdx.pool && static_cast<char*>(a.triIdx.p) + a.triIdx.bytes == b.triIdx.p;
+        }
+        nodeTotal += b.nodeCount;
+        primTotal += b.triCount;
+    }
+    if ((nodes && nodeCapacity < nodeTotal) || (primIdx && primCapacity < primTotal)) return fail_invalid("nxhip_read_blas_batch: destination too small");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    const BlasHost& b0 = c->blas[(size_t)firstBlasId];
+    if (oneRun) {
+        if (nodes) NX_HIP(hipMemcpy(nodes, b0.nodes.p, (size_t)nodeTotal * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+        if (primIdx) NX_HIP(hipMemcpy(primIdx, b0.triIdx.p, (size_t)primTotal * 4, hipMemcpyDeviceToHost));
+        return NXHIP_OK;
+    }
+    size_t nodeAt = 0, primAt = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const BlasHost& b = c->blas[(size_t)firstBlasId + k];
+        if (nodes) NX_HIP(hipMemcpy(nodes + nodeAt, b.nodes.p, (size_t)b.nodeCount * sizeof(nx_bvh8_node), hipMemcpyDeviceToHost));
+        if (primIdx) NX_HIP(hipMemcpy(primIdx + primAt, b.triIdx.p, (size_t)b.triCount * 4, hipMemcpyDeviceToHost));
+        nodeAt += b.nodeCount;
+        primAt += b.triCount;
+    }
+    return NXHIP_OK;
 }
 
 int nxhip_set_device_builder(nxhip_ctx* c, int clusteringRadius)

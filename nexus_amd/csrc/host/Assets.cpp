@@ -29,6 +29,18 @@ int32_t AssetManager::CreateBVH(const std::vector<Triangle>& triangles)
     return static_cast<int32_t>(m_Bvhs.size()) - 1;
 }
 
+int32_t AssetManager::CreateBVHs(const std::vector<std::vector<Triangle>>& meshes)
+{
+    const int32_t first = static_cast<int32_t>(m_Bvhs.size());
+    if (m_BlasBatchBuilder && meshes.size() > 1) {
+        std::vector<BVH8> built = m_BlasBatchBuilder(meshes, m_Bvhs.size());
+        for (BVH8& b : built) m_Bvhs.push_back(std::move(b));
+    } else {
+        for (const std::vector<Triangle>& m : meshes) CreateBVH(m);
+    }
+    return first;
+}
+
 int32_t AssetManager::AddMesh(Mesh&& mesh)
 {
     m_Meshes.push_back(std::move(mesh));

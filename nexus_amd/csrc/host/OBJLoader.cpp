@@ -635,11 +635,10 @@ void OBJLoader::LoadOBJ(const std::string& path, const std::string& filename, Sc
         if (ls.materialEmissiveTexture[i] >= 0) m.emissiveMapId = textureIds[static_cast<size_t>(ls.materialEmissiveTexture[i])];
         assetManager->AddMaterial(m);
     }
+    // one BVH8 per mesh of the file (OBJLoader.cpp:213-239) — created together, so that a device builder can build them in one go
     std::vector<int32_t> meshIds;
-    for (size_t i = 0; i < ls.meshes.size(); i++) {
-        const int32_t bvhId = assetManager->CreateBVH(ls.meshes[i]);
-        meshIds.push_back(assetManager->AddMesh(Mesh(ls.meshNames[i], bvhId, -1)));
-    }
+    const int32_t firstBvh = assetManager->CreateBVHs(ls.meshes);
+    for (size_t i = 0; i < ls.meshes.size(); i++) meshIds.push_back(assetManager->AddMesh(Mesh(ls.meshNames[i], firstBvh + static_cast<int32_t>(i), -1)));
     for (const LoadedInstance& inst : ls.instances) {
         MeshInstance& mi = scene->CreateMeshInstance(static_cast<uint32_t>(meshIds[static_cast<size_t>(inst.mesh)]));
         mi.name = inst.name.empty() ? ls.meshNames[static_cast<size_t>(inst.mesh)] : inst.name;

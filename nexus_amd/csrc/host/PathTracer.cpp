@@ -77,8 +77,51 @@ void PathTracer::SetDeviceBlasBuild(Scene& scene, bool enable)
     AssetManager& assets = scene.GetAssetManager();
     if (!enable) {
         assets.SetBlasBuilder(nullptr);
+        assets.SetBlasBatchBuilder(nullptr);
         return;
     }
+    // all meshes of a file in one device build (nxhip_build_blas_batch), the trees back in one transfer
+    assets.SetBlasBatchBuilder([this, &assets](const std::vector<std::vector<Triangle>>& meshes, size_t firstIndex) {
+        UploadPendingBlas(assets);
+        if (assets.uploadedBvhs == 0) Check(nxhip_clear_blas(m_Ctx), "nxhip_clear_blas");
+        std::vector<std::vector<nx_triangle>> dev(meshes.size());
+        std::vector<const nx_triangle*> ptrs(meshes.size());
+        std::vector<uint32_t> counts(meshes.size());
+        size_t triTotal = 0;
+        for (size_t m = 0; m < meshes.size(); m++) {
+            dev[m].resize(meshes[m].size());
+            for (size_t t = 0; t < dev[m].size(); t++) dev[m][t] = Triangle::ToDevice(meshes[m][t]);
+            ptrs[m] = dev[m].data();
+            counts[m] = static_cast<uint32_t>(dev[m].size());
+            triTotal += dev[m].size();
+        }
+        std::vector<int32_t> ids(meshes.size(), -1);
+        Check(nxhip_build_blas_batch(m_Ctx, ptrs.data(), counts.data(), static_cast<uint32_t>(meshes.size()), ids.data()), "nxhip_build_blas_batch");
+        for (size_t m = 0; m < meshes.size(); m++)
+            if (ids[m] != static_cast<int32_t>(firstIndex + m)) throw std::runtime_error("PathTracer: the device's BLAS ids and the asset manager's BVH ids have diverged");
+        std::vector<uint32_t> nodeCounts(meshes.size(), 0u);
+        Check(nxhip_read_blas_batch(m_Ctx, ids[0], static_cast<uint32_t>(meshes.size()), nullptr, 0, nodeCounts.data(), nullptr, 0), "nxhip_read_blas_batch");
+        size_t nodeTotal = 0;
+        for (uint32_t n : nodeCounts) nodeTotal += n;
+        std::vector<BVH8Node> nodes(nodeTotal);
+        std::vector<uint32_t> idx(triTotal);
+        Check(nxhip_read_blas_batch(m_Ctx, ids[0], static_cast<uint32_t>(meshes.size()), nodes.data(), static_cast<uint32_t>(nodeTotal), nodeCounts.data(), idx.data(),
+                                    static_cast<uint32_t>(triTotal)), "nxhip_read_blas_batch");
+        std::vector<BVH8> out;
+        out.reserve(meshes.size());
+        size_t nodeAt = 0, triAt = 0;
+        for (size_t m = 0; m < meshes.size(); m++) {
+            BVH8 bvh(meshes[m]);
+            bvh.nodes.assign(nodes.begin() + static_cast<std::ptrdiff_t>(nodeAt), nodes.begin() + static_cast<std::ptrdiff_t>(nodeAt + nodeCounts[m]));
+            bvh.triangleIdx.assign(idx.begin() + static_cast<std::ptrdiff_t>(triAt), idx.begin() + static_cast<std::ptrdiff_t>(triAt + counts[m]));
+            bvh.deviceBlasId = ids[m];
+            nodeAt += nodeCounts[m];
+            triAt += counts[m];
+            out.push_back(std::move(bvh));
+        }
+        assets.uploadedBvhs = firstIndex + meshes.size();
+        return out;
+    });
     assets.SetBlasBuilder([this, &assets](const std::vector<Triangle>& triangles, size_t index) {
         // everything created before is on the device first, so that this tree's id there is its id here
         UploadPendingBlas(assets);

@@ -189,3 +189,103 @@ def test_device_build_of_a_million_triangles_is_fast_and_valid(gpu_ctx_factory, 
     ha, hb = a.trace_batch(rays), ctx.trace_batch(rays)
     assert (ha["hitDistance"] < 1e29).mean() > 0.2
     assert np.array_equal(ha["hitDistance"].view(np.uint32), hb["hitDistance"].view(np.uint32))
+
+
+def _grid_scene(ctx, blas_ids, roots, spacing=3.0):
+    """every BLAS once, on a lattice: (instances, TLAS installed)"""
+    inst = []
+    side = int(np.ceil(len(blas_ids) ** (1.0 / 3.0)))
+    for k, (bid, root) in enumerate(zip(blas_ids, roots)):
+        m = np.eye(4, dtype=np.float32)
+        m[0, 3], m[1, 3], m[2, 3] = spacing * (k % side), spacing * ((k // side) % side), spacing * (k // (side * side))
+        inst.append(capi.instance_init(bid, 0, m.reshape(16), root))
+    inst = np.array(inst, dtype=pod.INST_DT)
+    tn, ti = capi.tlas_build(inst)
+    ctx.set_tlas(tn, ti, inst)
+    return inst, side
+
+
+def test_batched_blas_build_gives_every_mesh_the_tree_of_its_single_build(gpu_ctx_factory):
+    """nxhip_build_blas_batch: many meshes as one forest (per-mesh Morton order, one root segment each, the single build's level
+    loops over all of them).  Every mesh must come out as the tree its own nxhip_build_blas gives — judged like two single builds
+    of one mesh are (node numbering follows the order of atomics): same node count, a valid conservative CWBVH over its own
+    triangles with mesh-local indices, the same root node, and every ray walks it the same way (hit records including equidistant
+    ties, nodes and triangles visited).  The mix: single nodes (1, 5, 8 triangles), the smallest real trees (9, 10), duplicates
+    of one mesh, coincident triangles (equal Morton codes, position splits), a planar grid, soups and tori up to 40 000."""
+    meshes = [MESHES[k]() for k in ("one", "tiny", "nine", "soup", "torus", "same_centroids", "planar", "soup40k")]
+    meshes += [scenegen.random_soup(8, seed=11), scenegen.random_soup(10, seed=12), scenegen.displaced_torus(64, 20, seed=13, major=0.7, minor=0.2, amp=0.04)]
+    meshes += [meshes[4].copy(), meshes[2].copy()]  # the same mesh twice in one batch
+    meshes += [scenegen.random_soup(int(n), seed=100 + i, extent=0.8, size=0.08) for i, n in enumerate(np.random.RandomState(5).randint(11, 3000, size=24))]
+    meshes = [np.ascontiguousarray(m, dtype=pod.TRI_DT) for m in meshes]
+    counts = [len(m) for m in meshes]
+
+    single = gpu_ctx_factory(32, 32)
+    ids_s = [single.build_blas(m) for m in meshes]
+    trees_s = [single.read_blas(b, n) for b, n in zip(ids_s, counts)]
+    batch = gpu_ctx_factory(32, 32)
+    ids_b = batch.build_blas_batch(meshes)
+    assert ids_b == list(range(len(meshes)))
+    trees_b = batch.read_blas_batch(ids_b[0], counts)
+    for k, ((ns, _), (nb, ib)) in enumerate(zip(trees_s, trees_b)):
+        assert len(ns) == len(nb), "mesh %d (%d triangles): %d nodes alone, %d in the batch" % (k, counts[k], len(ns), len(nb))
+        assert ns[0].tobytes() == nb[0].tobytes() or counts[k] > 8, "single-node meshes are the same bytes"
+        assert np.array_equal(ns[0]["p"], nb[0]["p"]) and np.array_equal(ns[0]["e"], nb[0]["e"]), "same root frame"
+        if counts[k] <= 5000:
+            _check_structure(nb, ib, meshes[k])
+        else:
+            assert sorted(ib.tolist()) == list(range(counts[k]))
+    # the same scene over both sets of trees: every ray walks them the same way
+    stats = []
+    for ctx, ids, trees in ((single, ids_s, trees_s), (batch, ids_b, trees_b)):
+        _, side = _grid_scene(ctx, ids, [t[0][0] for t in trees])
+        ext = 3.0 * side
+        rays = np.concatenate([scenegen.random_rays(60000, seed=3, radius=2.0 * ext, target_extent=ext / 2), scenegen.interior_rays(60000, seed=4, extent=ext / 2)])
+        rays["origin"] += np.float32(ext / 2 - 1.5)
+        ctx.enable_trace_stats(True)
+        ctx.read_trace_stats(reset=True)
+        hits = ctx.trace_batch(rays)
+        st, _ = ctx.read_trace_stats(reset=True)
+        stats.append((hits, st["nodes"], st["tris"], st["instances"]))
+    assert (stats[0][0]["hitDistance"] < 1e29).mean() > 0.1
+    assert SH.hit_records_equal(stats[0][0], stats[1][0])
+    assert stats[0][1:] == stats[1][1:]
+
+
+def test_a_thousand_meshes_of_a_thousand_triangles_in_one_build(gpu_ctx_factory):
+    """1 000 meshes x 1 000 triangles (a glTF scene's worth of small meshes) in one nxhip_build_blas_batch call,
+    timed from the host arrays to installed BLASes, against the same meshes built one by one."""
+    import time
+
+    rng = np.random.RandomState(9)
+    base = scenegen.displaced_torus(25, 20, seed=3, major=0.6, minor=0.25, amp=0.05)
+    assert len(base) == 1000
+    meshes = []
+    for k in range(1000):
+        m = base.copy()
+        s = np.float32(rng.uniform(0.5, 2.0))
+        for f in ("pos0", "pos1", "pos2"):
+            m[f] = m[f] * s + rng.uniform(-0.2, 0.2, size=(1, 3)).astype(np.float32)
+        meshes.append(np.ascontiguousarray(m, dtype=pod.TRI_DT))
+    ctx = gpu_ctx_factory(32, 32)
+    ctx.build_blas_batch(meshes[:8])  # first use: code objects, sort temporaries, the pinned staging buffer
+    ctx.sync()
+    t0 = time.perf_counter()
+    ids = ctx.build_blas_batch(meshes)
+    ctx.sync()
+    dt_batch = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for m in meshes[:100]:
+        ctx.build_blas(m)
+    ctx.sync()
+    dt_single = (time.perf_counter() - t0) * 10.0
+    print("1000 meshes x 1000 triangles: one batched build %.1f ms; one by one %.0f ms (100 of them timed)" % (dt_batch * 1e3, dt_single * 1e3))
+    assert ids == list(range(8, 1008))
+    assert dt_batch < 0.05, "%.1f ms" % (dt_batch * 1e3)
+    trees = ctx.read_blas_batch(ids[0], [1000] * 1000)
+    for k in (0, 499, 999):
+        _check_structure(trees[k][0], trees[k][1], meshes[k])
+    # one of them against its own single build
+    single = gpu_ctx_factory(32, 32)
+    bid = single.build_blas(meshes[500])
+    ns, _ = single.read_blas(bid, 1000)
+    assert len(ns) == len(trees[500][0])

@@ -83,9 +83,11 @@ def test_facade_small_pass_measures_do_not_change_the_image():
     assert len(np.unique(images[0])) > 16
 
 
-def _cornell_from_file(width, height, path_length):
+def _cornell_from_file(width, height, path_length, before_load=None):
     """The reference's own call: Scene::CreateMeshInstanceFromFile (C++ glb reader), materials as the file gives them."""
     sc = capi.Scene(width, height)
+    if before_load:
+        before_load(sc)
     sc.load_file(SH.GOLDEN + os.sep, "cornell_box.glb")
     sc.set_camera((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, 5.0, 0.0)
     sc.set_render_settings(O.make_settings(use_mis=True, path_length=path_length))
@@ -220,6 +222,33 @@ def test_meshes_built_on_the_device_through_the_facade_render_like_host_built_on
         assert SH.image_agreement(b, a, 1e-6) >= 0.999
     assert SH.image_agreement(imgs[True][1], imgs[True][0], 1e-6) < 0.999  # the added mesh is visible
     assert np.array_equal(imgs[True][0], imgs[True][2]) and np.array_equal(imgs[True][1], imgs[True][3])  # the second scene renders as the first
+
+
+@pytest.mark.gpu
+def test_a_file_loaded_with_the_device_builder_on_builds_its_meshes_in_one_batch():
+    """OBJLoader::LoadOBJ creates the BVHs of a file's meshes together (AssetManager::CreateBVHs); with
+    PathTracer::SetDeviceBlasBuild on that is ONE nxhip_build_blas_batch call for the eight meshes of cornell_box.glb (the
+    reference: one CreateBVH per aiMesh, Assets/OBJLoader.cpp:213-239).  Same image as with the host-built trees, and the trees
+    the asset manager keeps are the device's."""
+    W = H = 64
+    imgs = {}
+    for device in (False, True):
+        pt = capi.PathTracer(W, H)
+        pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+        sc = _cornell_from_file(W, H, 4, before_load=(lambda s: pt.set_device_blas_build(s, True)) if device else None)
+        pt.update_device_scene(sc)
+        for _ in range(2):
+            pt.render(sc)
+        imgs[device] = pt.read_radiance()
+        if device:
+            # Cornell box: 8 meshes of 2 - 12 triangles: single-node trees (at most 8 triangles) and one real one
+            for bid in range(8):
+                nodes, idx = pt.read_blas(bid, 64)
+                assert len(nodes) >= 1
+            pt.set_device_blas_build(sc, False)
+        pt.close()
+    assert np.isfinite(imgs[False]).all() and imgs[False].max() > 0
+    assert SH.image_agreement(imgs[True], imgs[False], 1e-6) >= 0.999
 
 
 @pytest.mark.gpu
