@@ -489,6 +489,7 @@ def main():
     # serial slot order costs on the whole chip (`ordered`: same work as the headline) and what the reference's exact
     # configuration renders at (`reference`: conductor hits end unshaded, as the reference's commented-out kernel leaves them)
     reference_mode = None
+    headline_rgba8 = ctx.read_rgba8() if (args.png and not dist_mode) else None  # (--png shows the headline's image, not the second measurement's)
     if not args.no_reference_mode and not dist_mode:
         reference_mode = {"what": "the timed region again (median of 3 repetitions) with random numbers keyed by queue slot and slots in the reference's serial order "
                                   "(NX_RNG_REFERENCE_SLOT, NX_COMPACT_ORDERED: tiles by ticket + decoupled look-back on all CUs); `reference` also drops the conductor kernel "
@@ -694,9 +695,9 @@ def main():
             img = full_rgba.cpu().numpy().view(np.uint32)
         elif args.pixel_order == "tiles":
             img = np.zeros(W * H, np.uint32)
-            img[multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)] = ctx.read_rgba8()
+            img[multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)] = headline_rgba8
         else:
-            img = ctx.read_rgba8()
+            img = headline_rgba8
         imageio.write_png(args.png, img, W, H)
 
     if rank == 0:

@@ -37,13 +37,15 @@ __device__ __forceinline__ bool grow_by_children(const nx_bvh8_node& node, const
 // (row-major 4 x 4); `b`: in: the record's box, out: the tightened one.  Two levels: the root's leaf children by their own
 // boxes, its inner children by the boxes of THEIR children (up to 64 boxes: a rotated mesh is hugged more closely by many small
 // boxes than by eight large ones).
+// `singular`: the instance is traversed with the identity as its inverse transform — Mat4::Inverted's fallback for a matrix whose
+// 4 x 4 cofactor determinant is exactly zero (a mesh flattened by a zero scale, a projection) — which places the hits where no
+// box derived from T is: such an instance keeps the record's box.  The caller takes the decision from the SAME computation the
+// traversal's inverse comes from (the refit: mat4_invert's own determinant test; the builder: the record's inverse IS the
+// fallback), not from a determinant of its own, whose rounding could differ on nearly singular matrices.
 template <class NodePtr>
-__device__ __forceinline__ void tighten_instance_box(NodePtr nodes, const float* T, InstBox& b)
+__device__ __forceinline__ void tighten_instance_box(NodePtr nodes, const float* T, InstBox& b, const bool singular)
 {
-    // A singular matrix (a mesh flattened by a zero scale) has no inverse — the reference then traverses with the identity
-    // (Mat4::Inverted's fallback), which places the hits where no box derived from T is: such an instance keeps the record's box.
-    const float det = T[0] * (T[5] * T[10] - T[6] * T[9]) - T[1] * (T[4] * T[10] - T[6] * T[8]) + T[2] * (T[4] * T[9] - T[5] * T[8]);
-    if (!(det != 0.0f)) return;
+    if (singular) return;
     const nx_bvh8_node root = nodes[0];
     InstBox t;
     for (int a = 0; a < 3; a++) { t.lo[a] = 1e30f; t.hi[a] = -1e30f; }
@@ -64,6 +66,12 @@ __device__ __forceinline__ void tighten_instance_box(NodePtr nodes, const float*
         const float lo = fmaxf(b.lo[a], t.lo[a] - pad), hi = fminf(b.hi[a], t.hi[a] + pad);
         if (lo <= hi) { b.lo[a] = lo; b.hi[a] = hi; }
     }
+}
+
+// rows 0..3 of a row-major 4 x 4 matrix are the identity's, bit for bit
+__device__ __forceinline__ bool mat4_is_identity(const float* m)
+{
+    return rows_are_identity(m) && __float_as_uint(m[12]) == 0u && __float_as_uint(m[13]) == 0u && __float_as_uint(m[14]) == 0u && __float_as_uint(m[15]) == 0x3f800000u;
 }
 
 }  // namespace nxd

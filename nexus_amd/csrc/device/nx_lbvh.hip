@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(kBlock) instance_bounds_kernel(const nx_bvh_in
         if (blas && kNodeStride == 5) {
             InstBox t;
             for (int a = 0; a < 3; a++) { t.lo[a] = b.lo[a]; t.hi[a] = b.hi[a]; }
-            tighten_instance_box(reinterpret_cast<const nx_bvh8_node*>(blas[inst[i].bvhIdx].nodes), inst[i].transform.cell, t);
+            // (singular: the record carries Mat4::Inverted's identity fallback although its transform is not the identity)
+            const bool singular = mat4_is_identity(inst[i].invTransform.cell) && !mat4_is_identity(inst[i].transform.cell);
+            tighten_instance_box(reinterpret_cast<const nx_bvh8_node*>(blas[inst[i].bvhIdx].nodes), inst[i].transform.cell, t, singular);
             for (int a = 0; a < 3; a++) { b.lo[a] = t.lo[a]; b.hi[a] = t.hi[a]; }
         }
         for (int a = 0; a < 3; a++) {
@@ -224,12 +226,24 @@ __global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long 
     }
 }
 
-__device__ __forceinline__ Box3 load_fresh(const Box3* p)  // written by another thread of this launch: no register / L1 reuse
+// A box written by another thread of this launch (the bottom-up passes): device-scope loads / stores of its three 8-byte words —
+// a store is written through to where every XCD sees it, a load does not stop at this XCD's L2 — so that the passes need no
+// __threadfence() (an L2 write-back + invalidate per node visit: see cost_kernel).  Box arrays are 8-byte aligned (24-byte
+// elements from an allocation's start).
+__device__ __forceinline__ Box3 load_fresh(const Box3* p)
 {
-    const volatile float* v = reinterpret_cast<const volatile float*>(p);
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(p);
+    unsigned long long v[3];
+    for (int k = 0; k < 3; k++) v[k] = __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Box3 b;
-    for (int a = 0; a < 3; a++) { b.lo[a] = v[a]; b.hi[a] = v[3 + a]; }
+    memcpy(&b, v, sizeof b);
     return b;
+}
+__device__ __forceinline__ void store_shared(Box3* p, const Box3& b)
+{
+    unsigned long long v[3];
+    memcpy(v, &b, sizeof b);
+    for (int k = 0; k < 3; k++) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- 4. bounds, bottom-up: the second child to arrive at a node computes it and carries on
@@ -237,17 +251,16 @@ __global__ void __launch_bounds__(kBlock) fit_kernel(const Box3* __restrict__ tr
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int leaf = (n - 1) + k;
-        t.box[leaf] = triBox[order[k]];
+        store_shared(&t.box[leaf], triBox[order[k]]);
         int node = n > 1 ? t.parent[leaf] : -1;
         while (node >= 0) {
-            __threadfence();  // this thread's child box is visible before its arrival is
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the write-back must have completed: MI355X_MICROARCH.md, compiler hazard)
+            // this thread's child box is visible before its arrival is: written through (store_shared), and the store has completed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (atomicAdd(&t.arrived[node], 1) == 0) break;  // the sibling subtree is not done yet: its thread will do this node
-            __threadfence();
             const Box3 a = load_fresh(&t.box[t.left[node]]), b = load_fresh(&t.box[t.right[node]]);
             Box3 m;
             for (int x = 0; x < 3; x++) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
-            t.box[node] = m;
+            store_shared(&t.box[node], m);
             node = t.parent[node];
         }
     }

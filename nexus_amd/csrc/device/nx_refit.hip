@@ -33,7 +33,8 @@ NXD void box_grow(Box& b, const float* lo, const float* hi)
 
 // nexus::Mat4::Inverted (host/Math.cpp): cofactor expansion, every product and sum in the same order
 NXD float cof(const float* m, int a, int b, int c) { return m[a] * m[b] * m[c]; }
-NXD void mat4_invert(const float* m, float* out)
+// returns whether the matrix is singular (det == 0: the identity comes out, as nexus::Mat4's default)
+NXD bool mat4_invert(const float* m, float* out)
 {
     float inv[16];
     inv[0] = cof(m, 5, 10, 15) - cof(m, 5, 11, 14) - cof(m, 9, 6, 15) + cof(m, 9, 7, 14) + cof(m, 13, 6, 11) - cof(m, 13, 7, 10);
@@ -56,9 +57,10 @@ NXD void mat4_invert(const float* m, float* out)
     if (det != 0) {
         const float invdet = 1.0f / det;
         for (int i = 0; i < 16; ++i) out[i] = inv[i] * invdet;
-    } else {  // nexus::Mat4's default: identity
-        for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        return false;
     }
+    for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.0f : 0.0f;  // nexus::Mat4's default: identity
+    return true;
 }
 
 // BVHInstance::SetTransform for `count` instances: thread k handles instance ids[k] with matrix transforms[16 k .. 16 k + 15]
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
         const uint32_t id = ids[k];
         float m[16], inv[16];
         for (int i = 0; i < 16; i++) m[i] = transforms[16 * (size_t)k + i];
-        mat4_invert(m, inv);
+        const bool singular = mat4_invert(m, inv);
         NX_G nx_bvh_instance* inst = &instances[id];
         // world bounds: the 8 transformed corners of the BLAS root's quantisation frame [p, p + 2^(e-127) * 255]
         const NX_G uint4* root = S->blas[inst->bvhIdx].nodes;
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(256) instance_transform_kernel(const DeviceSta
         if (tightBoxes && kNodeStride == 5) {  // a TLAS built on the device keeps its tighter boxes (nx_instbox.h) through the refit
             InstBox tb;
             for (int a = 0; a < 3; a++) { tb.lo[a] = wb.lo[a]; tb.hi[a] = wb.hi[a]; }
-            tighten_instance_box(reinterpret_cast<const NX_G nx_bvh8_node*>(root), m, tb);
+            tighten_instance_box(reinterpret_cast<const NX_G nx_bvh8_node*>(root), m, tb, singular);
             tightBoxes[id] = tb;
         }
         NX_G InstTrav* t = &trav[leafOfInstance[id]];

@@ -246,6 +246,19 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __
     }
 }
 
+// The ray-batch hooks (nxhip_trace_batch / nxhip_trace_shadow_batch): `n` rays in the dense numbering of dense_piece — the sizes of
+// the regions in use and zeroed fetch heads at bounce slot `slot`.
+__global__ void hook_sizes_kernel(DeviceState* __restrict__ S, const uint32_t n, const int anyHit, const int slot)
+{
+    const uint32_t k = threadIdx.x;
+    if (k >= (uint32_t)kQueueShards) return;
+    const uint32_t shards = S->queueShards, piece = dense_piece(n, shards);
+    const int32_t size = k < shards ? (int32_t)min(piece, n - min(n, k * piece)) : 0;
+    NX_G RegionCounters* r = &S->counters->region[k];
+    if (anyHit) { r->traceShadowSize[slot] = size; r->shadowHead[slot] = 0; }
+    else { r->traceSize[slot] = size; r->traceHead[slot] = 0; }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // GenerateKernel — PathTracer.cu:85-122
 
@@ -1002,6 +1015,7 @@ const void* shade_kernel_ptr(int type, bool ordered)
 }
 const void* tail_kernel_ptr() { return (const void*)tail_kernel; }
 const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
+const void* hook_sizes_kernel_ptr() { return (const void*)hook_sizes_kernel; }
 const void* generate_kernel_ptr() { return (const void*)generate_kernel; }
 const void* accumulate_kernel_ptr() { return (const void*)accumulate_kernel; }
 const void* compose_kernel_ptr() { return (const void*)compose_kernel; }

@@ -20,6 +20,7 @@ const void* tail_kernel_ptr();
 const void* logic_kernel_ptr(bool ordered);
 const void* shade_kernel_ptr(int type, bool ordered);
 const void* begin_frame_kernel_ptr();
+const void* hook_sizes_kernel_ptr();
 const void* generate_kernel_ptr();
 const void* accumulate_kernel_ptr();
 const void* compose_kernel_ptr();
@@ -671,28 +672,31 @@ static int refresh_inst_trav(nxhip_ctx* c)
 // bytes: an inner slot must be announced in imask and carry exactly one bit (more would land on other slots' positions and
 // index one node past the children), a leaf's bits must stay below position 24 (beyond it they read as inner hits) and
 // inside the primitive list, children must exist and follow their parent (no cycles: the traversal would never end).
+static const char* wide_node_defect(const nx_bvh8_node& n, uint32_t i, uint32_t nodeCount, uint32_t primCount, bool childrenMustFollow)
+{
+    int inner = 0, prims = 0;
+    for (int s = 0; s < 8; s++) {
+        const uint32_t m = n.meta[s];
+        if (n.imask & (1u << s)) inner++;
+        if ((m & 0x18u) == 0x18u && (m >> 5) != 0u) {  // decoded as an inner child
+            if (!(n.imask & (1u << s))) return "a slot is encoded as an inner child but not announced in imask";
+            if ((m >> 5) != 1u) return "an inner slot carries more than one hit bit";
+            if ((m & 0x07u) != (uint32_t)s) return "an inner slot is encoded with another slot's number";
+        } else if (m >> 5) {  // decoded as a leaf of 1 .. 3 primitives at offset (m & 31)
+            const int top = 32 - __builtin_clz(m >> 5);
+            if ((int)(m & 0x1fu) + top > 24) return "a leaf slot's primitive bits leave the 24-bit primitive mask";
+            prims = std::max(prims, (int)(m & 0x1fu) + top);
+        }
+    }
+    if (inner && (uint64_t)n.childBaseIdx + (uint64_t)inner > nodeCount) return "child index out of range";
+    if (childrenMustFollow && inner && n.childBaseIdx <= i) return "child nodes must follow their parent";
+    if (prims && (uint64_t)n.triangleBaseIdx + (uint64_t)prims > primCount) return "leaf range out of range";
+    return nullptr;
+}
 static const char* wide_nodes_defect(const nx_bvh8_node* nodes, uint32_t nodeCount, uint32_t primCount)
 {
-    for (uint32_t i = 0; i < nodeCount; i++) {
-        const nx_bvh8_node& n = nodes[i];
-        int inner = 0, prims = 0;
-        for (int s = 0; s < 8; s++) {
-            const uint32_t m = n.meta[s];
-            if (n.imask & (1u << s)) inner++;
-            if ((m & 0x18u) == 0x18u && (m >> 5) != 0u) {  // decoded as an inner child
-                if (!(n.imask & (1u << s))) return "a slot is encoded as an inner child but not announced in imask";
-                if ((m >> 5) != 1u) return "an inner slot carries more than one hit bit";
-                if ((m & 0x07u) != (uint32_t)s) return "an inner slot is encoded with another slot's number";
-            } else if (m >> 5) {  // decoded as a leaf of 1 .. 3 primitives at offset (m & 31)
-                const int top = 32 - __builtin_clz(m >> 5);
-                if ((int)(m & 0x1fu) + top > 24) return "a leaf slot's primitive bits leave the 24-bit primitive mask";
-                prims = std::max(prims, (int)(m & 0x1fu) + top);
-            }
-        }
-        if (inner && (uint64_t)n.childBaseIdx + (uint64_t)inner > nodeCount) return "child index out of range";
-        if (inner && n.childBaseIdx <= i) return "child nodes must follow their parent";
-        if (prims && (uint64_t)n.triangleBaseIdx + (uint64_t)prims > primCount) return "leaf range out of range";
-    }
+    for (uint32_t i = 0; i < nodeCount; i++)
+        if (const char* defect = wide_node_defect(nodes[i], i, nodeCount, primCount, true)) return defect;
     return nullptr;
 }
 
@@ -948,13 +952,9 @@ int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, 
     if (!node || blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_debug_write_blas_node: no such BLAS");
     BlasHost& b = c->blas[(size_t)blasId];
     if (nodeIdx >= b.nodeCount) return fail_invalid("nxhip_debug_write_blas_node: no such node");
-    int inner = 0, prims = 0;
-    for (int s = 0; s < 8; s++) {
-        if (node->imask & (1u << s)) inner++;
-        else if (node->meta[s]) prims = std::max(prims, (node->meta[s] & 0x1f) + __builtin_popcount(node->meta[s] >> 5));
-    }
-    if ((inner && (uint64_t)node->childBaseIdx + inner > b.nodeCount) || (prims && (uint64_t)node->triangleBaseIdx + prims > b.triCount))
-        return fail_invalid("nxhip_debug_write_blas_node: child or leaf range outside the BLAS");
+    // the upload checks, as the traversal decodes a node (meta bytes), minus "children follow their parent": a node that points back
+    // at itself is what the hook exists for (the stall guard's test); everything that could index past an array is refused
+    if (const char* defect = wide_node_defect(*node, nodeIdx, b.nodeCount, b.triCount, false)) return fail_invalid(std::string("nxhip_debug_write_blas_node: ") + defect);
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     NX_HIP(hipMemcpy(b.nodes.as<uint4>() + (size_t)nodeIdx * kNodeStride, node, sizeof(nx_bvh8_node), hipMemcpyHostToDevice));
@@ -2212,13 +2212,13 @@ static int hook_copy(nxhip_ctx* c, const HookLayout& l, void* dev, void* host, s
 
 static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
 {
-    // region sizes + zeroed fetch heads for the reserved bounce slot
-    Counters* dc = c->counters.as<Counters>();
-    const HookLayout layout = hook_layout(c, n);
-    for (int k = 0; k < kQueueShards; k++) {
-        RegionCounters* r = &dc->region[k];
-        NX_HIP(hipMemcpyAsync(anyHit ? &r->traceShadowSize[kHookBounceSlot] : &r->traceSize[kHookBounceSlot], &layout.sizes[k], 4, hipMemcpyHostToDevice, c->stream));
-        NX_HIP(hipMemsetAsync(anyHit ? &r->shadowHead[kHookBounceSlot] : &r->traceHead[kHookBounceSlot], 0, 4, c->stream));
+    // region sizes + zeroed fetch heads for the reserved bounce slot, computed on the device from n (hook_layout's rule): no copy
+    // from a stack-local of this function is left in flight when it returns
+    {
+        DeviceState* S = c->dState.as<DeviceState>();
+        const int any = anyHit ? 1 : 0, slot = kHookBounceSlot;
+        void* args[4] = {(void*)&S, (void*)&n, (void*)&any, (void*)&slot};
+        NX_HIP(hipLaunchKernel(hook_sizes_kernel_ptr(), dim3(1), dim3(64), args, 0, c->stream));
     }
     Launch l = make_launch(trace_kernel_ptr(anyHit, c->statsEnabled), anyHit ? c->shadowBlocks : c->traceBlocks, kTraceBlockThreads,
                            anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot);

@@ -290,7 +290,29 @@ def test_device_tlas_boxes_hold_under_extreme_transforms(gpu_ctx_factory, seed):
     for k, i in enumerate((1, 5, 9, 13)):
         old = moved[i]
         moved[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), flat[k], scene.blas[int(old["bvhIdx"])][0][0])
-    ctx.rebuild_tlas(moved)
+    nodes2, idx2 = ctx.rebuild_tlas(moved)
+    assert len(ctx.trace_batch(rays)) == len(rays)
+    # ... and such an instance keeps the RECORD's box, in the build and in the refit alike.  Whether a matrix counts as singular is
+    # the inverse's own decision (Mat4::Inverted's 4 x 4 cofactor determinant == 0 -> identity), not a second determinant with
+    # its own rounding: a projection onto a plane and a matrix with a zero row among ordinary placements, geometry bounds for
+    # the ordinary ones, record bounds for the singular ones.
+    proj = capi.mat4_from_trs((0.5, -0.2, 0.3), (20.0, 40.0, 60.0), (1.0, 1.0, 1.0)).reshape(4, 4).astype(np.float64)
+    nrm = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    P = np.eye(4)
+    P[:3, :3] -= np.outer(nrm, nrm)                       # rank 2: every point onto the plane through the origin
+    special = {1: (P @ proj).astype(np.float32).reshape(16), 5: flat[1], 9: np.diag([1.0, 0.0, 2.0, 1.0]).astype(np.float32).reshape(16)}
+    for i, xf in special.items():
+        old = moved[i]
+        moved[i] = capi.instance_init(int(old["bvhIdx"]), int(old["materialId"]), xf, scene.blas[int(old["bvhIdx"])][0][0])
+        assert np.array_equal(np.asarray(moved[i]["invTransform"]).reshape(4, 4), np.eye(4, dtype=np.float32)), "Mat4::Inverted's fallback"
+    glo, ghi = _geometry_bounds(scene, moved)
+    for i in special:
+        glo[i], ghi[i] = moved[i]["boundsMin"], moved[i]["boundsMax"]
+    nodes3, idx3 = ctx.rebuild_tlas(moved)
+    _check_tlas_structure(nodes3, idx3, moved, (glo, ghi))
+    ctx.set_instance_transforms(np.array(sorted(special), np.uint32), np.array([special[i] for i in sorted(special)], np.float32))
+    refit3, _ = ctx.read_tlas(len(nodes3), n_inst)
+    _check_tlas_structure(refit3, idx3, moved, (glo, ghi))
     assert len(ctx.trace_batch(rays)) == len(rays)
 
 
