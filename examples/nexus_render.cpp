@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "nexus/PathTracer.h"
+#include "nexus_hip.h"
 #include "nexus/Scene.h"
 
 int main(int argc, char** argv)
@@ -20,6 +21,12 @@ int main(int argc, char** argv)
     if (argc < 4) {
         std::fprintf(stderr, "usage: %s <dir/> <file.glb|file.obj> <out.ppm> [width height frames pathLength] [eye(3) forward(3) hfov]\n", argv[0]);
         return 2;
+    }
+    // a program built against these headers and run with another build of libnexus_amd.so gets an error string here, not a GPU fault
+    // in its first launch (include/nexus_hip.h: the header's stamp is compiled into the caller, the library compares it with its own)
+    if (nxhip_check_library(nxhip_header_abi_stamp()) != NXHIP_OK) {
+        std::fprintf(stderr, "%s\n", nxhip_last_error());
+        return 3;
     }
     const std::string dir = argv[1], file = argv[2], out = argv[3];
     const uint32_t width = argc > 4 ? static_cast<uint32_t>(std::atoi(argv[4])) : 512;

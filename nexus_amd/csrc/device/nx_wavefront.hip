@@ -298,16 +298,24 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
 // ------------------------------------------------------------------------------------------------------
 // SampleBackground — PathTracer.cu:65-83
 
+// (u, v) of a direction on the latitude / longitude map — PathTracer.cu:65-83.  Computed ONCE per direction and handed to the
+// colour lookup and to the sampler's density lookup alike: the arc functions are the expensive part (include/nexus_fmath.h
+// evaluates them in binary64), and a miss under environment sampling needs both lookups for the same direction.
+struct EnvUv { float u, v; };
+NXD EnvUv env_uv(f3 d)
+{
+    const float theta = nxf_atan2f(d.z, d.x);
+    const float phi = nxf_asinf(d.y);
+    return EnvUv{(float)((theta + kPiD) * kInvPi * 0.5), (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi)};
+}
+NXD f3 env_colour(const DeviceState* S, EnvUv uv)
+{
+    const float4 c = tex2d(S->hdrMap, S->srgbLut, uv.u, uv.v);
+    return mk3(c.x, c.y, c.z);
+}
 NXD f3 sample_background(const DeviceState* S, f3 d)
 {
-    if (S->hdrMap.texels) {
-        const float theta = nxf_atan2f(d.z, d.x);
-        const float phi = nxf_asinf(d.y);
-        const float u = (float)((theta + kPiD) * kInvPi * 0.5);
-        const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
-        const float4 c = tex2d(S->hdrMap, S->srgbLut, u, v);
-        return mk3(c.x, c.y, c.z);
-    }
+    if (S->hdrMap.texels) return env_colour(S, env_uv(d));
     return ld3(S->settings.backgroundColor) * S->settings.backgroundIntensity;
 }
 
@@ -316,23 +324,20 @@ NXD f3 sample_background(const DeviceState* S, f3 d)
 // so an HDR map with a small bright sun converges very slowly): the NEE may pick the environment as one more light and
 // draws its direction from the map's luminance distribution; a BSDF-sampled ray that misses is MIS-weighted against it.
 
-// the texel a direction falls in, with (u, v) exactly as sample_background computes them
-NXD uint32_t env_texel(const DeviceState* S, f3 d)
+// the texel (u, v) falls in
+NXD uint32_t env_texel(const DeviceState* S, EnvUv uv)
 {
-    const float theta = nxf_atan2f(d.z, d.x);
-    const float phi = nxf_asinf(d.y);
-    const float u = (float)((theta + kPiD) * kInvPi * 0.5);
-    const float v = (float)(1.0f - (phi + kPiD * 0.5f) * kInvPi);
     const int W = (int)S->hdrMap.width, H = (int)S->hdrMap.height;
-    const int x = min(max((int)(u * (float)W), 0), W - 1), y = min(max((int)(v * (float)H), 0), H - 1);
+    const int x = min(max((int)(uv.u * (float)W), 0), W - 1), y = min(max((int)(uv.v * (float)H), 0), H - 1);
     return (uint32_t)y * (uint32_t)W + (uint32_t)x;
 }
 
-// pdf per solid angle of the environment sampler for the unit direction d (light-selection probability excluded)
-NXD float env_pdf(const DeviceState* S, f3 d)
+// pdf per solid angle of the environment sampler for the unit direction d whose map coordinates are uv (light-selection
+// probability excluded)
+NXD float env_pdf(const DeviceState* S, f3 d, EnvUv uv)
 {
     const float cosLat = sqrtf(fmaxf(1.0f - d.y * d.y, 1.0e-12f));
-    return S->envDensity[env_texel(S, d)] / cosLat;
+    return S->envDensity[env_texel(S, uv)] / cosLat;
 }
 
 // first index whose cdf exceeds r (n - 1 when none does).  `guide` brackets the answer: entry b is the first index whose cdf
@@ -386,10 +391,16 @@ NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame,
     survived = false;
     if (hitT == 1e30f) {
         miss = true;
-        bg = throughput * sample_background(S, dir);
+        EnvUv uv{0.0f, 0.0f};
+        if (S->hdrMap.texels) {
+            uv = env_uv(dir);
+            bg = throughput * env_colour(S, uv);
+        } else {
+            bg = throughput * sample_background(S, dir);
+        }
         if (S->envSampling && S->hdrMap.texels && bounce > 1 && S->settings.useMIS) {
             // the NEE samples the environment too: weight the BSDF-sampled miss against it (extension)
-            const float envPdf = env_pdf(S, dir) / (float)nee_light_count(S);
+            const float envPdf = env_pdf(S, dir, uv) / (float)nee_light_count(S);
             if (pdf_valid(envPdf)) bg = bg * power_heuristic(tp.w, envPdf);
         }
     } else {
@@ -530,10 +541,11 @@ NXD bool next_event_estimation(const DeviceState* S, f3 wi, const MatParams& mp,
         f3 sampleThroughput;
         float bsdfPdf;
         if (!Bsdf<TYPE>::eval(mp, wi, wo, sampleThroughput, bsdfPdf)) return false;
-        const float lightPdf = env_pdf(S, shDir) / (float)nLights;
+        const EnvUv uv = env_uv(shDir);
+        const float lightPdf = env_pdf(S, shDir, uv) / (float)nLights;
         if (!pdf_valid(lightPdf)) return false;
         const float weight = power_heuristic(lightPdf, bsdfPdf);
-        out.radiance = (((throughput * weight) * sampleThroughput) * sample_background(S, shDir)) / lightPdf;
+        out.radiance = (((throughput * weight) * sampleThroughput) * env_colour(S, uv)) / lightPdf;
         out.origin = offset_ray(hitPoint, hitGNormal * sgnE(dot3(shDir, normal)));
         out.direction = shDir;
         out.distance = 1e30f;

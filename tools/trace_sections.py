@@ -1,0 +1,78 @@
+"""Static instruction counts of the trace kernel's loop sections, from the ISA of its counting variant (trace_kernel<closest, STATS>):
+the variant reads the shader clock at the section boundaries (NX_STAMP in nx_trace.hip -> s_memtime), so the instructions between two
+consecutive clock reads in the code layout are one section's.  Beside the measured cycle shares (bench.py roofline.simd.cycle_share)
+this says whether a section's share of the wave's time is instructions or waiting (VERDICT r3 item 2 i).
+    python tools/trace_sections.py [extra -D flags] > profiles/r04_trace_sections.txt
+Sections, in source order: refill | pop / retire | record select + fetch issue | instance entry | node decode (child_trace) |
+triangle test | rest of the iteration (retire test, stall guard, loop condition).  Basic blocks the compiler moved out of line (the
+reservation path of the refill, scratch-stack spills) are attributed to the section whose clock read precedes them in the layout, so
+the figures are approximate for `refill` and exact enough for the others."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Iinclude", "-Inexus_amd/csrc/device", "-Inexus_amd/csrc/host", "-fno-slp-vectorize",
+         "--offload-arch=gfx950", "-DNX_BUILT_FOR_GFX950=1", "-S", "--cuda-device-only"] + sys.argv[1:]
+
+with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", tmp.name, os.path.join(ROOT, "nexus_amd/csrc/device/nx_trace.hip")], cwd=ROOT, check=True, capture_output=True)
+    text = open(tmp.name).read()
+
+
+def body(mangled_part):
+    m = re.search(r"^(_ZN3nxd12trace_kernel%s\S*):\s*; @" % mangled_part, text, re.M)
+    start = m.end()
+    end = text.index(".Lfunc_end", start)
+    return [l.strip() for l in text[start:end].split("\n")]
+
+
+def classify(op):
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith(("s_waitcnt", "s_nop", "s_sleep")):
+        return "wait"
+    if op.startswith(("s_cbranch", "s_branch")):
+        return "branch"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "flat_", "buffer_")):
+        return "vmem"
+    if op.startswith("scratch_"):
+        return "scratch"
+    return "other"
+
+
+def count(lines):
+    sections, cur = [], {}
+    for l in lines:
+        if not l or l.startswith((";", ".", "//")) or l.endswith(":"):
+            continue
+        op = l.split()[0]
+        if op.startswith("s_memtime") or op.startswith("s_memrealtime"):
+            sections.append(cur)
+            cur = {}
+            continue
+        k = classify(op)
+        cur[k] = cur.get(k, 0) + 1
+    sections.append(cur)
+    return sections
+
+
+KEYS = ["valu", "salu", "lds", "vmem", "scratch", "wait", "branch"]
+for label, part in (("closest hit, counting variant (STATS): sections between clock reads, in code layout order", "ILb0ELb1EEE"), ("closest hit, product kernel: whole kernel", "ILb0ELb0EEE"),
+                    ("any hit, product kernel: whole kernel", "ILb1ELb0EEE")):
+    secs = count(body(part))
+    print(label)
+    print("  %-9s " % "section" + " ".join("%8s" % k for k in KEYS) + "   total")
+    for i, s in enumerate(secs):
+        if len(secs) == 1:
+            name = "all"
+        else:
+            name = "pre" if i == 0 else "s%d" % i
+        print("  %-9s " % name + " ".join("%8d" % s.get(k, 0) for k in KEYS) + "   %5d" % sum(s.values()))
+    print()
