@@ -67,6 +67,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievabl
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
 SIMDS = 256 * 4         # 256 CUs x 4 SIMD-32
 VALU_ISSUE_CYCLES = 2   # wave64 VALU instruction, several waves resident (MI355X_MICROARCH.md, execution model)
+# What a wave64 VALU instruction really costs a gfx950 SIMD with several waves resident (tools/micro/vgpr_bank.hip ->
+# profiles/r04_vgpr_bank_and_opcode_classes.txt, tools/micro/valu_cost.hip -> r04_valu_cost_microbench.txt): two limits.  (1) ISSUE: one
+# VALU instruction per ~2.7 cycles whatever its kind (fp32 fma / mul / add, and / or / xor, integer add / sub, right shifts, mov run at
+# exactly that: 2.5-2.9).  (2) A second, slower unit takes conversions, min / max, compares, selects, left shifts, bit-field and
+# three-operand integer forms at one per ~4.3 cycles (reciprocals / division steps ~8) — but it works beside the first: 4 fma + 4 cvt
+# alternating cost 2.7 per instruction, not (2.5 + 4.3) / 2.  The closest-hit kernel's mix (319 fast, 289 slow, 58 very slow instructions,
+# tools/trace_sections.py) needs 666 x 2.7 = 1 798 issue cycles and 289 x 4.3 + 58 x 8 = 1 707 cycles of the slow unit: balanced, bound by
+# issue at 2.7 cycles per instruction.  (Register banks play no part: same cost with all sources in one bank.)  Reported beside the
+# guide's 2-cycle fraction, not instead.
+VALU_CYCLES_AT_TRACE_MIX = 2.7
 L1_GATHER_PEAK = 3.8    # 16-byte per-lane loads a CU's vector L1 serves per ns when all of them hit (tools/micro/gather.hip)
 CUS = 256
 TILE_ROWS = 5           # 1080 = 5 * 216: divides evenly over 1, 2, 4, 8 ranks
@@ -607,6 +617,8 @@ def main():
                 both = ginst + shadow_rays_per_launch * cks["valu_insts_per_ray"] / dur_s / 1e9
                 ceilings["valu-issue"]["frac_with_concurrent_any_hit"] = round(both / peak_ginst, 4)
                 ceilings["valu-issue"]["frac_with_concurrent_any_hit_at_measured_2.42_cycles"] = round(both / peak_ginst * 2.42 / VALU_ISSUE_CYCLES, 4)
+                ceilings["valu-issue"]["frac_with_concurrent_any_hit_at_the_kernel_mix_%.1f_cycles" % VALU_CYCLES_AT_TRACE_MIX] = round(both / peak_ginst * VALU_CYCLES_AT_TRACE_MIX / VALU_ISSUE_CYCLES, 4)
+            ceilings["valu-issue"]["frac_at_the_kernel_mix_%.1f_cycles" % VALU_CYCLES_AT_TRACE_MIX] = round(ginst / peak_ginst * VALU_CYCLES_AT_TRACE_MIX / VALU_ISSUE_CYCLES, 4)
             if "l1_accesses_per_ray" in ck:
                 loads = rays_per_launch * ck["l1_accesses_per_ray"] / (dur_s * 1e9) / CUS
                 ceilings["l1-gather"] = {"achieved": round(loads, 3), "peak": L1_GATHER_PEAK, "unit": "16-B lane-loads/ns/CU", "frac": round(loads / L1_GATHER_PEAK, 4),

@@ -63,7 +63,7 @@ int nxhip_upload_blas(nxhip_ctx *ctx, const nx_bvh8_node *nodes, uint32_t nodeCo
  * one primitive per leaf, "split in half" when nothing separates (level-synchronous: atomics into 16 bins per axis and node,
  * a scan partition per level, nodes of up to 8 primitives finished by an exact sweep) — and the reference's SAH dynamic
  * programme for the collapse into 80-byte 8-wide nodes (cost table bottom-up, decisions followed top-down, the reference's
- * octant slot assignment and quantisation).  36 ms per million triangles (host builder of this repo: 0.4 s on 16 threads; the
+ * octant slot assignment and quantisation).  29 ms per million triangles (host builder of this repo: 0.4 s on 16 threads; the
  * reference: ~10 s on one) and fewer node visits per ray than the host build on every mesh of
  * profiles/r03_builder_quality.txt.  A valid, conservative CWBVH whose node bytes differ from the host builder's (another
  * tree); hit records are the same up to equidistant ties.  Returns the BLAS id like nxhip_upload_blas. */
@@ -84,7 +84,7 @@ int nxhip_read_blas_batch(nxhip_ctx *ctx, int32_t firstBlasId, uint32_t count, n
                           uint32_t *primIdx, uint32_t primCapacity);
 /* Which binary tree the device builders (nxhip_build_blas, nxhip_rebuild_tlas) collapse into 8-wide nodes.
  * NXHIP_BUILDER_SAH (default): the top-down binned SAH build described above.  0: the binary radix tree of the 63-bit
- * Morton codes (LBVH: sort + one launch; 21 ms per million triangles).  clusteringRadius > 0: parallel locally-ordered
+ * Morton codes (LBVH: sort + one launch; 15 ms per million triangles).  clusteringRadius > 0: parallel locally-ordered
  * clustering — the Morton-sorted primitives are merged bottom-up, every cluster pairing with the neighbour within `radius`
  * places whose union has the smallest surface area; a few dozen rounds.  All three go through the same SAH collapse.
  * Measured (profiles/r03_builder_quality.txt, node visits per ray against the host SAH build): top-down SAH -1 ... -14 %,
