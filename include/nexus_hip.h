@@ -280,6 +280,11 @@ int nxhip_trace_shadow_batch(nxhip_ctx *ctx, const nx_ray *rays, const float *tm
  * abandon such rays and nxhip_sync must report NXHIP_ERR_TRAVERSAL (nx_device.h kStallLimit) instead of never returning.
  * The node's child / leaf ranges must still lie inside the BLAS (that part is checked: a wild index is a wild device read). */
 int nxhip_debug_write_blas_node(nxhip_ctx *ctx, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node *node);
+/* Test hook: the number of passes every slot has begun since its ordered-compaction status words were last cleared.  The words
+ * are tagged with that number instead of being cleared per launch (NX_COMPACT_ORDERED); it wraps after 2^20 - 1 passes — a
+ * viewer at a thousand one-frame passes per second gets there in 17 minutes — where the words are cleared in stream order and
+ * the count starts over.  The test sets it just below the limit and renders across the wrap. */
+int nxhip_debug_set_scan_epoch(nxhip_ctx *ctx, uint32_t epoch);
 
 /* Kernel-level test hooks for the shading functions (same role as nxhip_trace_batch for the traversal): run the device
  * BSDF sample / eval (the headers of Cuda/BSDF/ as restated in nx_bsdf.h) and the software texture fetch on host arrays.

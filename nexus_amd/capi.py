@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
-    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch",
+    "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
 ]
 HOST_SYMBOLS = [
     "nxh_bvh8_build", "nxh_tlas_build", "nxh_tlas_refit", "nxh_bvh8_node_count", "nxh_bvh8_prim_count", "nxh_bvh8_nodes",
@@ -595,6 +595,11 @@ class Context:
         node = np.ascontiguousarray(node, dtype=pod.NODE_DT).reshape(1)
         self.L.nxhip_debug_write_blas_node.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
         check(self.L.nxhip_debug_write_blas_node(self.h, blas_id, node_idx, _ptr(node)), "nxhip_debug_write_blas_node")
+
+    def debug_set_scan_epoch(self, epoch):
+        """test hook: passes begun since the ordered compaction's status words were last cleared (wraps at 2^20)"""
+        self.L.nxhip_debug_set_scan_epoch.argtypes = [C.c_void_p, C.c_uint32]
+        check(self.L.nxhip_debug_set_scan_epoch(self.h, int(epoch)), "nxhip_debug_set_scan_epoch")
 
     def set_instance_transforms(self, instance_ids, transforms16):
         """move existing instances on the device (inverse, bounds, traversal records, TLAS refit): no scene re-upload"""

@@ -966,6 +966,14 @@ int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, 
     return NXHIP_OK;
 }
 
+int nxhip_debug_set_scan_epoch(nxhip_ctx* c, uint32_t epoch)
+{
+    NX_CHECK_CTX(c);
+    NX_SYNC_ALL(c);
+    for (uint32_t k = 0; k < slot_count(c); k++) slot_at(c, k)->scanEpoch = std::min(epoch, kScanEpochLimit - 1u);
+    return NXHIP_OK;
+}
+
 int nxhip_clear_blas(nxhip_ctx* c)
 try {
     NX_CHECK_CTX(c);

@@ -276,3 +276,36 @@ def test_released_queues_come_back_with_the_next_render(gpu_ctx_factory):
         ref.render_frame()
         ref.accumulate()
     assert np.array_equal(ctx.read_accumulation().view(np.uint32), ref.read_accumulation().view(np.uint32))
+
+
+def test_batched_blas_build_refuses_bad_input_and_falls_back_for_other_builders(gpu_ctx_factory):
+    """nxhip_build_blas_batch: an empty batch, a mesh without triangles and a null mesh pointer are NXHIP_ERR_INVALID with the
+    context untouched; with another builder selected (radix tree, clustering) the meshes are built one by one and still get
+    consecutive ids."""
+    import ctypes as C
+
+    from nexus_amd import scenegen
+
+    ctx = gpu_ctx_factory(32, 32)
+    L = ctx.L  # (status 1 = NXHIP_ERR_INVALID, include/nexus_hip.h)
+    L.nxhip_build_blas_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    a = np.ascontiguousarray(scenegen.random_soup(20, seed=1), dtype=pod.TRI_DT)
+    ptrs = (C.c_void_p * 2)(a.ctypes.data, None)
+    counts = np.array([20, 5], dtype=np.uint32)
+    assert L.nxhip_build_blas_batch(ctx.h, ptrs, counts.ctypes.data, 2, None) == 1      # a null mesh
+    ptrs = (C.c_void_p * 2)(a.ctypes.data, a.ctypes.data)
+    counts = np.array([20, 0], dtype=np.uint32)
+    assert L.nxhip_build_blas_batch(ctx.h, ptrs, counts.ctypes.data, 2, None) == 1      # no triangles
+    assert L.nxhip_build_blas_batch(ctx.h, ptrs, counts.ctypes.data, 0, None) == 1      # no meshes
+    assert ctx.build_blas(a) == 0, "nothing of the refused calls stayed behind"
+    for builder in (0, 8):
+        ctx.set_device_builder(builder)
+        first = ctx.build_blas_batch([a, a[:9], a[:3]])
+        assert first == list(range(first[0], first[0] + 3))
+        for bid, n in zip(first, (20, 9, 3)):
+            nodes, idx = ctx.read_blas(bid, n)
+            assert sorted(idx.tolist()) == list(range(n)) and len(nodes) >= 1
+    ctx.set_device_builder(-1)
+    ids = ctx.build_blas_batch([a, a[:9], a[:3]])
+    trees = ctx.read_blas_batch(ids[0], [20, 9, 3])
+    assert [len(t[1]) for t in trees] == [20, 9, 3]

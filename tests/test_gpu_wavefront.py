@@ -437,3 +437,37 @@ def test_pass_through_at_the_first_hit_keeps_the_camera_origin_for_mis(gpu_ctx_f
         for f in range(3):
             assert want[f].max() > 0.5
             assert SH.frames_identical(got[f], want[f], "pass-through rng mode %d frame %d" % (rng_mode, f + 1))
+
+
+def test_ordered_compaction_with_passes_in_flight_and_across_the_epoch_wrap(gpu_ctx_factory):
+    """The grid-wide ordered compaction keeps its tile status words between launches and tells them apart by a serial (pass epoch
+    of the slot, bounce, kernel kind).  Two things no single-pass test reaches: several passes in flight, each in a slot with its
+    own status words and its own epoch count; and the wrap of the epoch after 2^20 - 1 passes (a viewer at a thousand one-frame
+    passes per second is there in 17 minutes), where the words are cleared in stream order and the count starts over.  Frames
+    must stay those of the serial oracle, bit for bit, on both sides of the wrap."""
+    W, H = 128, 96  # 12 288 paths: 48 tiles of 256, 12 of 1 024
+    scene = SH.material_zoo_scene(W, H, path_length=5)
+    frames = 9
+    orc, want = _render_oracle(scene, W * H, frames, pod.RNG_REFERENCE_SLOT, pod.CONDUCTOR_EXTENDED)
+    for R in (1, 3):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, pod.CONDUCTOR_EXTENDED)
+        ctx.set_tail_bounce(0)
+        ctx.set_passes_in_flight(R)
+        ctx.reset_frame_number()
+        ctx.render_frame()
+        ctx.accumulate()
+        ctx.sync()
+        ctx.debug_set_scan_epoch((1 << 20) - 4)  # three more passes per slot, then the wrap
+        got = [ctx.read_radiance()]
+        for _ in range(frames - 1):
+            ctx.render_frame()
+            ctx.accumulate()
+            got.append(ctx.read_radiance())
+        ctx.sync()
+        for f in range(frames):
+            if R == 1 or f == frames - 1:  # (with passes in flight read_radiance returns the last ACCUMULATED pass: compare the end state)
+                assert SH.frames_identical(got[f], want[f], "ordered, %d in flight, frame %d" % (R, f + 1))
+        assert SH.frames_identical(ctx.read_accumulation(), orc.accumulation(), "accumulation, %d in flight" % R)
+        assert np.array_equal(ctx.read_rgba8(), orc.rgba8())
