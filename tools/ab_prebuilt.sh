@@ -6,10 +6,13 @@ ROUNDS=${ROUNDS:-3}
 ARGS=${ARGS:---steps 256 --warmup 64}
 OUT=${OUT:-gpurun_out/ab}
 mkdir -p $OUT
-lib_of() { if [ "$1" = main ]; then echo nexus_amd/lib/libnexus_amd.so; else echo nexus_amd/lib/variants/lib_$1.so; fi; }
+# A tag may carry environment settings for the run: "main+NX_ANY_FIRST=1" = the product library with that variable (and
+# NX_TUNING_KNOBS=1) set; files are named after the whole tag.
+lib_of() { local t=${1%%+*}; if [ "$t" = main ]; then echo nexus_amd/lib/libnexus_amd.so; else echo nexus_amd/lib/variants/lib_$t.so; fi; }
+env_of() { case "$1" in *+*) echo "NX_TUNING_KNOBS=1 ${1#*+}" | tr '+' ' ';; esac; }
 for r in $(seq 1 $ROUNDS); do
   for tag in "$@"; do
-    NEXUS_AMD_LIB=$(lib_of $tag) timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline --no-obj-check > $OUT/${tag}_$r.json 2> $OUT/${tag}_$r.err || { echo "bench failed: $tag"; tail -3 $OUT/${tag}_$r.err; exit 1; }
+    env $(env_of $tag) NEXUS_AMD_LIB=$(lib_of $tag) timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline --no-obj-check > $OUT/${tag}_$r.json 2> $OUT/${tag}_$r.err || { echo "bench failed: $tag"; tail -3 $OUT/${tag}_$r.err; exit 1; }
   done
 done
 python - "$OUT" "$ROUNDS" "$@" <<'PY'
