@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
     ap.add_argument("--host-bvh", action="store_true", help="upload the BLASes of the host builder (binned SAH with 8 bins + SAH-DP collapse on CPU threads: the reference's "
                                                             "algorithm) instead of building them on the GPU (nxhip_build_blas: the same rule top-down on the device with 16 bins, "
-                                                            "then the same collapse; 36 ms instead of 0.4 s per million triangles and 2 % fewer node visits per ray)")
+                                                            "then the same collapse; 36 ms instead of 0.4 s per million triangles and 2 %% fewer node visits per ray)")
     ap.add_argument("--device-bvh", action="store_true", help="(the default since round 3; kept so that older command lines still parse)")
     ap.add_argument("--host-tlas", action="store_true", help="with the device-built BLASes: the TLAS from the host builder (the reference's agglomerative clustering + collapse) "
                                                              "instead of nxhip_rebuild_tlas")

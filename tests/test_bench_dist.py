@@ -42,3 +42,12 @@ def test_bench_through_torchrun_and_rccl_renders_the_plain_image(tmp_path, extra
     assert pr["backend"] == "nccl" and len(pr["rep_ms_by_rank"]) == 2 and len(pr["median_ms_by_rank"]) == 1 and pr["slowest_rank"] == 0
     assert pr["gather_bytes_per_rank_and_pass"] == 256 * 160 * 16
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0
+
+
+def test_bench_help_prints_its_options_without_a_gpu():
+    """`python bench.py --help`: argparse expands every help string with %-formatting, so a literal per-cent sign in one of them
+    is a crash before anything runs (it was: "2 % fewer node visits")."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for option in ("--gpus", "--steps", "--warmup", "--config", "--passes-in-flight"):
+        assert option in r.stdout
