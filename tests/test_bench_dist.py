@@ -44,6 +44,23 @@ def test_bench_through_torchrun_and_rccl_renders_the_plain_image(tmp_path, extra
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0
 
 
+@pytest.mark.gpu
+def test_a_distributed_bench_line_carries_rank_zeros_roofline(tmp_path):
+    """The line of an N > 1 run has the `roofline` block too (rank 0's launches on its own tiles; no collective inside the section, the
+    other ranks wait at the closing barrier) — `cpu_baseline` stays an N = 1 figure."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NX_BENCH_FORCE_DIST="1")
+    env.pop("NX_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--reps", "2", "--width", "256", "--height", "160", "--no-obj-check"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    rf = line["roofline"]
+    assert rf["kernel"] == "trace_kernel<closest>" and rf["frac"] is not None and 0.0 < rf["frac"] < 1.5 and rf["traffic"] > 0
+    assert rf["rays_per_launch"] > 0 and rf["avg_launch_ms"] > 0 and "scope" in rf
+    assert "cpu_baseline" not in line and "per_rank" in line["config"]
+
+
 def test_bench_help_prints_its_options_without_a_gpu():
     """`python bench.py --help`: argparse expands every help string with %-formatting, so a literal per-cent sign in one of them
     is a crash before anything runs (it was: "2 % fewer node visits")."""

@@ -65,7 +65,7 @@ def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--png", one], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common + ["--png", two]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + [c for c in common if c != "--no-roofline"] + ["--png", two]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert open(one, "rb").read() == open(two, "rb").read()
@@ -75,3 +75,6 @@ def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     pr = line["config"]["per_rank"]
     assert len(pr["median_ms_by_rank"]) == 2 and pr["slowest_rank"] in (0, 1) and pr["backend"] == "gloo" and line["n_gpus"] == 2
+    # ... and rank 0's roofline block (its launches on its half of the pixels; rank 1 waits at the closing barrier meanwhile)
+    rf = line["roofline"]
+    assert rf["scope"].startswith("rank 0 of 2") and rf["frac"] is not None and rf["rays_per_launch"] > 0 and "cpu_baseline" not in line
