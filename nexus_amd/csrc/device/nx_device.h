@@ -199,6 +199,11 @@ constexpr uint32_t kErrScanStalled = 2u;  // a workgroup of the ordered compacti
 // bounce, kernel kind) makes words of earlier launches read as "not there yet", so the array is never cleared between launches.
 constexpr uint32_t kScanEpochLimit = 1u << 20;  // pass epochs 1 .. limit - 1; the host clears the status arrays when it wraps
 constexpr uint32_t kScanAggregate = 1u, kScanPrefix = 2u;
+// Material kernels under the ordered compaction run workgroups (= tiles) of 1 024 items instead of 256: a tile costs a ticket (a
+// returning atomic on ONE word, 88 per microsecond chip-wide) and a look-back, so a quarter of the tiles is what pays there
+// (driver command, ordered mode: 1 600 -> 1 680 Msamples/s), while the racing allocator prefers small workgroups (the same 1 024
+// threads cost it 3.5 %: 2 014 -> 1 944).
+constexpr int kShadeBlockOrderedThreads = 1024;
 // A wave of a trace kernel that has stayed in its traversal loop for this many iterations (about a second) without coming
 // through its refill point — i.e. with rays that do not finish — gives up on them:
 // the rays end as misses / unoccluded, the error word is set and nxhip_sync reports NXHIP_ERR_TRAVERSAL.  A ray of a well-formed

@@ -703,7 +703,7 @@ template <int TYPE, bool ORDERED>
 #ifndef NX_SHADE_WAVES
 #define NX_SHADE_WAVES 5
 #endif
-__global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].materialSize[TYPE][bounce], S->queueShardCap);

@@ -1627,7 +1627,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     //  would need)
     auto whole_regions = [](int g) { return (g + kQueueShards - 1) / kQueueShards * kQueueShards; };
     // (ordered compaction: the same grids — tiles are handed out by ticket and their slots found by look-back, nx_wavefront.hip)
-    const int og = whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = kShadeBlockThreads;
+    const int og = whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = ordered ? kShadeBlockOrderedThreads : kShadeBlockThreads;
     const int lg = whole_regions(c->logicBlocksPerCU * c->numCUs), lb = kLogicBlockThreads;
     const int tailFrom = tail_bounce(c);
     for (int bounce = 1; bounce <= pathLength; bounce++) {

@@ -56,8 +56,13 @@ def test_a_distributed_bench_line_carries_rank_zeros_roofline(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     rf = line["roofline"]
-    assert rf["kernel"] == "trace_kernel<closest>" and rf["frac"] is not None and 0.0 < rf["frac"] < 1.5 and rf["traffic"] > 0
-    assert rf["rays_per_launch"] > 0 and rf["avg_launch_ms"] > 0 and "scope" in rf
+    assert rf["kernel"] == "trace_kernel<closest>" and rf["rays_per_launch"] > 0 and rf["avg_launch_ms"] > 0 and "scope" in rf
+    # (the fractions need the committed per-ray counters, which are tied to the hash of the device sources they were collected on: a
+    #  build whose sources have changed since says so instead of quoting stale figures)
+    if rf["frac"] is None:
+        assert rf["traffic"] is None and "source" in rf["traffic_source"]
+    else:
+        assert 0.0 < rf["frac"] < 1.5 and rf["traffic"] > 0
     assert "cpu_baseline" not in line and "per_rank" in line["config"]
 
 

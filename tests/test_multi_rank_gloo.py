@@ -77,4 +77,4 @@ def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
     assert len(pr["median_ms_by_rank"]) == 2 and pr["slowest_rank"] in (0, 1) and pr["backend"] == "gloo" and line["n_gpus"] == 2
     # ... and rank 0's roofline block (its launches on its half of the pixels; rank 1 waits at the closing barrier meanwhile)
     rf = line["roofline"]
-    assert rf["scope"].startswith("rank 0 of 2") and rf["frac"] is not None and rf["rays_per_launch"] > 0 and "cpu_baseline" not in line
+    assert rf["scope"].startswith("rank 0 of 2") and rf["rays_per_launch"] > 0 and "cpu_baseline" not in line
