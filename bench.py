@@ -272,6 +272,9 @@ def main():
     # gave, even 1 — a rehearsal of the RCCL path on a single-GPU box
     dist_mode = world > 1 or bool(os.environ.get("NX_BENCH_FORCE_DIST"))
     if dist_mode:
+        # (this pool's host driver only supports dmabuf IPC: without the setting RCCL's peer buffers fail with
+        #  "hipIpcGetMemHandle: invalid argument"; the launcher exports it, a bare `torchrun bench.py` may not)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # torch ships its own libamdhip64 / libhsa-runtime64: import it BEFORE libnexus_amd.so is loaded so that the
         # library's libamdhip64.so.7 dependency binds to the copy torch already holds (two HIP runtimes in one process
         # cannot share the device, nor a stream handle).
