@@ -703,7 +703,11 @@ template <int TYPE, bool ORDERED>
 #ifndef NX_SHADE_WAVES
 #define NX_SHADE_WAVES 5
 #endif
-__global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBlock, NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
+#ifndef NX_SHADE_WAVES_ORDERED
+#define NX_SHADE_WAVES_ORDERED 4
+#endif
+// (ordered: one 1 024-thread workgroup per CU is 4 waves per SIMD whatever the register budget says, so it may as well be 128)
+__global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBlock, ORDERED ? NX_SHADE_WAVES_ORDERED : NX_SHADE_WAVES) shade_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].materialSize[TYPE][bounce], S->queueShardCap);
