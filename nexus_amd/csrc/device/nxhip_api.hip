@@ -1589,8 +1589,9 @@ int trace_blocks(const nxhip_ctx* c, int fullGrid)
 //   passes in flight: bounce 5 for passes of up to 4 frames' worth of paths (by then a pass carries ~2 % of its primary rays; one
 //     frame per pass, 6 in flight: 969 -> 1 123; an earlier start loses: bounce 4, 4 frames: -9 %), bounce 3 for up to 2.5 frames'
 //     worth in at most 3 slots (one frame, 3 in flight: 832 -> 889);
-//   one pass at a time: one frame's worth from bounce 3 (521 -> 599), up to 6 frames' worth from bounce 4 (2: 793 -> 875,
-//     3: 952 -> 999, 5: 1 125 -> 1 169), up to 10 from bounce 5 (8 frames: 1 299 -> 1 355) — the share of a rank of 4 or 8 in the
+//   one pass at a time: one frame's worth from bounce 3 (521 -> 599), up to 4 frames' worth from bounce 4 (2: 793 -> 875,
+//     3: 952 -> 999; 2.5 — a rank of 8 — 4.70 ms from 4 or 5, 4.93 without), up to 10 from bounce 5 (5 — a rank of 4 — 7.45 ms from 5,
+//     7.57 from 4, 7.69 without; 8 frames: 1 299 -> 1 355) — the share of a rank of 4 or 8 in the
 //     driver's 20-frame job is such a pass (rank of 4: 8.65 -> 8.2 ms).
 // Larger passes lose (12 frames +-1 %, 20 frames -2 % from bounce 6 and -3 % from 5, 64 frames -7 %: a wave of the tail kernel keeps
 // 64 lanes for as long as its longest path, and there the level-by-level launches are already amortised).
@@ -1601,7 +1602,7 @@ int tail_bounce(const nxhip_ctx* c)
         const double frames = pass_size_in_frames(c);
         const unsigned slots = effective_slots(c);
         if (slots > 1u) bounce = frames > 4.0 ? 0 : (frames <= 2.5 && slots <= 3u) ? 3 : 5;
-        else bounce = frames <= 1.5 ? 3 : frames <= 6.0 ? 4 : frames <= 10.0 ? 5 : 0;
+        else bounce = frames <= 1.5 ? 3 : frames <= 4.0 ? 4 : frames <= 10.0 ? 5 : 0;
         if (bounce > (int)c->h.settings.pathLength) bounce = 0;
     }
     if (bounce < 2 || bounce > (int)c->h.settings.pathLength) return 0;
