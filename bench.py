@@ -19,7 +19,9 @@ to stderr, and a watchdog dumps the Python stacks if a phase takes longer than N
 Scene and BVH live in HBM before the timed region starts.  N > 1: the frame is cut into interleaved 5-row tiles, every
 rank renders AND accumulates its tiles with the scene replicated, and the accumulated tiles (16 B per pixel) are gathered
 to rank 0 with ONE RCCL gather per pass, where they are scattered into the full image and tonemapped; the image is
-bit-identical to the 1-GPU one.  Total work per step is fixed (one frame): strong scaling.
+bit-identical to the 1-GPU one.  A step on N GPUs is one frame PER GPU (--scaling weak, the default: every GPU keeps the 1-GPU run's
+work, K steps = K x N frames, all counted in `value`) or one frame in total (--scaling strong); a weak run on N > 1 GPUs reports the
+strong region too (config.strong_scaling).
 
 Rank 0 prints ONE JSON line.  It also carries
   roofline     : the closest-hit trace kernel against the three ceilings that could bind it, all from live launch durations
@@ -228,6 +230,11 @@ def main():
                     help="passes rendered concurrently on separate streams (nxhip_set_passes_in_flight): the drain of one pass overlaps the bulk of the next. "
                          "Default: 6 for passes of up to 4 frames, else 4; never more than the timed region has passes")
     ap.add_argument("--pixel-order", choices=["rows", "tiles"], default="tiles", help="order of a rank's paths: image rows, or 8x8 tiles")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="what a step is on N GPUs.  weak (default): one frame PER GPU — a step renders N frames, each tile-split over the N GPUs, so every GPU keeps "
+                         "the work of the 1-GPU run (K steps = K x N frames; Msamples/s counts them all).  strong: one frame in total, tile-split — K steps = K frames "
+                         "whatever N (a rank of 8 then renders 2.5 frames' worth of paths per 20-step region: the latency floor of a pass, DESIGN.md section 5). "
+                         "Identical at N = 1.  A weak run at N > 1 also times the strong region and reports it as config.strong_scaling")
     ap.add_argument("--host-bvh", action="store_true", help="upload the BLASes of the host builder (binned SAH with 8 bins + SAH-DP collapse on CPU threads: the reference's "
                                                             "algorithm) instead of building them on the GPU (nxhip_build_blas: the same rule top-down on the device with 16 bins, "
                                                             "then the same collapse; 36 ms instead of 0.4 s per million triangles and 2 %% fewer node visits per ray)")
@@ -284,15 +291,18 @@ def main():
     W, H = args.width, args.height
     if args.steps < 1 or args.warmup < 0 or args.reps < 1:
         raise SystemExit("--steps and --reps must be >= 1 and --warmup >= 0")
+    # frames per step: one per GPU under weak scaling (per-GPU work fixed as N grows), one in total under strong scaling
+    F = world if args.scaling == "weak" else 1
+    n_frames, n_warm = args.steps * F, args.warmup * F
     explicit_fpp = args.frames_per_pass is not None
     cap = max(1, min((args.frames_per_pass or (16 if big else 64)) * world, 512))
     if args.config == 4 and not args.passes_in_flight:
         args.passes_in_flight = 1  # configs[3] (heavily instanced: long trace launches, little to overlap): 271 Msamples/s with one pass at a time, 254 with four
-    S, R, n_passes = plan_schedule(args.steps, cap, args.passes_in_flight, explicit_fpp, 1.0 / world, args.width * args.height)
+    S, R, n_passes = plan_schedule(n_frames, cap, args.passes_in_flight, explicit_fpp, 1.0 / world, args.width * args.height)
     pass_sizes = [int(x) for x in args.pass_sizes.split(",")] if args.pass_sizes else None
     if pass_sizes:
-        if sum(pass_sizes) != args.steps or min(pass_sizes) < 1:
-            raise SystemExit("--pass-sizes must be positive and sum to --steps")
+        if sum(pass_sizes) != n_frames or min(pass_sizes) < 1:
+            raise SystemExit("--pass-sizes must be positive and sum to --steps (x the number of GPUs under weak scaling)")
         S = max(pass_sizes)
         R = max(1, min(args.passes_in_flight or R, 8, len(pass_sizes)))
     if R > 1 or args.emulate_rank_of > 1:
@@ -303,7 +313,7 @@ def main():
     def schedule(frames, size=None):
         """pass sizes that render exactly `frames` frames"""
         size = size or S
-        if pass_sizes and frames == args.steps and size == S:
+        if pass_sizes and frames == n_frames and size == S:
             return list(pass_sizes)
         return [size] * (frames // size) + ([frames % size] if frames % size else [])
 
@@ -466,8 +476,23 @@ def main():
         return out
 
     # one step = one frame; a pass renders up to S frames
-    rep_s = measure(args.steps, args.warmup, args.reps, S, "timed region")
+    rep_s = measure(n_frames, n_warm, args.reps, S, "timed region")
     elapsed = statistics.median(rep_s)
+
+    # (--png shows the headline's image, not what later measurements add to the accumulation)
+    headline_full = full_rgba.clone() if (dist_mode and args.png and rank == 0) else None
+
+    # a weak-scaling run on N > 1 GPUs also times the strong-scaling region — K frames in total, tile-split — as a second figure
+    strong = None
+    if dist_mode and world > 1 and F > 1:
+        S_strong, _, _ = plan_schedule(args.steps, cap, 1, explicit_fpp, 1.0 / world, W * H)
+        ss = measure(args.steps, args.warmup, 3, S_strong, "strong-scaling region")
+        med = statistics.median(ss)
+        strong = {"what": "the same K steps with ONE frame per step, tile-split over the N GPUs (total work fixed: --scaling strong), median of 3 repetitions",
+                  "value": round(W * H * args.steps / med / 1e6, 3), "unit": "Msamples/s", "frames_timed": args.steps, "frames_per_pass": S_strong,
+                  "ms_per_step": round(med / args.steps * 1e3, 4), "rep_ms": [round(x * 1e3, 3) for x in ss]}
+        sync()
+        ctx.set_frames_per_pass(S)
 
     emulated = None
     if args.emulate_rank_of > 1 and not dist_mode:
@@ -480,17 +505,20 @@ def main():
         # (an explicit --frames-per-pass is taken as the rank's pass size itself, for sweeps)
         capN = max(1, min(args.frames_per_pass if explicit_fpp else (16 if big else 64) * N, 512))
         S_full, R_full = S, R
-        S, R, _ = plan_schedule(args.steps, capN, args.passes_in_flight, explicit_fpp, 1.0 / N, W * H)
+        emu_frames = args.steps * (N if args.scaling == "weak" else 1)  # a rank's share: N x K frames of 1 / N of the pixels, or K frames of them
+        emu_warm = args.warmup * (N if args.scaling == "weak" else 1)
+        S, R, _ = plan_schedule(emu_frames, capN, args.passes_in_flight, explicit_fpp, 1.0 / N, W * H)
         sync()
         ctx.set_pixel_map(pm)
         ctx.set_frames_per_pass(S)
         ctx.set_passes_in_flight(max(R, 1))
-        rank_s = measure(args.steps, args.warmup, args.reps, S, "rank 0 of %d" % N)
+        rank_s = measure(emu_frames, emu_warm, args.reps, S, "rank 0 of %d" % N)
         per_rank = statistics.median(rank_s)
-        emulated = {"ranks": N, "local_pixels": int(len(pm)), "frames_per_pass": S, "passes_in_flight": R,
-                    "per_rank_ms": round(per_rank * 1e3, 3), "full_ms": round(elapsed * 1e3, 3), "ideal_ms": round(elapsed * 1e3 / N, 3),
-                    "efficiency_without_communication": round(elapsed / N / per_rank, 4),
-                    "msamples_per_s_if_all_ranks_matched": round(W * H * args.steps / per_rank / 1e6, 1), "rep_ms": [round(x * 1e3, 3) for x in rank_s]}
+        ideal = elapsed * emu_frames / n_frames / N  # the rank's share of the work at the 1-GPU rate
+        emulated = {"ranks": N, "scaling": args.scaling, "frames": emu_frames, "local_pixels": int(len(pm)), "frames_per_pass": S, "passes_in_flight": R,
+                    "per_rank_ms": round(per_rank * 1e3, 3), "full_ms": round(elapsed * 1e3, 3), "ideal_ms": round(ideal * 1e3, 3),
+                    "efficiency_without_communication": round(ideal / per_rank, 4),
+                    "msamples_per_s_if_all_ranks_matched": round(W * H * emu_frames / per_rank / 1e6, 1), "rep_ms": [round(x * 1e3, 3) for x in rank_s]}
         # back to the full frame for the roofline section below
         S, R = S_full, R_full
         sync()
@@ -511,15 +539,15 @@ def main():
         for key, conductor in (("ordered", pod.CONDUCTOR_EXTENDED), ("reference", pod.CONDUCTOR_REFERENCE)):
             sync()
             ctx.set_modes(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, conductor)
-            rs = measure(args.steps, min(args.warmup, S), 3, S, "%s mode" % key)
+            rs = measure(n_frames, min(n_warm, S), 3, S, "%s mode" % key)
             med = statistics.median(rs)
-            reference_mode[key] = {"value": round(W * H * args.steps / med / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(med / args.steps * 1e3, 4),
+            reference_mode[key] = {"value": round(W * H * n_frames / med / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(med / args.steps * 1e3, 4),
                                    "rep_ms": [round(x * 1e3, 3) for x in rs], "vs_headline": round(elapsed / med, 4)}
         sync()
         ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
         ctx.reset_frame_number()
 
-    value = W * H * args.steps / elapsed / 1e6
+    value = W * H * n_frames / elapsed / 1e6
     out = {
         "metric": "Msamples/sec (rays traced/sec) at 1080p, 8-bounce, 1M-tri BVH8; 1/2/4/8 GPU",  # BASELINE.json's metric, verbatim
         "value": round(value, 3),
@@ -529,7 +557,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -538,9 +566,11 @@ def main():
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, per-rank accumulation, one RCCL gather of accumulated tiles per pass" % (world, TILE_ROWS),
             "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of up to %d frames" % S,
             "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-            "timing": "median of %d repetitions of the %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps),
+            "step": "one frame" if F == 1 else "%d frames (one per GPU), each tile-split over the %d GPUs" % (F, world),
+            "frames_per_step": F, "frames_timed": n_frames, "samples_timed": int(W) * int(H) * n_frames,
+            "timing": "median of %d repetitions of the %d-step = %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps, n_frames),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
-            "pass_sizes": schedule(args.steps), "frames_rendered_by_the_timed_loop": frames_rendered[0],
+            "pass_sizes": schedule(n_frames), "frames_rendered_by_the_timed_loop": frames_rendered[0],
             "host_scene_build_s": round(t_build, 2), "tlas_builder": "device (nxhip_rebuild_tlas)" if (args.device_bvh and not args.host_tlas) else "host: agglomerative clustering + SAH-DP collapse (the reference's algorithm)",
             "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
         },
@@ -555,6 +585,8 @@ def main():
             "rep_ms_by_rank": rows, "median_ms_by_rank": med, "slowest_rank": int(max(range(world), key=lambda k: med[k])),
             "spread": round(max(med) / max(1e-9, min(med)), 4),
             "gather_bytes_per_rank_and_pass": int(n_local * 16), "backend": backend}
+    if strong:
+        out["config"]["strong_scaling"] = strong
     if reference_mode:
         out["config"]["reference_mode"] = reference_mode
     if emulated:
@@ -568,7 +600,7 @@ def main():
         stamp("roofline: counting variant + in-graph kernel timing")
         if ctx.frames_per_pass != S:
             ctx.set_frames_per_pass(S)
-        passes = max(1, min(args.steps // S, 4))
+        passes = max(1, min(n_frames // S, 4))
         frames = passes * S
         # (a) units: the counting variant of the same kernel over `frames` frames
         ctx.enable_trace_stats(True)
@@ -709,7 +741,7 @@ def main():
         from nexus_amd import imageio
 
         if dist_mode:
-            img = full_rgba.cpu().numpy().view(np.uint32)
+            img = headline_full.cpu().numpy().view(np.uint32)
         elif args.pixel_order == "tiles":
             img = np.zeros(W * H, np.uint32)
             img[multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)] = headline_rgba8

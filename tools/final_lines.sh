@@ -8,4 +8,5 @@ b default_r1 --passes-in-flight 1 --no-cpu-baseline
 b cfg5 --config 5 --no-cpu-baseline
 b cfg4 --config 4 --no-cpu-baseline
 b s1 --frames-per-pass 1 --no-cpu-baseline --no-reference-mode
-for n in 2 4 8; do b emulate_$n --steps 20 --warmup 5 --reps 7 --emulate-rank-of $n --no-cpu-baseline --no-reference-mode --no-roofline; done
+for n in 2 4 8; do b emulate_$n --steps 20 --warmup 5 --reps 7 --scaling strong --emulate-rank-of $n --no-cpu-baseline --no-reference-mode --no-roofline; done
+for n in 2 4 8; do b emulate_weak_$n --steps 20 --warmup 5 --reps 5 --scaling weak --emulate-rank-of $n --no-cpu-baseline --no-reference-mode --no-roofline; done
