@@ -290,7 +290,7 @@ constexpr uint64_t layout_stamp()
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
         offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
-        (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit,
+        (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
         sizeof(ShadeInst), offsetof(ShadeInst, tris), offsetof(ShadeInst, material), offsetof(DeviceState, shadeInst), sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),

@@ -63,7 +63,8 @@ def count(lines):
     return sections
 
 
-# the two (and a half) speed classes of wave64 VALU instructions on gfx950 at 5 waves per SIMD (tools/micro/vgpr_bank.hip, valu_cost.hip)
+# the two (and a half) classes of wave64 VALU instructions on gfx950 (tools/micro/valu_classes.hip -> profiles/r04_valu_opcode_classes.txt:
+# 2.2 cycles of issue for every instruction; the second class also occupies a unit for 4.1 cycles, the third for 8.1, beside the issue slot)
 FAST = ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32",
         "v_lshrrev_b32", "v_ashrrev_i32", "v_mul_legacy_f32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32")
 VERY_SLOW = ("v_rcp_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_pk_fma_f32", "v_mov_b64", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32")
@@ -100,6 +101,6 @@ for label, part in (("closest hit, counting variant (STATS): sections between cl
             name = "pre" if i == 0 else "s%d" % i
         print("  %-9s " % name + " ".join("%8d" % s.get(k, 0) for k in KEYS) + "   %5d" % sum(s.values()))
     f, sl, vs = valu_classes(body(part))
-    print("  VALU speed classes (2.75 / 4.4 / 8 cycles per wave64 instruction): %d fast, %d slow, %d very slow -> %.2f cycles per VALU instruction at this mix"
-          % (f, sl, vs, (2.75 * f + 4.4 * sl + 8.0 * vs) / max(1, f + sl + vs)))
+    print("  VALU classes: %d full-rate, %d second-unit (4.1 cycles), %d reciprocal-class (8.1) -> issue %d cycles (2.2 per instruction), second unit %d cycles per pass through this code"
+          % (f, sl, vs, round(2.2 * (f + sl + vs)), round(4.1 * sl + 8.1 * vs)))
     print()
