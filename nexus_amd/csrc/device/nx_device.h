@@ -157,7 +157,7 @@ struct MaterialQueue {
 // region 0, whose capacity is then the whole buffer.
 constexpr int kQueueShards = 8;
 static_assert(kQueueShards == kXcds, "one queue region per fetch head");
-constexpr int kQueueShardSlack = 4096;  // slots a region may exceed its even share by (see above; tiles are at most 1 024 items)
+constexpr int kQueueShardSlack = 4096;  // slots a region may exceed its even share by (see above; tiles are at most 2 048 items: the logic kernel's)
 
 // Mutable per-frame words, zeroed / advanced by begin_frame_kernel.  Mirrors D_QueueSize (PathTracer.cuh:61-73) with every
 // size word and traceCount / traceShadowCount widened to one per region / XCD group — and each region's words on 4 KiB of

@@ -31,7 +31,15 @@ constexpr int kWideBlock = 256;     // generate / accumulate
 #ifndef NX_LOGIC_BLOCK
 #define NX_LOGIC_BLOCK 1024
 #endif
-constexpr int kLogicBlock = NX_LOGIC_BLOCK;   // one slot atomic per block-sized tile of items
+constexpr int kLogicBlock = NX_LOGIC_BLOCK;   // one slot atomic per tile of kLogicItems x this many items
+// Items per logic thread.  Two: a tile of 2 048 items pays ONE round of slot allocation (barriers, the returning atomic per queue
+// or, ordered, the ticket and four look-backs) where 1 024-item tiles paid two — logic kernel -4.5 % racing, ordered mode +2.7 % on
+// the driver command — at 64 VGPRs with 20 spilled (two workgroups per CU as before; with a 4-wave register budget and no spills
+// only one workgroup fits a CU: +18 % on the kernel).
+#ifndef NX_LOGIC_ITEMS
+#define NX_LOGIC_ITEMS 2
+#endif
+constexpr int kLogicItems = NX_LOGIC_ITEMS;
 constexpr int kShadeBlock = NX_SHADE_BLOCK;
 
 // ------------------------------------------------------------------------------------------------------
@@ -59,10 +67,13 @@ NXD int wave_sum(int v)
     return v;
 }
 
-template <bool ORDERED, int K>
+// U: sub-tiles per tile.  A tile is U * blockDim.x consecutive items, thread t handles items t, t + blockDim.x, ... of it; the
+// slots of sub-tile u lie in front of those of sub-tile u + 1 (ascending item index, as ORDERED needs).  One ticket, one look-back
+// and one atomic per queue cover the whole tile: what a tile costs beside its items is paid once per U * blockDim.x of them.
+template <bool ORDERED, int K, int U = 1>
 struct SlotAllocator {
-    int* sWave;  // [K][kMaxWavesPerBlock] per-wave counts of the current tile
-    int* sBase;  // [K] base slot of the current tile
+    int* sWave;  // [U * K][kMaxWavesPerBlock] per-wave counts of the current tile
+    int* sBase;  // [U * K] base slot of the current tile's sub-tile u in queue k
     int* sTile;  // ORDERED: the ticket of the current tile
     int* counter0;  // the K counter words are counter0 + k * counterStep (an address computation, not an array of pointers: an
     int counterStep;  // array indexed by anything but a constant makes the allocator a private-memory object in LDS or scratch)
@@ -70,13 +81,13 @@ struct SlotAllocator {
     NX_G int* ticket;
     NX_G FrameState* frame;
     uint32_t serial;
-    int size, lastTile;
+    int size, lastTile, tileItems;
 
     // `kind`: 0 logic, 1 + NX_MAT_* material kernel; `items`: size of the launch's input queue
     NXD void init(const DeviceState* S, int* const first, const int step, const int kind, const int bounce, const int items)
     {
-        __shared__ int wave[K * kMaxWavesPerBlock];
-        __shared__ int base[K];
+        __shared__ int wave[U * K * kMaxWavesPerBlock];
+        __shared__ int base[U * K];
         __shared__ int tile;
         sWave = wave;
         sBase = base;
@@ -84,7 +95,8 @@ struct SlotAllocator {
         counter0 = first;
         counterStep = step;
         size = items;
-        lastTile = (items + (int)blockDim.x - 1) / (int)blockDim.x - 1;
+        tileItems = U * (int)blockDim.x;
+        lastTile = (items + tileItems - 1) / tileItems - 1;
         if (ORDERED) {
             status = S->scanStatus;
             ticket = &S->counters->scanTicket[kind][bounce];
@@ -97,15 +109,15 @@ struct SlotAllocator {
         return counter0 + k * counterStep;
     }
     // first item of the workgroup's first / next tile (>= size: none left)
-    NXD int first_tile() { return ORDERED ? take() : (int)(blockIdx.x * blockDim.x); }
-    NXD int next_tile(const int tile) { return ORDERED ? take() : tile + (int)(gridDim.x * blockDim.x); }
+    NXD int first_tile() { return ORDERED ? take() : (int)blockIdx.x * tileItems; }
+    NXD int next_tile(const int tile) { return ORDERED ? take() : tile + (int)gridDim.x * tileItems; }
     NXD int take()
     {
         __syncthreads();  // the previous tile's readers are done with sTile
         if (threadIdx.x == 0) *sTile = atomicAdd(ticket, 1);
         __syncthreads();
         const int t = *sTile;
-        return t > lastTile ? size : t * (int)blockDim.x;
+        return t > lastTile ? size : t * tileItems;
     }
 
     // ORDERED, one wave per queue: the slots taken by all tiles before tile t of this launch (and by the kernels before it in
@@ -155,51 +167,76 @@ struct SlotAllocator {
     }
 
     // `tile`: first item of the tile (what first_tile / next_tile returned); `region`: the queue region this tile appends to
-    // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words
-    NXD void alloc(const bool (&want)[K], int (&slot)[K], const int tile, const int region = 0)
+    // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words.  want[u][k]: this thread's
+    // item of sub-tile u goes to queue k.
+    NXD void alloc(const bool (&want)[U][K], int (&slot)[U][K], const int tile, const int region = 0)
     {
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
         const int nWaves = blockDim.x / kWave;
-        unsigned long long mask[K];
+        unsigned long long mask[U][K];
         __syncthreads();  // the previous tile's readers are done with sWave / sBase
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            mask[k] = __ballot(want[k]);
-            if (lane == 0) sWave[k * kMaxWavesPerBlock + wave] = __popcll(mask[k]);
-        }
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                mask[u][k] = __ballot(want[u][k]);
+                if (lane == 0) sWave[(u * K + k) * kMaxWavesPerBlock + wave] = __popcll(mask[u][k]);
+            }
         __syncthreads();
         if (ORDERED) {
             if (wave < K) {  // (a workgroup has at least K waves: 256 threads, K <= 4)
-                const int total = wave_sum(lane < nWaves ? sWave[wave * kMaxWavesPerBlock + lane] : 0);
-                const int t = tile / (int)blockDim.x;
+                int subTotal[U], total = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    subTotal[u] = wave_sum(lane < nWaves ? sWave[(u * K + wave) * kMaxWavesPerBlock + lane] : 0);
+                    total += subTotal[u];
+                }
+                const int t = tile / tileItems;
                 const int excl = look_back(wave, t, total);
                 if (lane == 0) {
-                    sBase[wave] = excl;
+                    int run = excl;
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        sBase[u * K + wave] = run;
+                        run += subTotal[u];
+                    }
                     if (t == lastTile) *counter_of(wave) = excl + total;
                 }
             }
         } else if (threadIdx.x < K) {
-            int total = 0;
-            for (int w = 0; w < nWaves; w++) total += sWave[threadIdx.x * kMaxWavesPerBlock + w];
+            int subTotal[U], total = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                subTotal[u] = 0;
+                for (int w = 0; w < nWaves; w++) subTotal[u] += sWave[(u * K + (int)threadIdx.x) * kMaxWavesPerBlock + w];
+                total += subTotal[u];
+            }
             int* const word = counter_of((int)threadIdx.x) + region * kRegionStride;
-            sBase[threadIdx.x] = total ? atomicAdd(word, total) : 0;
+            int run = total ? atomicAdd(word, total) : 0;
 #ifdef NX_EXTRA_ATOMICS
             // experiment: are the logic / material kernels bound by the returning atomics on their queue
             // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
             for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
-                if (total && atomicAdd(word, 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
+                if (total && atomicAdd(word, 0) == -123456789) run = 0;  // (returning, result unused)
 #endif
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                sBase[u * K + (int)threadIdx.x] = run;
+                run += subTotal[u];
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            slot[k] = -1;
-            if (want[k]) {
-                int prefix = 0;
-                for (int w = 0; w < wave; w++) prefix += sWave[k * kMaxWavesPerBlock + w];
-                slot[k] = sBase[k] + prefix + __popcll(mask[k] & ((1ull << lane) - 1ull));
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                slot[u][k] = -1;
+                if (want[u][k]) {
+                    int prefix = 0;
+                    for (int w = 0; w < wave; w++) prefix += sWave[(u * K + k) * kMaxWavesPerBlock + w];
+                    slot[u][k] = sBase[u * K + k] + prefix + __popcll(mask[u][k] & ((1ull << lane) - 1ull));
+                }
             }
-        }
     }
 };
 
@@ -441,66 +478,78 @@ template <bool ORDERED>
 #endif
 __global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
+    constexpr int U = kLogicItems;  // items per thread: a tile is U * 1 024 items behind ONE round of slot allocation
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
     const int size = in.total;
     // the grid is sized for the largest queue: a workgroup with no tile to process leaves before the allocator's
     // barriers (late bounces carry a few thousand items; an all-empty launch used to cost 30 us)
-    if ((int)(blockIdx.x * blockDim.x) >= size) return;
+    if ((int)(blockIdx.x * blockDim.x) * U >= size) return;
     const uint32_t frame = S->frame->frameNumber;
-    SlotAllocator<ORDERED, 4> slots;
+    SlotAllocator<ORDERED, 4, U> slots;
     // queue k of this kernel: the material queue of type k
     slots.init(S, &C->region[0].materialSize[0][bounce], kMaxBounceSlots, 0, bounce, size);
-    const ProducerRegions out = producer_regions(S, size, (int)blockDim.x);
+    const ProducerRegions out = producer_regions(S, size, U * (int)blockDim.x);
     for (int tile = slots.first_tile(); tile < size; tile = slots.next_tile(tile)) {
-        const int index = tile + (int)threadIdx.x;
-        int type = -1;
-        float4 hit = make_float4(0, 0, 0, 0), dirPix = make_float4(0, 0, 0, 0), tpOut = make_float4(0, 0, 0, 0);
-        uint32_t inst = 0, pixelIdx = 0;
-        if (index < size) {
-            const int at = in.slot(index);  // where item `index` of the trace queue lives
-            hit = S->trace.hit[at];
-            dirPix = S->trace.rayD[at];
-            pixelIdx = __float_as_uint(dirPix.w);
-            const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->trace.tp[at];
-            // the hit's instance is loaded with the rest of the entry, not behind the roulette decision that first needs it: a
-            // load inside the branch is one more dependent round trip per tile for the paths that survive (4 B per item more for
-            // those that do not; logic kernel -4 %)
-            const uint32_t hitInstance = S->trace.hitInst[at];
-            bool miss, survived, needsPrevVertex;
-            f3 bg = mk3(0.0f), t = mk3(0.0f);
-            type = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx, hit.x, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return hitInstance; }, miss, bg, survived, t, inst,
-                              needsPrevVertex);
-            if (needsPrevVertex) keep_previous_vertex(S, pixelIdx, S->trace.rayO[at]);
-            if (miss) {
-                // A background contribution of exactly +0 in all three components (a black environment: the reference's default
-                // backgroundIntensity 0) leaves the pixel's radiance as it is — generate_kernel zeroed it, later additions never
-                // produce a negative zero from non-negative emission — so the scattered 16-byte read-modify-write is skipped:
-                // it was a third of this kernel's memory traffic on such scenes.  (Anything else, -0 included, is added.)
-                if ((__float_as_uint(bg.x) | __float_as_uint(bg.y) | __float_as_uint(bg.z)) != 0u) {
-                    float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
-                    r.x += bg.x; r.y += bg.y; r.z += bg.z;
-                    if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
-                    S->radiance[pixelIdx] = r;
+        int type[U];
+        float4 hit[U], dirPix[U], tpOut[U];
+        uint32_t inst[U], pixelIdx[U];
+        bool want[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int index = tile + u * (int)blockDim.x + (int)threadIdx.x;
+            type[u] = -1;
+            hit[u] = make_float4(0, 0, 0, 0); dirPix[u] = make_float4(0, 0, 0, 0); tpOut[u] = make_float4(0, 0, 0, 0);
+            inst[u] = 0; pixelIdx[u] = 0;
+            if (index < size) {
+                const int at = in.slot(index);  // where item `index` of the trace queue lives
+                hit[u] = S->trace.hit[at];
+                dirPix[u] = S->trace.rayD[at];
+                pixelIdx[u] = __float_as_uint(dirPix[u].w);
+                const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->trace.tp[at];
+                // the hit's instance is loaded with the rest of the entry, not behind the roulette decision that first needs it: a
+                // load inside the branch is one more dependent round trip per tile for the paths that survive (4 B per item more for
+                // those that do not; logic kernel -4 %)
+                const uint32_t hitInstance = S->trace.hitInst[at];
+                bool miss, survived, needsPrevVertex;
+                f3 bg = mk3(0.0f), t = mk3(0.0f);
+                type[u] = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx[u], hit[u].x, mk3(dirPix[u].x, dirPix[u].y, dirPix[u].z), tp, [&]() { return hitInstance; }, miss, bg, survived, t,
+                                     inst[u], needsPrevVertex);
+                if (needsPrevVertex) keep_previous_vertex(S, pixelIdx[u], S->trace.rayO[at]);
+                if (miss) {
+                    // A background contribution of exactly +0 in all three components (a black environment: the reference's default
+                    // backgroundIntensity 0) leaves the pixel's radiance as it is — generate_kernel zeroed it, later additions never
+                    // produce a negative zero from non-negative emission — so the scattered 16-byte read-modify-write is skipped:
+                    // it was a third of this kernel's memory traffic on such scenes.  (Anything else, -0 included, is added.)
+                    if ((__float_as_uint(bg.x) | __float_as_uint(bg.y) | __float_as_uint(bg.z)) != 0u) {
+                        float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx[u]];
+                        r.x += bg.x; r.y += bg.y; r.z += bg.z;
+                        if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
+                        S->radiance[pixelIdx[u]] = r;
+                    }
+                    if (bounce == 1 && pixelIdx[u] < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx[u])) S->frame->pixelQueryInstance = -1;
                 }
-                if (bounce == 1 && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx)) S->frame->pixelQueryInstance = -1;
+                // (at bounce 1 every hit survives with throughput 1 and the material kernels use that constant instead of reading
+                //  it back)
+                if (survived) tpOut[u] = make_float4(t.x, t.y, t.z, tp.w);
             }
-            // (at bounce 1 every hit survives with throughput 1 and the material kernels use that constant instead of reading
-            //  it back)
-            if (survived) tpOut = make_float4(t.x, t.y, t.z, tp.w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) want[u][k] = type[u] == k;
         }
-        const bool want[4] = {type == 0, type == 1, type == 2, type == 3};
-        int slot[4];
+        int slot[U][4];
         const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
         slots.alloc(want, slot, tile, region);
-        if (type >= 0) {
-            const MaterialQueue mq = S->material[type];
-            const int sl = regionBase + (type == 0 ? slot[0] : (type == 1 ? slot[1] : (type == 2 ? slot[2] : slot[3])));
-            // the hit distance is of no use to the material kernels (they work from u, v): its slot carries the path index,
-            // which saves a third array (4 B written and read per path, one load and one store instruction each)
-            mq.hit[sl] = make_float4(__uint_as_float(pixelIdx), hit.y, hit.z, hit.w);
-            mq.dirInst[sl] = make_float4(dirPix.x, dirPix.y, dirPix.z, __uint_as_float(inst));
-            if (bounce != 1) mq.tp[sl] = tpOut;  // the path's throughput after Russian roulette and its last pdf go with it
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (type[u] >= 0) {
+                const MaterialQueue mq = S->material[type[u]];
+                const int sl = regionBase + (type[u] == 0 ? slot[u][0] : (type[u] == 1 ? slot[u][1] : (type[u] == 2 ? slot[u][2] : slot[u][3])));
+                // the hit distance is of no use to the material kernels (they work from u, v): its slot carries the path index,
+                // which saves a third array (4 B written and read per path, one load and one store instruction each)
+                mq.hit[sl] = make_float4(__uint_as_float(pixelIdx[u]), hit[u].y, hit[u].z, hit[u].w);
+                mq.dirInst[sl] = make_float4(dirPix[u].x, dirPix[u].y, dirPix[u].z, __uint_as_float(inst[u]));
+                if (bounce != 1) mq.tp[sl] = tpOut[u];  // the path's throughput after Russian roulette and its last pdf go with it
+            }
         }
     }
 }
@@ -753,11 +802,11 @@ __global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBl
                              },
                              wantShadow, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
         }
-        const bool want[2] = {wantShadow, wantTrace};
-        int slot[2];
+        const bool want[1][2] = {{wantShadow, wantTrace}};
+        int slot[1][2];
         const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
         slots.alloc(want, slot, tile, region);
-        const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
+        const int shadowSlot = regionBase + slot[0][0], traceSlot = regionBase + slot[0][1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
             S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
