@@ -470,7 +470,7 @@ NXD void keep_previous_vertex(const DeviceState* S, const uint32_t pixelIdx, con
     if (rayOrigin.w == 0.0f) S->rayOrigin[pixelIdx] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
 }
 
-template <bool ORDERED>
+template <bool ORDERED, int U>
 // 8 waves per SIMD (60 VGPRs, no spills): two of the 1024-thread workgroups fit a CU instead of one, so the barriers of the
 // slot allocation in one overlap with the streaming of the other (logic kernel -16 %, bench +1 %)
 #ifndef NX_LOGIC_WAVES
@@ -478,7 +478,7 @@ template <bool ORDERED>
 #endif
 __global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(const DeviceState* __restrict__ S, const int bounce)
 {
-    constexpr int U = kLogicItems;  // items per thread: a tile is U * 1 024 items behind ONE round of slot allocation
+    // U items per thread: a tile is U * 1 024 items behind ONE round of slot allocation
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
     const int size = in.total;
@@ -1071,7 +1071,14 @@ __global__ void __launch_bounds__(kWideBlock) tex2d_hook_kernel(const TextureDev
 
 // ------------------------------------------------------------------------------------------------------
 
-const void* logic_kernel_ptr(bool ordered) { return ordered ? (const void*)logic_kernel<true> : (const void*)logic_kernel<false>; }
+// `items` per thread: kLogicItems (2) unless the caller asks for 1 — what a scene with an environment map gets, whose misses run the
+// map lookups (binary64 arc functions) in this kernel: with a second item's state live beside them the 64-register budget spills
+// into that path (configs[3]: logic kernel +8 % with two items, -6 % on configs[1])
+const void* logic_kernel_ptr(bool ordered, int items)
+{
+    if (items == 1 || kLogicItems == 1) return ordered ? (const void*)logic_kernel<true, 1> : (const void*)logic_kernel<false, 1>;
+    return ordered ? (const void*)logic_kernel<true, kLogicItems> : (const void*)logic_kernel<false, kLogicItems>;
+}
 
 const void* shade_kernel_ptr(int type, bool ordered)
 {

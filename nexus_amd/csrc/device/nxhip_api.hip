@@ -17,7 +17,7 @@ namespace nxd {
 
 const void* trace_kernel_ptr(bool anyHit, bool stats);
 const void* tail_kernel_ptr();
-const void* logic_kernel_ptr(bool ordered);
+const void* logic_kernel_ptr(bool ordered, int items);
 const void* shade_kernel_ptr(int type, bool ordered);
 const void* begin_frame_kernel_ptr();
 const void* hook_sizes_kernel_ptr();
@@ -1636,7 +1636,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
             levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce)});
             break;
         }
-        levels.push_back({make_launch(logic_kernel_ptr(ordered), lg, lb, NXHIP_K_LOGIC, S, bounce)});
+        levels.push_back({make_launch(logic_kernel_ptr(ordered, c->hdrMap.texels.p ? 1 : 2), lg, lb, NXHIP_K_LOGIC, S, bounce)});
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
         // (only the types some material of the scene has: a queue no material feeds stays empty)
         std::vector<Launch> shade;
