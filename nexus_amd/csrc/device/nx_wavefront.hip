@@ -67,11 +67,156 @@ NXD int wave_sum(int v)
     return v;
 }
 
-// U: sub-tiles per tile.  A tile is U * blockDim.x consecutive items, thread t handles items t, t + blockDim.x, ... of it; the
+template <bool ORDERED, int K>
+struct SlotAllocator {
+    int* sWave;  // [K][kMaxWavesPerBlock] per-wave counts of the current tile
+    int* sBase;  // [K] base slot of the current tile
+    int* sTile;  // ORDERED: the ticket of the current tile
+    int* counter0;  // the K counter words are counter0 + k * counterStep (an address computation, not an array of pointers: an
+    int counterStep;  // array indexed by anything but a constant makes the allocator a private-memory object in LDS or scratch)
+    NX_G unsigned long long* status;  // ORDERED: tile status words, [tile][kScanWords]
+    NX_G int* ticket;
+    NX_G FrameState* frame;
+    uint32_t serial;
+    int size, lastTile;
+
+    // `kind`: 0 logic, 1 + NX_MAT_* material kernel; `items`: size of the launch's input queue
+    NXD void init(const DeviceState* S, int* const first, const int step, const int kind, const int bounce, const int items)
+    {
+        __shared__ int wave[K * kMaxWavesPerBlock];
+        __shared__ int base[K];
+        __shared__ int tile;
+        sWave = wave;
+        sBase = base;
+        sTile = &tile;
+        counter0 = first;
+        counterStep = step;
+        size = items;
+        lastTile = (items + (int)blockDim.x - 1) / (int)blockDim.x - 1;
+        if (ORDERED) {
+            status = S->scanStatus;
+            ticket = &S->counters->scanTicket[kind][bounce];
+            frame = S->frame;
+            serial = S->frame->scanEpoch * 1024u + (uint32_t)bounce * 8u + (uint32_t)kind;
+        }
+    }
+    NXD int* counter_of(const int k) const
+    {
+        return counter0 + k * counterStep;
+    }
+    // first item of the workgroup's first / next tile (>= size: none left)
+    NXD int first_tile() { return ORDERED ? take() : (int)(blockIdx.x * blockDim.x); }
+    NXD int next_tile(const int tile) { return ORDERED ? take() : tile + (int)(gridDim.x * blockDim.x); }
+    NXD int take()
+    {
+        __syncthreads();  // the previous tile's readers are done with sTile
+        if (threadIdx.x == 0) *sTile = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int t = *sTile;
+        return t > lastTile ? size : t * (int)blockDim.x;
+    }
+
+    // ORDERED, one wave per queue: the slots taken by all tiles before tile t of this launch (and by the kernels before it in
+    // the chain), and this tile's count published for its successors
+    NXD int look_back(const int k, const int t, const int total)
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        NX_G unsigned long long* const st = status + k;
+        if (t == 0) {
+            const int base = *counter_of(k);
+            if (lane == 0) __hip_atomic_store(&st[0], scan_word(serial, kScanPrefix, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return base;
+        }
+        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanAggregate, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0, nearest = t - 1;
+        uint32_t spins = 0u;
+        for (;;) {
+            const int j = nearest - lane;  // lane 0 looks at the nearest predecessor not summed yet
+            uint32_t tag = (serial << 2) | kScanPrefix;  // (tiles "before tile 0" never decide: tile 0 itself is a prefix)
+            int value = 0;
+            if (j >= 0) {
+                const unsigned long long w = __hip_atomic_load(&st[(size_t)j * kScanWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tag = (uint32_t)(w >> 32);
+                value = (int)(uint32_t)w;
+            }
+            const bool ready = (tag >> 2) == serial && (tag & 3u) != 0u;
+            const unsigned long long notReady = __ballot(!ready), prefixes = __ballot(ready && (tag & 3u) == kScanPrefix);
+            const int firstNot = notReady ? __ffsll((long long)notReady) - 1 : kWave;
+            const int firstPrefix = prefixes ? __ffsll((long long)prefixes) - 1 : kWave;
+            if (firstPrefix < firstNot) {  // every tile between here and a known prefix has published its count
+                excl += wave_sum(lane <= firstPrefix ? value : 0);
+                break;
+            }
+            // counts in front of the first tile that has not published yet are final: take them, then look again from there
+            excl += wave_sum(lane < firstNot ? value : 0);
+            nearest -= firstNot;
+            if (firstNot < kWave) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 20)) {  // (about a second; see kErrScanStalled)
+                    if (lane == 0) atomicOr(&frame->errorWord, kErrScanStalled);
+                    break;
+                }
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanPrefix, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return excl;
+    }
+
+    // `tile`: first item of the tile (what first_tile / next_tile returned); `region`: the queue region this tile appends to
+    // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words
+    NXD void alloc(const bool (&want)[K], int (&slot)[K], const int tile, const int region = 0)
+    {
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        const int nWaves = blockDim.x / kWave;
+        unsigned long long mask[K];
+        __syncthreads();  // the previous tile's readers are done with sWave / sBase
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            mask[k] = __ballot(want[k]);
+            if (lane == 0) sWave[k * kMaxWavesPerBlock + wave] = __popcll(mask[k]);
+        }
+        __syncthreads();
+        if (ORDERED) {
+            if (wave < K) {  // (a workgroup has at least K waves: 256 threads, K <= 4)
+                const int total = wave_sum(lane < nWaves ? sWave[wave * kMaxWavesPerBlock + lane] : 0);
+                const int t = tile / (int)blockDim.x;
+                const int excl = look_back(wave, t, total);
+                if (lane == 0) {
+                    sBase[wave] = excl;
+                    if (t == lastTile) *counter_of(wave) = excl + total;
+                }
+            }
+        } else if (threadIdx.x < K) {
+            int total = 0;
+            for (int w = 0; w < nWaves; w++) total += sWave[threadIdx.x * kMaxWavesPerBlock + w];
+            int* const word = counter_of((int)threadIdx.x) + region * kRegionStride;
+            sBase[threadIdx.x] = total ? atomicAdd(word, total) : 0;
+#ifdef NX_EXTRA_ATOMICS
+            // experiment: are the logic / material kernels bound by the returning atomics on their queue
+            // counters?  NX_EXTRA_ATOMICS more of them per tile and counter, adding zero
+            for (int x = 0; x < NX_EXTRA_ATOMICS; x++)
+                if (total && atomicAdd(word, 0) == -123456789) sBase[threadIdx.x] = 0;  // (returning, result unused)
+#endif
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            slot[k] = -1;
+            if (want[k]) {
+                int prefix = 0;
+                for (int w = 0; w < wave; w++) prefix += sWave[k * kMaxWavesPerBlock + w];
+                slot[k] = sBase[k] + prefix + __popcll(mask[k] & ((1ull << lane) - 1ull));
+            }
+        }
+    }
+};
+
+// The same allocator for tiles of U sub-tiles (the logic kernel: two items per thread; the material kernels keep SlotAllocator above,
+// whose register allocation the generalised text disturbed: 18-21 -> 19-35 spilled VGPRs).  U: sub-tiles per tile.  A tile is U * blockDim.x consecutive items, thread t handles items t, t + blockDim.x, ... of it; the
 // slots of sub-tile u lie in front of those of sub-tile u + 1 (ascending item index, as ORDERED needs).  One ticket, one look-back
 // and one atomic per queue cover the whole tile: what a tile costs beside its items is paid once per U * blockDim.x of them.
-template <bool ORDERED, int K, int U = 1>
-struct SlotAllocator {
+template <bool ORDERED, int K, int U>
+struct TileAllocator {
     int* sWave;  // [U * K][kMaxWavesPerBlock] per-wave counts of the current tile
     int* sBase;  // [U * K] base slot of the current tile's sub-tile u in queue k
     int* sTile;  // ORDERED: the ticket of the current tile
@@ -486,7 +631,7 @@ __global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(cons
     // barriers (late bounces carry a few thousand items; an all-empty launch used to cost 30 us)
     if ((int)(blockIdx.x * blockDim.x) * U >= size) return;
     const uint32_t frame = S->frame->frameNumber;
-    SlotAllocator<ORDERED, 4, U> slots;
+    TileAllocator<ORDERED, 4, U> slots;
     // queue k of this kernel: the material queue of type k
     slots.init(S, &C->region[0].materialSize[0][bounce], kMaxBounceSlots, 0, bounce, size);
     const ProducerRegions out = producer_regions(S, size, U * (int)blockDim.x);
@@ -802,11 +947,11 @@ __global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBl
                              },
                              wantShadow, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
         }
-        const bool want[1][2] = {{wantShadow, wantTrace}};
-        int slot[1][2];
+        const bool want[2] = {wantShadow, wantTrace};
+        int slot[2];
         const int region = out.of_tile(tile), regionBase = region * (int)S->queueShardCap;
         slots.alloc(want, slot, tile, region);
-        const int shadowSlot = regionBase + slot[0][0], traceSlot = regionBase + slot[0][1];
+        const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
         if (wantShadow) {
             S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
             S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
