@@ -7,7 +7,11 @@ OBJDIR    := build/obj
 # DEVEXTRA -fno-slp-vectorize (device files only): the SLP vectorizer pairs fp32 operations into v_pk_fma_f32 / v_pk_mul_f32; on gfx950 those are not
 # double-rate and the register shuffling they need costs more than they save (trace kernel: +9 %, 10 fewer VGPRs)
 COMMON    := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Inexus_amd/csrc/device -Inexus_amd/csrc/host -Wall -Wno-unused-function
-DEVEXTRA  ?= -fno-slp-vectorize
+# -mllvm -amdgpu-use-amdgpu-trackers=1: the machine scheduler follows register pressure with the AMDGPU-specific trackers instead of
+# the generic ones — the material kernels spill 12-14 VGPRs instead of 18-21 at their 96-register budget (-10 % on them), the trace
+# kernels 3 / 0 instead of 7 / 1; -amdgpu-sched-strategy=max-memory-clause on top of it: another 1 % (round 4: driver command 2 021 ->
+# 2 091, default 2 308 -> 2 397, configs[4] 1 263 -> 1 293; images bit-identical: scheduling reorders no arithmetic)
+DEVEXTRA  ?= -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -amdgpu-sched-strategy=max-memory-clause
 DEVFLAGS  := $(COMMON) $(DEVEXTRA) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
 HOSTFLAGS := $(COMMON)
 

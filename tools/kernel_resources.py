@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Iinclude", "-Inexus_amd/csrc/device", "-Inexus_amd/csrc/host", "-fno-slp-vectorize",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Iinclude", "-Inexus_amd/csrc/device", "-Inexus_amd/csrc/host", "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause",
          "--offload-arch=gfx950", "-DNX_BUILT_FOR_GFX950=1", "-S", "--cuda-device-only"] + [a for a in sys.argv[1:] if a != "--all"]
 
 
