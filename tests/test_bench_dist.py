@@ -73,3 +73,20 @@ def test_bench_help_prints_its_options_without_a_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     for option in ("--gpus", "--steps", "--warmup", "--config", "--passes-in-flight"):
         assert option in r.stdout
+
+
+def test_the_pass_plan_of_the_drivers_scaling_run():
+    """`--steps 20` on N = 1, 2, 4, 8 GPUs: under weak scaling (a step = one frame per GPU) every rank renders its tiles of 20 N frames as
+    ONE pass — the path count of the 1-GPU pass —, under strong scaling its tiles of 20 frames; the default 512 steps are passes of
+    64 N frames (at most 512), four in flight.  (bench.plan_schedule; no GPU needed.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for n in (1, 2, 4, 8):
+        cap = min(64 * n, 512)
+        assert bench.plan_schedule(20 * n, cap, None, False, 1.0 / n) == (20 * n, 1, 1)  # weak
+        assert bench.plan_schedule(20, cap, None, False, 1.0 / n) == (20, 1, 1)          # strong
+        S, R, passes = bench.plan_schedule(512 * n, cap, None, False, 1.0 / n)
+        assert S == cap and R == 4 and passes == 512 * n // cap
+        # the paths of a rank's pass never exceed what the 1-GPU run allocates for its own
+        assert S * (1920 * 1080 // n) <= 128 * 1920 * 1080
