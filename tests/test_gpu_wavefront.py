@@ -471,3 +471,22 @@ def test_ordered_compaction_with_passes_in_flight_and_across_the_epoch_wrap(gpu_
                 assert SH.frames_identical(got[f], want[f], "ordered, %d in flight, frame %d" % (R, f + 1))
         assert SH.frames_identical(ctx.read_accumulation(), orc.accumulation(), "accumulation, %d in flight" % R)
         assert np.array_equal(ctx.read_rgba8(), orc.rgba8())
+
+
+@pytest.mark.parametrize("rng_mode,compact_mode", [(pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED), (pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST)])
+@pytest.mark.parametrize("W,H", [(1, 1), (33, 31), (32, 32), (41, 25), (23, 89), (64, 32), (683, 3), (241, 17)],
+                         ids=["1", "1023", "1024", "1025", "2047", "2048", "2049", "4097"])
+def test_path_counts_at_the_tile_boundaries_of_the_slot_allocators(gpu_ctx_factory, rng_mode, compact_mode, W, H):
+    """The logic kernel hands out slots per tile of 2 048 items (two per thread, sub-tile 0's slots in front of sub-tile 1's), the
+    material kernels per 256 (racing) or 1 024 (ordered): viewports whose pixel count — the size of the first queue — sits on, one
+    below and one above those edges, in the serial-order mode and in the racing one, every frame and queue size against the oracle."""
+    scene = SH.material_zoo_scene(W, H, path_length=4)
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(rng_mode, compact_mode, pod.CONDUCTOR_EXTENDED)
+    ctx.set_tail_bounce(0)
+    got = _render_gpu(ctx, 2)
+    orc, want = _render_oracle(scene, W * H, 2, rng_mode, pod.CONDUCTOR_EXTENDED)
+    for f in range(2):
+        assert SH.frames_identical(got[f], want[f], "%d paths, frame %d" % (W * H, f + 1))
+    _check_queue_sizes(ctx.read_queue_sizes(), orc.queue_sizes(), 4)
