@@ -11,7 +11,16 @@ COMMON    := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Inexus_amd/csrc/d
 # the generic ones — the material kernels spill 12-14 VGPRs instead of 18-21 at their 96-register budget (-10 % on them), the trace
 # kernels 3 / 0 instead of 7 / 1; -amdgpu-sched-strategy=max-memory-clause on top of it: another 1 % (round 4: driver command 2 021 ->
 # 2 091, default 2 308 -> 2 397, configs[4] 1 263 -> 1 293; images bit-identical: scheduling reorders no arithmetic)
-DEVEXTRA  ?= -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -amdgpu-sched-strategy=max-memory-clause
+# The two -mllvm options are internal LLVM cl::opts (present in ROCm 7.2's hipcc): a toolchain without them rejects the whole
+# command line ("Unknown command line argument"), so they are probed once — an empty translation unit compiled with them — and
+# left out when the probe fails (the build then still succeeds, the kernels spill a little more: see above).
+SCHEDFLAGS := -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -amdgpu-sched-strategy=max-memory-clause
+SCHED_OK   := $(shell echo '__global__ void k(){}' | $(HIPCC) -x hip --offload-arch=$(ARCH) $(SCHEDFLAGS) -c -o /dev/null - >/dev/null 2>&1 && echo yes)
+ifneq ($(SCHED_OK),yes)
+$(warning hipcc does not accept "$(SCHEDFLAGS)": building the device code without them (material kernels spill 18-21 VGPRs instead of 12-14))
+SCHEDFLAGS :=
+endif
+DEVEXTRA  ?= -fno-slp-vectorize $(SCHEDFLAGS)
 DEVFLAGS  := $(COMMON) $(DEVEXTRA) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
 HOSTFLAGS := $(COMMON)
 

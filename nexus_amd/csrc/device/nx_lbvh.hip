@@ -230,6 +230,12 @@ __global__ void __launch_bounds__(kBlock) radix_tree_kernel(const unsigned long 
 // a store is written through to where every XCD sees it, a load does not stop at this XCD's L2 — so that the passes need no
 // __threadfence() (an L2 write-back + invalidate per node visit: see cost_kernel).  Box arrays are 8-byte aligned (24-byte
 // elements from an allocation's start).
+// What publishes a child's box here is gfx950 behaviour, not the HIP / LLVM memory model (which gives relaxed atomics no release /
+// acquire edge): device-scope stores are written through (sc1), a wave's memory instructions issue in order, and the arrival
+// counter is bumped only after `s_waitcnt vmcnt(0)` on the stores.  Another target must put the fences back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "nx_lbvh.hip: load_fresh / store_shared publish without fences, which is only argued for gfx950 (see the comment above)"
+#endif
 __device__ __forceinline__ Box3 load_fresh(const Box3* p)
 {
     const unsigned long long* w = reinterpret_cast<const unsigned long long*>(p);
@@ -1549,6 +1555,10 @@ int lbvh_build_batch(nxhip_ctx* c, const nx_triangle* dTris, const std::vector<u
     };
     if (!layout() || !arena.reserve() || !layout()) return NXHIP_ERR_HIP;
     if (!primIdx.alloc((size_t)n * 4) || !isect.alloc((size_t)n * kTriStride * sizeof(float4))) return NXHIP_ERR_HIP;
+    // (zeroed: isect_kernel below runs before the per-mesh counters are read back and checked, and an entry the collapse left
+    //  unwritten — its 'cannot happen' branch, a mesh that came out short — must index a triangle of the mesh, not wherever
+    //  the allocation's previous contents point; the build then ends in NXHIP_ERR_INVALID instead of a wild device read)
+    NX_HIP(hipMemsetAsync(primIdx.p, 0, (size_t)n * 4, c->stream));
     lap("allocations (1)");
     NX_HIP(hipMemcpyAsync(dMeshes.p, meshes.data(), (size_t)M * sizeof(BatchMesh), hipMemcpyHostToDevice, st));  // (`meshes` outlives the synchronisations below)
     batch_fill_kernel<<<M, kBlock, 0, st>>>(dMeshes.as<BatchMesh>(), meshOf.as<int>(), ws.segOfA.as<int>());

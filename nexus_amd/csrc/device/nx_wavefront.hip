@@ -67,6 +67,53 @@ NXD int wave_sum(int v)
     return v;
 }
 
+// Decoupled look-back of the ordered compaction, ONE text for both allocators below (one wave per queue calls it): the slots taken
+// by all tiles before tile t of this launch (and by the kernels before it in the chain: tile 0 starts from the counter word), and
+// this tile's count published for its successors.  `st`: the queue's status words ([tile * kScanWords]), `counter`: the queue's
+// counter word, `serial`: the launch's tag (words of other launches read as "not there yet").
+NXD int scan_look_back(NX_G unsigned long long* const st, const int* const counter, NX_G FrameState* const frame, const uint32_t serial, const int t, const int total)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    if (t == 0) {
+        const int base = *counter;
+        if (lane == 0) __hip_atomic_store(&st[0], scan_word(serial, kScanPrefix, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return base;
+    }
+    if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanAggregate, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int excl = 0, nearest = t - 1;
+    uint32_t spins = 0u;
+    for (;;) {
+        const int j = nearest - lane;  // lane 0 looks at the nearest predecessor not summed yet
+        uint32_t tag = (serial << 2) | kScanPrefix;  // (tiles "before tile 0" never decide: tile 0 itself is a prefix)
+        int value = 0;
+        if (j >= 0) {
+            const unsigned long long w = __hip_atomic_load(&st[(size_t)j * kScanWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tag = (uint32_t)(w >> 32);
+            value = (int)(uint32_t)w;
+        }
+        const bool ready = (tag >> 2) == serial && (tag & 3u) != 0u;
+        const unsigned long long notReady = __ballot(!ready), prefixes = __ballot(ready && (tag & 3u) == kScanPrefix);
+        const int firstNot = notReady ? __ffsll((long long)notReady) - 1 : kWave;
+        const int firstPrefix = prefixes ? __ffsll((long long)prefixes) - 1 : kWave;
+        if (firstPrefix < firstNot) {  // every tile between here and a known prefix has published its count
+            excl += wave_sum(lane <= firstPrefix ? value : 0);
+            break;
+        }
+        // counts in front of the first tile that has not published yet are final: take them, then look again from there
+        excl += wave_sum(lane < firstNot ? value : 0);
+        nearest -= firstNot;
+        if (firstNot < kWave) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) {  // (about a second; see kErrScanStalled)
+                if (lane == 0) atomicOr(&frame->errorWord, kErrScanStalled);
+                break;
+            }
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanPrefix, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 template <bool ORDERED, int K>
 struct SlotAllocator {
     int* sWave;  // [K][kMaxWavesPerBlock] per-wave counts of the current tile
@@ -116,51 +163,7 @@ struct SlotAllocator {
         return t > lastTile ? size : t * (int)blockDim.x;
     }
 
-    // ORDERED, one wave per queue: the slots taken by all tiles before tile t of this launch (and by the kernels before it in
-    // the chain), and this tile's count published for its successors
-    NXD int look_back(const int k, const int t, const int total)
-    {
-        const int lane = threadIdx.x & (kWave - 1);
-        NX_G unsigned long long* const st = status + k;
-        if (t == 0) {
-            const int base = *counter_of(k);
-            if (lane == 0) __hip_atomic_store(&st[0], scan_word(serial, kScanPrefix, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return base;
-        }
-        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanAggregate, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int excl = 0, nearest = t - 1;
-        uint32_t spins = 0u;
-        for (;;) {
-            const int j = nearest - lane;  // lane 0 looks at the nearest predecessor not summed yet
-            uint32_t tag = (serial << 2) | kScanPrefix;  // (tiles "before tile 0" never decide: tile 0 itself is a prefix)
-            int value = 0;
-            if (j >= 0) {
-                const unsigned long long w = __hip_atomic_load(&st[(size_t)j * kScanWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tag = (uint32_t)(w >> 32);
-                value = (int)(uint32_t)w;
-            }
-            const bool ready = (tag >> 2) == serial && (tag & 3u) != 0u;
-            const unsigned long long notReady = __ballot(!ready), prefixes = __ballot(ready && (tag & 3u) == kScanPrefix);
-            const int firstNot = notReady ? __ffsll((long long)notReady) - 1 : kWave;
-            const int firstPrefix = prefixes ? __ffsll((long long)prefixes) - 1 : kWave;
-            if (firstPrefix < firstNot) {  // every tile between here and a known prefix has published its count
-                excl += wave_sum(lane <= firstPrefix ? value : 0);
-                break;
-            }
-            // counts in front of the first tile that has not published yet are final: take them, then look again from there
-            excl += wave_sum(lane < firstNot ? value : 0);
-            nearest -= firstNot;
-            if (firstNot < kWave) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 20)) {  // (about a second; see kErrScanStalled)
-                    if (lane == 0) atomicOr(&frame->errorWord, kErrScanStalled);
-                    break;
-                }
-            }
-        }
-        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanPrefix, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return excl;
-    }
+    NXD int look_back(const int k, const int t, const int total) { return scan_look_back(status + k, counter_of(k), frame, serial, t, total); }
 
     // `tile`: first item of the tile (what first_tile / next_tile returned); `region`: the queue region this tile appends to
     // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words
@@ -265,51 +268,7 @@ struct TileAllocator {
         return t > lastTile ? size : t * tileItems;
     }
 
-    // ORDERED, one wave per queue: the slots taken by all tiles before tile t of this launch (and by the kernels before it in
-    // the chain), and this tile's count published for its successors
-    NXD int look_back(const int k, const int t, const int total)
-    {
-        const int lane = threadIdx.x & (kWave - 1);
-        NX_G unsigned long long* const st = status + k;
-        if (t == 0) {
-            const int base = *counter_of(k);
-            if (lane == 0) __hip_atomic_store(&st[0], scan_word(serial, kScanPrefix, base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return base;
-        }
-        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanAggregate, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int excl = 0, nearest = t - 1;
-        uint32_t spins = 0u;
-        for (;;) {
-            const int j = nearest - lane;  // lane 0 looks at the nearest predecessor not summed yet
-            uint32_t tag = (serial << 2) | kScanPrefix;  // (tiles "before tile 0" never decide: tile 0 itself is a prefix)
-            int value = 0;
-            if (j >= 0) {
-                const unsigned long long w = __hip_atomic_load(&st[(size_t)j * kScanWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tag = (uint32_t)(w >> 32);
-                value = (int)(uint32_t)w;
-            }
-            const bool ready = (tag >> 2) == serial && (tag & 3u) != 0u;
-            const unsigned long long notReady = __ballot(!ready), prefixes = __ballot(ready && (tag & 3u) == kScanPrefix);
-            const int firstNot = notReady ? __ffsll((long long)notReady) - 1 : kWave;
-            const int firstPrefix = prefixes ? __ffsll((long long)prefixes) - 1 : kWave;
-            if (firstPrefix < firstNot) {  // every tile between here and a known prefix has published its count
-                excl += wave_sum(lane <= firstPrefix ? value : 0);
-                break;
-            }
-            // counts in front of the first tile that has not published yet are final: take them, then look again from there
-            excl += wave_sum(lane < firstNot ? value : 0);
-            nearest -= firstNot;
-            if (firstNot < kWave) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 20)) {  // (about a second; see kErrScanStalled)
-                    if (lane == 0) atomicOr(&frame->errorWord, kErrScanStalled);
-                    break;
-                }
-            }
-        }
-        if (lane == 0) __hip_atomic_store(&st[(size_t)t * kScanWords], scan_word(serial, kScanPrefix, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return excl;
-    }
+    NXD int look_back(const int k, const int t, const int total) { return scan_look_back(status + k, counter_of(k), frame, serial, t, total); }
 
     // `tile`: first item of the tile (what first_tile / next_tile returned); `region`: the queue region this tile appends to
     // (uniform over the workgroup; ORDERED keeps one region); counters[] point at region 0's words.  want[u][k]: this thread's

@@ -10,9 +10,9 @@ tags=()
 for spec in "$@"; do
   tag=${spec%%=*}; flags=${spec#*=}
   tags+=($tag)
-  devextra="-fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -amdgpu-sched-strategy=max-memory-clause"                                            # the Makefile's default for device files
+  devextra=""   # empty: the Makefile's own default for device files (it probes the -mllvm scheduler options before using them)
   if [ "${flags:0:1}" = "@" ]; then devextra="${flags:1}"; flags=""; fi   # "@..." = flags for the device files only (replaces the default)
-  make -j16 OUT=build/variants/lib_$tag.so OBJDIR=build/obj_$tag COMMON="$BASEFLAGS $flags" DEVEXTRA="$devextra" >/dev/null 2>gpurun_out/ab/build_$tag.err || { echo "build failed: $tag"; tail -5 gpurun_out/ab/build_$tag.err; exit 1; }
+  make -j16 OUT=build/variants/lib_$tag.so OBJDIR=build/obj_$tag COMMON="$BASEFLAGS $flags" ${devextra:+DEVEXTRA="$devextra"} >/dev/null 2>gpurun_out/ab/build_$tag.err || { echo "build failed: $tag"; tail -5 gpurun_out/ab/build_$tag.err; exit 1; }
   NEXUS_AMD_LIB=build/variants/lib_$tag.so timeout -k 10 120 python -m pytest tests/test_gpu_trace.py -m gpu -x -q 2>&1 | tail -1
 done
 for r in $(seq 1 $ROUNDS); do
