@@ -88,6 +88,8 @@ struct PassSlot {
     bool ownsStream = false;
     DevBuf radiance, rayOrigin;
     DevBuf trRayO, trRayD, trHit, trHitInst, trTp;
+    DevBuf trRayO2, trRayD2, trTp2;  // the second set of rays (TraceQueue::rays[1]): SCAN pipeline only
+    bool queuesScan = false;         // which pipeline the buffers above were allocated for (scan: no material queues; classic: no second ray set)
     DevBuf shRayO, shRayD, shRadiance;
     DevBuf mqHit[4], mqDirInst[4], mqTp[4];
     DevBuf counters, frame, dState;
@@ -102,6 +104,7 @@ struct PassSlot {
         hipGraphExec_t exec = nullptr;
         bool serialShade = false;
         int traceBlocks = 0, tailBounce = 0;
+        int flavor = 0;  // pass_flavor(): pipeline, miss kernel, logic kernel variant
     };
     std::vector<GraphInstance> graphs;
     // pass bookkeeping (slots >= 1 and slot 0 alike)
@@ -198,4 +201,6 @@ struct nxhip_ctx : nxd::PassSlot {
     // material types the scene's materials use (bit NX_MAT_*): a type no material has can never receive a queue item, so its
     // kernel is left out of the pass graph (a launch on the critical path of every bounce, however empty)
     uint32_t materialTypeMask = 0xfu;
+    // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
+    bool classicPipeline = false;
 };

@@ -127,13 +127,35 @@ struct TextureDev {
     uint32_t width, height;
 };
 
-struct TraceQueue {
-    NX_G float4* rayO;
-    NX_G float4* rayD;
-    NX_G float4* hit;
-    NX_G uint32_t* hitInst;
+// The rays of the trace queue: what a material kernel writes and the trace kernel reads.
+struct TraceRays {
+    NX_G float4* rayO;     // origin; w: kRayPassThrough | kRaySurvives (bit patterns, below)
+    NX_G float4* rayD;     // direction; w: path index
     NX_G float4* tp;       // the path's throughput (rgb) and last pdf (w) travel with its ray: see MaterialQueue::tp
 };
+// Two sets of rays: the SCAN pipeline's material kernels of bounce b read the queue of bounce b - 1 (hit, ray direction, path
+// state) while they write the rays of bounce b, so the rays alternate between the two sets by bounce parity (rays[b & 1]); the hit
+// records need no second set (written by trace(b), read by the material kernels of b + 1, which have finished before trace(b + 1)
+// starts).  The CLASSIC pipeline (logic kernel + material queues: the reference's copy, PathTracer.cu:183-206) uses rays[0] only.
+struct TraceQueue {
+    TraceRays rays[2];
+    NX_G float4* hit;        // (t, u, v, triangle)
+    NX_G uint32_t* hitInst;  // instance of the hit | what the path does next << kHitCodeShift (SCAN pipeline; classic: the instance alone)
+};
+// rayO.w of a trace-queue ray, as a bit pattern
+constexpr uint32_t kRayPassThrough = 1u;  // a pass-through continuation: the path's previous vertex stays what it was (keep_previous_vertex)
+constexpr uint32_t kRaySurvives = 2u;     // SCAN pipeline: the Russian-roulette draw of the NEXT logic step (PathTracer.cu:167-175), made by the ray's
+                                          // producer — the draw depends on the path's throughput and on a random number keyed by pixel (or slot), bounce
+                                          // and frame, all known when the ray is made, and only counts if the ray hits
+// hitInst word: the instance in the low bits, a code above them.  InstTrav::instIdx carries the instance's material type + 1 there
+// (inst_code_kernel), so the closest-hit kernel has "which material kernel shades this hit" in the register that holds the hit's
+// instance anyway.  0: nothing to shade (Russian roulette ended the path, or no kernel for the type); 1 .. 4: NX_MAT_* + 1; 7: a miss.
+constexpr int kHitCodeShift = 29;
+constexpr uint32_t kHitInstMask = (1u << kHitCodeShift) - 1u;
+constexpr uint32_t kHitCodeMiss = 7u;
+// the trace kernels' `bounce` argument: bounce | kTraceScanFlag = the SCAN pipeline's launch (ray set by bounce parity, codes in
+// the hit records); without the flag: rays[0], plain hit records (classic pipeline, ray-batch hooks)
+constexpr int kTraceScanFlag = 0x100;
 struct ShadowQueue {
     NX_G float4* rayO;
     NX_G float4* rayD;
@@ -170,9 +192,12 @@ struct RegionCounters {
     int32_t materialSize[4][kMaxBounceSlots];  // enum order DIFFUSE, DIELECTRIC, PLASTIC, CONDUCTOR
     int32_t traceHead[kMaxBounceSlots];        // rays of this region handed out by the closest-hit / any-hit trace launch
     int32_t shadowHead[kMaxBounceSlots];
-    int32_t pad_[1024 - 8 * kMaxBounceSlots];
+    // SCAN pipeline (nx_wavefront.hip shade_scan_kernel): tiles of this region's trace queue handed out so far to the material
+    // kernel of a type, beyond the one every workgroup takes by its rank
+    int32_t scanTile[4][kMaxBounceSlots];
+    int32_t pad_[2048 - 12 * kMaxBounceSlots];
 };
-static_assert(sizeof(RegionCounters) == 4096, "one region's counters per 4 KiB");
+static_assert(sizeof(RegionCounters) == 8192, "one region's counters per 8 KiB");
 constexpr int kRegionStride = (int)(sizeof(RegionCounters) / sizeof(int32_t));  // distance between the same word of two regions
 
 struct Counters {
@@ -292,11 +317,11 @@ constexpr uint64_t layout_stamp()
         offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
-        offsetof(RegionCounters, shadowHead), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
+        offsetof(RegionCounters, shadowHead), offsetof(RegionCounters, scanTile), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),
         sizeof(ShadeInst), offsetof(ShadeInst, tris), offsetof(ShadeInst, material), offsetof(DeviceState, shadeInst), sizeof(InstTrav), offsetof(InstTrav, nodes), offsetof(InstTrav, instIdx), offsetof(InstTrav, root), sizeof(BlasDev), offsetof(BlasDev, nodeCount),
         sizeof(TextureDev), sizeof(TraceQueue), sizeof(ShadowQueue), sizeof(MaterialQueue), sizeof(FrameState), sizeof(TraceStatsDev),
         (uint64_t)kNodeStride, (uint64_t)kTriStride, (uint64_t)kShadeTriStride, (uint64_t)kQueueShards, (uint64_t)kQueueShardSlack, (uint64_t)kRegionStride, (uint64_t)kMaxBounceSlots,
-        (uint64_t)kEnvGuide, (uint64_t)kMaterialTypeOffset, sizeof(nx_material), sizeof(nx_bvh_instance), sizeof(nx_triangle), sizeof(nx_light), sizeof(nx_camera),
+        (uint64_t)kEnvGuide, (uint64_t)kHitCodeShift, sizeof(TraceRays), offsetof(TraceQueue, hit), (uint64_t)kMaterialTypeOffset, sizeof(nx_material), sizeof(nx_bvh_instance), sizeof(nx_triangle), sizeof(nx_light), sizeof(nx_camera),
     };
     for (uint64_t v : w) h = layout_mix(h, v);
     return h;

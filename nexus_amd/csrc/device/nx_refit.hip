@@ -202,6 +202,22 @@ __global__ void __launch_bounds__(kRefitBlock) tlas_refit_kernel(nx_bvh8_node* n
     }
 }
 
+// The material code of every traversal record (nx_device.h, kHitCodeShift): record k — TLAS leaf order — belongs to instance
+// instIdx, whose shading record holds a copy of its material; type + 1 goes above the instance index, where the closest-hit
+// kernel finds it in the register that carries the hit's instance (nx_trace.hip, flush).  Run by the host after it has rebuilt
+// the shading records (refresh_shade_inst: an instance, BLAS or material table changed).
+__global__ void __launch_bounds__(256) inst_code_kernel(const DeviceState* __restrict__ S, InstTrav* travArg, const ShadeInst* shadeInstArg, const uint32_t count)
+{
+    NX_G InstTrav* trav = (NX_G InstTrav*)travArg;
+    const NX_G ShadeInst* shadeInst = (const NX_G ShadeInst*)shadeInstArg;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const uint32_t inst = trav[k].instIdx & kHitInstMask;
+        const int type = (int)shadeInst[inst].material.type;
+        trav[k].instIdx = inst | ((type >= 0 && type <= 3) ? (uint32_t)(type + 1) << kHitCodeShift : 0u);
+    }
+}
+
+const void* inst_code_kernel_ptr() { return (const void*)inst_code_kernel; }
 const void* instance_transform_kernel_ptr() { return (const void*)instance_transform_kernel; }
 const void* tlas_refit_kernel_ptr() { return (const void*)tlas_refit_kernel; }
 

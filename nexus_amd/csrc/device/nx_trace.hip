@@ -41,6 +41,7 @@ constexpr int kReserve = NX_RESERVE;  // most rays reserved per fetch atomic (me
 #ifndef NX_REFILL_BELOW
 #define NX_REFILL_BELOW 40
 #endif
+static_assert((kRaySurvives << 30) == 0x80000000u, "the roulette bit of rayO.w moves to bit 31 of the lane's ray index");
 constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
 template <bool ANY_HIT, bool STATS>
@@ -51,8 +52,13 @@ template <bool ANY_HIT, bool STATS>
 #define NX_WAVES_PER_EU 5
 #endif
 __attribute__((amdgpu_waves_per_eu(NX_WAVES_PER_EU, NX_WAVES_PER_EU)))
-__global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounce)
+__global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* __restrict__ S, const int bounceArg)
 {
+    // bounce | kTraceScanFlag: a launch of the SCAN pipeline — its rays are the set of the bounce's parity, and the closest-hit
+    // record says what the path does next (see the flush below); without the flag: rays[0] and plain hit records
+    const int bounce = bounceArg & 0xff;
+    const bool scan = !ANY_HIT && (bounceArg & kTraceScanFlag) != 0;
+    const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
     // the world-space ray (origin, direction, 1 / direction) of a lane that is inside a transformed instance: parked here on
     // entry and taken back on exit.  (Re-reading the ray from its queue on exit put a second, dependent memory round trip
@@ -77,8 +83,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const auto shard_begin = [&](const int k) { return oneRegion ? k * piece : k * cap; };
     const auto shard_rays = [&](const int k) { return oneRegion ? max(0, min(piece, size - k * piece)) : (int)regionRays[k * kRegionStride]; };
     NX_G int* heads = ANY_HIT ? &C->region[0].shadowHead[bounce] : &C->region[0].traceHead[bounce];
-    GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rayO;
-    GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rayD;
+    GF4 rayO = ANY_HIT ? S->shadow.rayO : S->trace.rays[raySet].rayO;
+    GF4 rayD = ANY_HIT ? S->shadow.rayD : S->trace.rays[raySet].rayD;
     GU4 tlasNodes = S->tlasNodes;
     const NX_G InstTrav* instTrav = S->instTrav;
 #ifdef NX_NO_SCENE_FLAG
@@ -153,8 +159,16 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 cur.x += r.x; cur.y += r.y; cur.z += r.z;
                 *dst = cur;
             } else {
-                S->trace.hit[rayIdx] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
-                S->trace.hitInst[rayIdx] = hitInst;
+                // The hit's instance arrives with its material type + 1 above kHitCodeShift (InstTrav::instIdx), the ray with the
+                // Russian-roulette draw of the next logic step in bit 31 of rayIdx (kRaySurvives, made by the ray's producer).  SCAN
+                // pipeline: the record's instance word then IS the logic step's decision (PathTracer.cu:136-210) — a miss, a path
+                // the roulette ends (0), or the material kernel that shades the hit — and no logic kernel runs; otherwise the plain
+                // instance index.
+                const uint32_t slot = rayIdx & 0x7fffffffu;
+                const bool missed = hitTri == 0xffffffffu;
+                S->trace.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
+                S->trace.hitInst[slot] = scan ? (missed ? (kHitCodeMiss << kHitCodeShift) : ((rayIdx >> 31) ? hitInst : 0u))
+                                              : (missed ? 0xffffffffu : (hitInst & kHitInstMask));
             }
         }
         // ---- refill idle lanes from the wave's reserved range; one atomic reserves kReserve rays of a shard at a time
@@ -204,8 +218,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     const int idx = rngCur + rank;
                     need = false;
                     active = true;
-                    rayIdx = (uint32_t)idx;
                     const float4 o = rayO[idx], d = rayD[idx];
+                    // (closest hit: the producer's roulette draw rides in the top bit, see the flush; a queue holds < 2^31 rays)
+                    rayIdx = ANY_HIT ? (uint32_t)idx : ((uint32_t)idx | ((__float_as_uint(o.w) & kRaySurvives) << 30));
                     org = mk3(o.x, o.y, o.z);
                     dir = mk3(d.x, d.y, d.z);
                     pixelBits = __float_as_uint(d.w);

@@ -274,6 +274,8 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
             }
         }
     }
+    // (an instance record's index word carries the instance's material code above kHitCodeShift: nx_device.h)
+    if (!ANY_HIT && hitTri != 0xffffffffu) hitInst &= kHitInstMask;
     return occluded;
 }
 

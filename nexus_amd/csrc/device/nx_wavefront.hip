@@ -379,6 +379,10 @@ __global__ void __launch_bounds__(kWideBlock) begin_frame_kernel(DeviceState* __
         S->pathCount = S->localCount * frames;
         S->frame->frameNumber = frameLast;
         S->frame->scanEpoch = scanEpoch;
+        // a pending pixel query (D_PixelQuery, PathTracer.cuh:54-58) starts the pass as "nothing hit": the bounce-1 material kernel
+        // writes the instance a primary ray of that pixel hits (the reference's logic kernel writes -1 on a miss, PathTracer.cu:160;
+        // the SCAN pipeline has no kernel that looks at misses when the background is black)
+        if (S->frame->pixelQueryPixel >= 0) S->frame->pixelQueryInstance = -1;
     }
     if (threadIdx.x < kQueueShards) {
         // the primary rays: path i goes to region i / piece (generate_kernel)
@@ -431,8 +435,10 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         // throughput / lastPdf start as (1, 1, 1, 1e10): the bounce-1 logic and shade kernels use those constants instead of
         // reading them back, and the logic kernel stores them for every path that survives its first hit
         const uint32_t region = index / piece, slot = region * cap + (index - region * piece);
-        S->trace.rayO[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-        S->trace.rayD[slot] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
+        // w: kRaySurvives — the bounce-1 logic step draws against a throughput of 1, and rng_next() < 1 always (PathTracer.cu:167-175
+        // with the implicit throughput of :149)
+        S->trace.rays[0].rayO[slot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kRaySurvives));
+        S->trace.rays[0].rayD[slot] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
     }
 }
 
@@ -571,7 +577,7 @@ NXD int logic_path(const DeviceState* S, const int bounce, const uint32_t frame,
 // predecessor hit a pass-through-capable material and therefore stored the right vertex itself.  Same values as before.
 NXD void keep_previous_vertex(const DeviceState* S, const uint32_t pixelIdx, const float4 rayOrigin)
 {
-    if (rayOrigin.w == 0.0f) S->rayOrigin[pixelIdx] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+    if ((__float_as_uint(rayOrigin.w) & kRayPassThrough) == 0u) S->rayOrigin[pixelIdx] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
 }
 
 template <bool ORDERED, int U>
@@ -608,9 +614,9 @@ __global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(cons
             if (index < size) {
                 const int at = in.slot(index);  // where item `index` of the trace queue lives
                 hit[u] = S->trace.hit[at];
-                dirPix[u] = S->trace.rayD[at];
+                dirPix[u] = S->trace.rays[0].rayD[at];
                 pixelIdx[u] = __float_as_uint(dirPix[u].w);
-                const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->trace.tp[at];
+                const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : S->trace.rays[0].tp[at];
                 // the hit's instance is loaded with the rest of the entry, not behind the roulette decision that first needs it: a
                 // load inside the branch is one more dependent round trip per tile for the paths that survive (4 B per item more for
                 // those that do not; logic kernel -4 %)
@@ -619,7 +625,7 @@ __global__ void __launch_bounds__(kLogicBlock, NX_LOGIC_WAVES) logic_kernel(cons
                 f3 bg = mk3(0.0f), t = mk3(0.0f);
                 type[u] = logic_path(S, bounce, frame, (uint32_t)index, pixelIdx[u], hit[u].x, mk3(dirPix[u].x, dirPix[u].y, dirPix[u].z), tp, [&]() { return hitInstance; }, miss, bg, survived, t,
                                      inst[u], needsPrevVertex);
-                if (needsPrevVertex) keep_previous_vertex(S, pixelIdx[u], S->trace.rayO[at]);
+                if (needsPrevVertex) keep_previous_vertex(S, pixelIdx[u], S->trace.rays[0].rayO[at]);
                 if (miss) {
                     // A background contribution of exactly +0 in all three components (a black environment: the reference's default
                     // backgroundIntensity 0) leaves the pixel's radiance as it is — generate_kernel zeroed it, later additions never
@@ -917,11 +923,210 @@ __global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBl
             S->shadow.radiance[shadowSlot] = make_float4(sh.radiance.x, sh.radiance.y, sh.radiance.z, 0.0f);
         }
         if (wantTrace) {
-            // w: 1 for a pass-through continuation (the path's previous vertex stays what it was: keep_previous_vertex)
-            S->trace.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, updatePath ? 0.0f : 1.0f);
-            S->trace.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
+            // w: kRayPassThrough for a pass-through continuation (the path's previous vertex stays what it was: keep_previous_vertex)
+            S->trace.rays[0].rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, __uint_as_float(updatePath ? 0u : kRayPassThrough));
+            S->trace.rays[0].rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
             // the path state that goes with the ray: the new one, or — a pass-through — the one the path arrived with
-            S->trace.tp[traceSlot] = updatePath ? make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf) : tpdf;
+            S->trace.rays[0].tp[traceSlot] = updatePath ? make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf) : tpdf;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The SCAN pipeline's material kernels: Shade<BSDF> straight from the trace queue, no logic kernel, no material queues.
+//
+// The reference's logic kernel (PathTracer.cu:136-210) reads every trace result, decides miss / Russian roulette / material
+// type and COPIES the survivors into one of four material queues (48 B per path and bounce, :183-206) for the Shade kernels to
+// read back.  Here the decision is already in the hit record when the closest-hit launch ends — the roulette draw is made by the
+// ray's producer and rides in the ray (kRaySurvives), the material type rides in the instance record (InstTrav::instIdx), the
+// trace kernel's flush combines the two into a code beside the hit's instance (nx_trace.hip) — so a material kernel only has to
+// FIND its items: a workgroup walks its share of the trace queue 1 024 rays at a time (one 16-byte load of four instance words
+// per thread), collects the slots whose code is its type in an LDS ring (ballots + one LDS atomic per wave), and shades them
+// 256 at a time with every lane busy, reading hit, direction and path state at the ray's own slot (ascending within a batch).
+// Per path and bounce that is 4 B scanned per material kernel in the graph + 52 B gathered, against the 52 B in / 48 B out of
+// the logic kernel + 48 B in of the material kernel; and one launch less per bounce.  The rays alternate between two sets by
+// bounce parity (TraceQueue), because a kernel of bounce b reads the rays of b - 1 while it writes those of b.
+//
+// Regions: workgroup w serves region w % 8 of the input queue (its blockIdx % 8 is its XCD: the XCD whose trace waves call that
+// region home) and appends to the same region of the output queues, so a region never holds more than it did the bounce before
+// (the primary pieces are even), and no batch mixes regions.  Fast compaction only (slot order = order of the atomics); the
+// ordered mode keeps the classic pipeline, which is the reference's serial-slot semantics.
+constexpr int kScanTile = 1024;  // rays per scan step of a workgroup: four per thread
+constexpr int kScanRing = 2048;  // LDS ring of found slots: fewer than 256 left over + 1 024 new ones at most
+static_assert(kScanTile == 4 * kShadeBlock && kScanRing >= kShadeBlock + kScanTile && (kScanRing & (kScanRing - 1)) == 0, "scan geometry");
+
+template <int TYPE>
+__global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel(const DeviceState* __restrict__ S, const int bounce)
+{
+    __shared__ int sRing[kScanRing];
+    __shared__ int sHead, sTicket;
+    Counters* C = S->counters;
+    const int region = (int)(blockIdx.x & (kQueueShards - 1));
+    const int inRegion = C->region[region].traceSize[bounce - 1];  // rays of this region after trace(bounce - 1)
+    // Tiles: the region's workgroups take one each by their rank, the rest are handed out by ticket (one returning atomic per tile
+    // on the region's own word) — the share of a tile that is this kernel's to shade varies from none to all with what the camera
+    // sees there, so a static split leaves most workgroups waiting for the few whose tiles were full (measured: +40 % on the kernels).
+    // A launch with fewer tiles than workgroups (late bounces) does no atomic at all.
+    const int tiles = (inRegion + kScanTile - 1) / kScanTile;
+    const int rank = (int)(blockIdx.x >> 3), ranks = max(1, (int)(gridDim.x >> 3));
+    if (rank >= tiles) return;
+    int* const ticket = &C->region[region].scanTile[TYPE][bounce];
+    const uint32_t frame = S->frame->frameNumber;
+    const int regionBase = region * (int)S->queueShardCap;
+    const TraceRays in = S->trace.rays[(bounce - 1) & 1], out = S->trace.rays[bounce & 1];
+    const NX_G uint32_t* const codes = S->trace.hitInst + regionBase;
+    SlotAllocator<false, 2> slots;  // 0: shadow requests, 1: continuation rays
+    static_assert(offsetof(RegionCounters, traceSize) + kMaxBounceSlots * sizeof(int32_t) == offsetof(RegionCounters, traceShadowSize), "traceShadowSize follows traceSize");
+    slots.init(S, &C->region[0].traceShadowSize[bounce], -kMaxBounceSlots, 1 + TYPE, bounce, inRegion);
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+    if (threadIdx.x == 0) sHead = 0;
+    __syncthreads();
+    int tail = 0, head = 0;  // ring positions [tail, head) hold found slots not shaded yet (uniform)
+
+    // shades `take` <= 256 slots from the ring's tail
+    const auto shade_batch = [&](const int take) {
+        const bool have = (int)threadIdx.x < take;
+        const int at = regionBase + (have ? sRing[(tail + (int)threadIdx.x) & (kScanRing - 1)] : 0);
+        tail += take;
+        bool wantShadow = false, wantTrace = false, updatePath = false;
+        ShadowPayload sh;
+        f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
+        float nextPdf = 0.0f;
+        uint32_t pixelIdx = 0;
+        float4 tpdf = make_float4(0, 0, 0, 0);
+        if (have) {
+            const uint32_t instanceIdx = S->trace.hitInst[at] & kHitInstMask;
+            const float4 hit = S->trace.hit[at];
+            const float4 dirPix = in.rayD[at];
+            pixelIdx = __float_as_uint(dirPix.w);
+            // the rest of the logic step (PathTracer.cu:167-175): the survivor's throughput is divided by the roulette's
+            // probability (at bounce 1 both are 1)
+            tpdf = make_float4(1.0f, 1.0f, 1.0f, 1.0e10f);
+            if (bounce != 1) {
+                const float4 tp = in.tp[at];
+                const f3 throughput = mk3(tp.x, tp.y, tp.z);
+                const f3 t = throughput / maxcomp3(throughput);
+                tpdf = make_float4(t.x, t.y, t.z, tp.w);
+            }
+            // ... and the path's previous vertex, for hits that can need it (keep_previous_vertex)
+            const uint32_t typeAndFlag = *(const NX_G uint32_t*)((const NX_G char*)&S->shadeInst[instanceIdx].material + kMaterialTypeOffset);
+            if ((typeAndFlag >> 8) & 1u) keep_previous_vertex(S, pixelIdx, in.rayO[at]);
+            shade_path<TYPE>(S, bounce, frame, (uint32_t)at, pixelIdx, hit.y, hit.z, __float_as_uint(hit.w), instanceIdx, mk3(dirPix.x, dirPix.y, dirPix.z), tpdf,
+                             [&]() { return S->rayOrigin[pixelIdx]; },
+                             [&](f3 emitted, uint32_t instIdx) {
+                                 if (bounce == 1 && bounce != (int)S->settings.pathLength && pixelIdx < S->localCount && S->frame->pixelQueryPixel == (int)global_pixel(S, pixelIdx))
+                                     S->frame->pixelQueryInstance = (int)instIdx;
+                                 if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+                                     float4 r = S->radiance[pixelIdx];
+                                     r.x += emitted.x; r.y += emitted.y; r.z += emitted.z;
+                                     S->radiance[pixelIdx] = r;
+                                 }
+                             },
+                             wantShadow, sh, wantTrace, updatePath, nextOrigin, nextDir, nextThroughput, nextPdf);
+        }
+        const bool want[2] = {wantShadow, wantTrace};
+        int slot[2];
+        slots.alloc(want, slot, 0, region);
+        const int shadowSlot = regionBase + slot[0], traceSlot = regionBase + slot[1];
+        if (wantShadow) {
+            S->shadow.rayO[shadowSlot] = make_float4(sh.origin.x, sh.origin.y, sh.origin.z, sh.distance);
+            S->shadow.rayD[shadowSlot] = make_float4(sh.direction.x, sh.direction.y, sh.direction.z, __uint_as_float(pixelIdx));
+            S->shadow.radiance[shadowSlot] = make_float4(sh.radiance.x, sh.radiance.y, sh.radiance.z, 0.0f);
+        }
+        if (wantTrace) {
+            // the path state that goes with the ray: the new one, or — a pass-through — the one the path arrived with
+            const float4 tpNext = updatePath ? make_float4(nextThroughput.x, nextThroughput.y, nextThroughput.z, nextPdf) : tpdf;
+            // the next logic step's Russian roulette, drawn here (kRaySurvives): its random number is keyed by the pixel — or, with
+            // slot-keyed numbers, by the slot the ray goes to — the next bounce and the frame, its probability is the throughput
+            // just computed
+            uint32_t rng = seed_for(S, (uint32_t)traceSlot, pixelIdx, (uint32_t)bounce + 1u, 0u, frame);
+            const bool survives = rng_next(rng) < maxcomp3(mk3(tpNext.x, tpNext.y, tpNext.z));
+            out.rayO[traceSlot] = make_float4(nextOrigin.x, nextOrigin.y, nextOrigin.z, __uint_as_float((updatePath ? 0u : kRayPassThrough) | (survives ? kRaySurvives : 0u)));
+            out.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
+            out.tp[traceSlot] = tpNext;
+        }
+    };
+
+    for (int t = rank;;) {
+        // ---- find: which of this tile's rays does this kernel shade
+        {
+            const int r0 = t * kScanTile + 4 * (int)threadIdx.x;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (r0 + 3 < inRegion) w = *(const NX_G uint4*)(codes + r0);
+            else {
+                if (r0 < inRegion) w.x = codes[r0];
+                if (r0 + 1 < inRegion) w.y = codes[r0 + 1];
+                if (r0 + 2 < inRegion) w.z = codes[r0 + 2];
+            }
+            const bool m0 = (w.x >> kHitCodeShift) == (uint32_t)(TYPE + 1), m1 = (w.y >> kHitCodeShift) == (uint32_t)(TYPE + 1);
+            const bool m2 = (w.z >> kHitCodeShift) == (uint32_t)(TYPE + 1), m3 = (w.w >> kHitCodeShift) == (uint32_t)(TYPE + 1);
+            const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
+            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+            const int total = n0 + n1 + n2 + n3;
+            if (total) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sHead, total);  // (an LDS atomic: the ring's head)
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (m0) sRing[(base + __popcll(b0 & laneLt)) & (kScanRing - 1)] = r0;
+                if (m1) sRing[(base + n0 + __popcll(b1 & laneLt)) & (kScanRing - 1)] = r0 + 1;
+                if (m2) sRing[(base + n0 + n1 + __popcll(b2 & laneLt)) & (kScanRing - 1)] = r0 + 2;
+                if (m3) sRing[(base + n0 + n1 + n2 + __popcll(b3 & laneLt)) & (kScanRing - 1)] = r0 + 3;
+            }
+        }
+        __syncthreads();
+        head = sHead;
+        // the next tile: by ticket (issued here, needed only after this tile's batches)
+        if (threadIdx.x == 0) sTicket = tiles > ranks ? ranks + atomicAdd(ticket, 1) : tiles;
+        // ---- shade: full batches; what is left over waits for the next tile's finds, or goes last
+        while (head - tail >= kShadeBlock) shade_batch(kShadeBlock);
+        __syncthreads();  // the ticket is there; and nobody appends to the ring before everybody has read its head
+        t = sTicket;
+        if (t >= tiles) break;
+    }
+    if (head - tail > 0) shade_batch(head - tail);
+    // the items this workgroup shaded, for nxhip_read_queue_sizes (the reference's per-type queue sizes, D_QueueSize)
+    if (threadIdx.x == 0 && head) atomicAdd(&C->region[region].materialSize[TYPE][bounce], head);
+}
+
+// The reference's queue sizes count the hits of a material type whether or not a kernel shades them (its conductor kernel's body is
+// commented out, PathTracer.cu:475-478, but the logic kernel still fills that queue): with NX_CONDUCTOR_REFERENCE the SCAN
+// pipeline has no conductor kernel to count its items, so this one does (4 B per ray; in the graph only in that mode).
+__global__ void __launch_bounds__(kWideBlock) count_scan_kernel(const DeviceState* __restrict__ S, const int bounce, const int type)
+{
+    Counters* C = S->counters;
+    const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
+    int n = 0;
+    for (int index = (int)(blockIdx.x * blockDim.x + threadIdx.x); index < in.total; index += (int)(gridDim.x * blockDim.x))
+        n += (S->trace.hitInst[in.slot(index)] >> kHitCodeShift) == (uint32_t)(type + 1) ? 1 : 0;
+    n = wave_sum(n);
+    if ((threadIdx.x & (kWave - 1)) == 0 && n) atomicAdd(&C->region[0].materialSize[type][bounce], n);
+}
+
+// What is left of the logic kernel in the SCAN pipeline when a miss can contribute: the environment (flat colour or map, MIS-
+// weighted against the environment sampler) added to the radiance of the paths that missed — PathTracer.cu:152-164.  In the
+// graph only when the scene has an environment map or a background that is not black.
+__global__ void __launch_bounds__(kWideBlock) miss_scan_kernel(const DeviceState* __restrict__ S, const int bounce)
+{
+    Counters* C = S->counters;
+    const QueueView in = queue_view(&C->region[0].traceSize[bounce - 1], S->queueShardCap);
+    const uint32_t frame = S->frame->frameNumber;
+    const TraceRays rays = S->trace.rays[(bounce - 1) & 1];
+    for (int index = (int)(blockIdx.x * blockDim.x + threadIdx.x); index < in.total; index += (int)(gridDim.x * blockDim.x)) {
+        const int at = in.slot(index);
+        if ((S->trace.hitInst[at] >> kHitCodeShift) != kHitCodeMiss) continue;
+        const float4 dirPix = rays.rayD[at];
+        const uint32_t pixelIdx = __float_as_uint(dirPix.w);
+        const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : rays.tp[at];
+        bool miss, survived, needsPrevVertex;
+        f3 bg = mk3(0.0f), t = mk3(0.0f);
+        uint32_t inst = 0;
+        logic_path(S, bounce, frame, (uint32_t)at, pixelIdx, 1e30f, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return 0u; }, miss, bg, survived, t, inst, needsPrevVertex);
+        if ((__float_as_uint(bg.x) | __float_as_uint(bg.y) | __float_as_uint(bg.z)) != 0u) {  // (as the logic kernel: +0 changes nothing)
+            float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
+            r.x += bg.x; r.y += bg.y; r.z += bg.z;
+            if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
+            S->radiance[pixelIdx] = r;
         }
     }
 }
@@ -937,8 +1142,13 @@ __global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBl
 #ifndef NX_TAIL_REFILL_BELOW
 #define NX_TAIL_REFILL_BELOW 40
 #endif
-__global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __restrict__ S, const int firstBounce)
+__global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __restrict__ S, const int firstBounceArg)
 {
+    // firstBounce | kTraceScanFlag: the pass ran the SCAN pipeline so far — the rays of trace(firstBounce - 1) are in the set of
+    // that bounce's parity and the hit records carry codes (which this kernel does not need: it makes the logic step's decisions
+    // itself, with the same random numbers)
+    const int firstBounce = firstBounceArg & 0xff;
+    const TraceRays rays = S->trace.rays[(firstBounceArg & kTraceScanFlag) ? ((firstBounce - 1) & 1) : 0];
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
     Counters* C = S->counters;
     const QueueView in = queue_view(&C->region[0].traceSize[firstBounce - 1], S->queueShardCap);
@@ -974,16 +1184,16 @@ __global__ void __launch_bounds__(kTraceBlock) tail_kernel(const DeviceState* __
                 index = mine;
                 const int at = in.slot(mine);
                 const float4 hit = S->trace.hit[at];
-                const float4 dirPix = S->trace.rayD[at];
-                inst = S->trace.hitInst[at];
+                const float4 dirPix = rays.rayD[at];
+                inst = S->trace.hitInst[at] & kHitInstMask;
                 pixelIdx = __float_as_uint(dirPix.w);
                 dir = mk3(dirPix.x, dirPix.y, dirPix.z);
                 hitT = hit.x; hu = hit.y; hv = hit.z; tri = __float_as_uint(hit.w);
-                tp = S->trace.tp[at];
+                tp = rays.tp[at];
                 // the path's previous vertex: the origin of the ray that produced this hit, or, after a pass-through, what
                 // the logic step of the pass-through surface kept
-                ro = S->trace.rayO[at];
-                if (ro.w != 0.0f) ro = S->rayOrigin[pixelIdx];
+                ro = rays.rayO[at];
+                if (__float_as_uint(ro.w) & kRayPassThrough) ro = S->rayOrigin[pixelIdx];
                 rad = S->radiance[pixelIdx];
                 bounce = firstBounce;
                 alive = true;
@@ -1193,6 +1403,17 @@ const void* shade_kernel_ptr(int type, bool ordered)
     default: return ordered ? (const void*)shade_kernel<NX_MAT_CONDUCTOR, true> : (const void*)shade_kernel<NX_MAT_CONDUCTOR, false>;
     }
 }
+const void* shade_scan_kernel_ptr(int type)
+{
+    switch (type) {
+    case NX_MAT_DIFFUSE: return (const void*)shade_scan_kernel<NX_MAT_DIFFUSE>;
+    case NX_MAT_DIELECTRIC: return (const void*)shade_scan_kernel<NX_MAT_DIELECTRIC>;
+    case NX_MAT_PLASTIC: return (const void*)shade_scan_kernel<NX_MAT_PLASTIC>;
+    default: return (const void*)shade_scan_kernel<NX_MAT_CONDUCTOR>;
+    }
+}
+const void* miss_scan_kernel_ptr() { return (const void*)miss_scan_kernel; }
+const void* count_scan_kernel_ptr() { return (const void*)count_scan_kernel; }
 const void* tail_kernel_ptr() { return (const void*)tail_kernel; }
 const void* begin_frame_kernel_ptr() { return (const void*)begin_frame_kernel; }
 const void* hook_sizes_kernel_ptr() { return (const void*)hook_sizes_kernel; }

@@ -19,6 +19,10 @@ const void* trace_kernel_ptr(bool anyHit, bool stats);
 const void* tail_kernel_ptr();
 const void* logic_kernel_ptr(bool ordered, int items);
 const void* shade_kernel_ptr(int type, bool ordered);
+const void* shade_scan_kernel_ptr(int type);
+const void* miss_scan_kernel_ptr();
+const void* count_scan_kernel_ptr();
+const void* inst_code_kernel_ptr();
 const void* begin_frame_kernel_ptr();
 const void* hook_sizes_kernel_ptr();
 const void* generate_kernel_ptr();
@@ -186,6 +190,21 @@ static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) /
 static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
 static size_t scan_status_tiles(size_t n) { return n / (size_t)std::min(kLogicBlockThreads, kShadeBlockThreads) + 2; }
 
+// Which pipeline a pass runs (nx_wavefront.hip): SCAN — the logic step's decision rides in the hit records and the material kernels
+// pick their items out of the trace queue — whenever slots are handed out by racing atomics; the CLASSIC logic kernel + material
+// queues for the ordered compaction, whose serial slot order IS the reference's copy order (PathTracer.cu:183-206).
+static bool scan_pipeline(const nxhip_ctx* c) { return c->h.compactMode == NX_COMPACT_FAST && !c->classicPipeline; }
+
+static TraceQueue trace_queue_of(const PassSlot* s)
+{
+    TraceQueue t{};
+    t.rays[0] = TraceRays{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trTp.as<float4>()};
+    t.rays[1] = TraceRays{s->trRayO2.as<float4>(), s->trRayD2.as<float4>(), s->trTp2.as<float4>()};
+    t.hit = s->trHit.as<float4>();
+    t.hitInst = s->trHitInst.as<uint32_t>();
+    return t;
+}
+
 // The device-state block of a slot: the scene part of the host mirror plus the slot's own queues, counters and frame words.
 static void compose_view(nxhip_ctx* c, PassSlot* s)
 {
@@ -194,7 +213,7 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     if (s != static_cast<PassSlot*>(c)) {
         v.radiance = s->radiance.as<float4>();
         v.rayOrigin = s->rayOrigin.as<float4>();
-        v.trace = TraceQueue{s->trRayO.as<float4>(), s->trRayD.as<float4>(), s->trHit.as<float4>(), s->trHitInst.as<uint32_t>(), s->trTp.as<float4>()};
+        v.trace = trace_queue_of(s);
         v.shadow = ShadowQueue{s->shRayO.as<float4>(), s->shRayD.as<float4>(), s->shRadiance.as<float4>()};
         for (int m = 0; m < 4; m++) v.material[m] = MaterialQueue{s->mqHit[m].as<float4>(), s->mqDirInst[m].as<float4>(), s->mqTp[m].as<float4>()};
     }
@@ -228,13 +247,19 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
 {
     DevBuf* const slots[] = {&q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->trTp, &q->shRayO, &q->shRayD, &q->shRadiance,
                              &q->mqHit[0], &q->mqDirInst[0], &q->mqTp[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqTp[1],
-                             &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2], &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3]};
-    const size_t elem[] = {16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+                             &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2], &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3],
+                             &q->trRayO2, &q->trRayD2, &q->trTp2};
+    const size_t elem[] = {16, 16, 16, 16, 16, 4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     constexpr int kCount = (int)(sizeof(slots) / sizeof(slots[0]));
+    constexpr int kFirstMaterial = 10, kFirstSecondSet = 22;
     static_assert(sizeof(elem) / sizeof(elem[0]) == (size_t)kCount, "one element size per buffer");
+    // the pipeline decides which buffers exist: SCAN has no material queues (192 B per path), CLASSIC no second set of rays (48 B)
+    const bool scan = scan_pipeline(c);
     DevBuf fresh[kCount];
-    for (int i = 0; i < kCount; i++)  // the first two are per path, the rest are queues (regions + slack)
-        if (!fresh[i].alloc((i < 2 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    for (int i = 0; i < kCount; i++) {  // the first two are per path, the rest are queues (regions + slack)
+        const bool unused = scan ? (i >= kFirstMaterial && i < kFirstSecondSet) : i >= kFirstSecondSet;
+        if (!fresh[i].alloc(unused ? 0 : (i < 2 ? n : queue_buffer_slots(n)) * elem[i])) return NXHIP_ERR_HIP;  // `fresh` frees what it got; the context is untouched
+    }
     // ordered compaction: status words of the tiles of the largest possible launch (a queue never holds more than n items;
     // tiles of the smaller of the two workgroup sizes), zeroed once — tag 0 is never a launch's serial
     DevBuf freshStatus;
@@ -248,12 +273,13 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     q->scanStatus = std::move(freshStatus);
     q->scanEpoch = 0;
     q->pathCapacity = n;
+    q->queuesScan = scan;
     if (q == static_cast<PassSlot*>(c)) {
         c->radianceBoundCapacity = 0;
         DeviceState& h = c->h;
         h.radiance = c->radiance.as<float4>();
         h.rayOrigin = c->rayOrigin.as<float4>();
-        h.trace = TraceQueue{c->trRayO.as<float4>(), c->trRayD.as<float4>(), c->trHit.as<float4>(), c->trHitInst.as<uint32_t>(), c->trTp.as<float4>()};
+        h.trace = trace_queue_of(c);
         h.shadow = ShadowQueue{c->shRayO.as<float4>(), c->shRayD.as<float4>(), c->shRadiance.as<float4>()};
         for (int m = 0; m < 4; m++) h.material[m] = MaterialQueue{c->mqHit[m].as<float4>(), c->mqDirInst[m].as<float4>(), c->mqTp[m].as<float4>()};
     }
@@ -266,7 +292,7 @@ static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
 {
     DevBuf* const bufs[] = {&q->radiance, &q->rayOrigin, &q->trRayO, &q->trRayD, &q->trHit, &q->trHitInst, &q->trTp, &q->shRayO, &q->shRayD, &q->shRadiance,
                             &q->mqHit[0], &q->mqDirInst[0], &q->mqTp[0], &q->mqHit[1], &q->mqDirInst[1], &q->mqTp[1], &q->mqHit[2], &q->mqDirInst[2], &q->mqTp[2],
-                            &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3]};
+                            &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3], &q->trRayO2, &q->trRayD2, &q->trTp2};
     for (DevBuf* b : bufs) b->release();
     q->scanStatus.release();
     q->pathCapacity = 0;
@@ -295,9 +321,11 @@ static int alloc_queues(nxhip_ctx* c, size_t n)
 }
 
 // Before a slot is used: its queues exist at the nominal capacity.
+static bool slot_queues_ready(const nxhip_ctx* c, const PassSlot* q) { return q->pathCapacity >= c->queueCapacity && q->pathCapacity > 0 && q->queuesScan == scan_pipeline(c); }
+
 static int ensure_slot_queues(nxhip_ctx* c, PassSlot* q)
 {
-    if (q->pathCapacity >= c->queueCapacity && q->pathCapacity > 0) return NXHIP_OK;
+    if (slot_queues_ready(c, q)) return NXHIP_OK;
     float4* const boundPtr = c->h.radiance;
     const size_t boundCap = c->radianceBoundCapacity;
     const int rc = alloc_slot_queues(c, q, std::max<size_t>(c->queueCapacity, 1));
@@ -453,6 +481,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
             }
+            if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
             if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
             if (const char* e = std::getenv("NX_SHADE_PARALLEL")) c->parallelShade = std::atoi(e);    // tuning experiments only
             if (const char* e = std::getenv("NX_TRACE_BLOCKS_TOTAL")) {  // tuning experiments only
@@ -626,6 +655,16 @@ static int refresh_shade_inst(nxhip_ctx* c)
     c->h.shadeInst = c->shadeInst.as<ShadeInst>();
     c->stateDirty = true;
     c->shadeInstDirty = false;
+    // the traversal records' material codes follow the shading records (nx_refit.hip inst_code_kernel)
+    if (c->instTrav.p && !c->hostInstIdx.empty()) {
+        const DeviceState* S = c->dState.as<DeviceState>();
+        InstTrav* trav = c->instTrav.as<InstTrav>();
+        const ShadeInst* si = c->shadeInst.as<ShadeInst>();
+        const uint32_t count = (uint32_t)c->hostInstIdx.size();
+        void* args[4] = {(void*)&S, (void*)&trav, (void*)&si, (void*)&count};
+        NX_HIP(hipLaunchKernel(inst_code_kernel_ptr(), dim3((count + 255u) / 256u), dim3(256), args, 0, c->stream));
+        NX_HIP(hipStreamSynchronize(c->stream));
+    }
     return NXHIP_OK;
 }
 
@@ -662,6 +701,7 @@ static int refresh_inst_trav(nxhip_ctx* c)
     c->h.instTrav = c->instTrav.as<InstTrav>();
     c->h.sceneFlags = allIdentity ? kSceneAllIdentity : 0u;
     c->stateDirty = true;
+    c->shadeInstDirty = true;  // (the records' material codes are written when the shading records are rebuilt: refresh_shade_inst)
     return NXHIP_OK;
 }
 
@@ -996,6 +1036,7 @@ int nxhip_set_tlas(nxhip_ctx* c, const nx_bvh8_node* nodes, uint32_t nodeCount, 
 try {
     NX_CHECK_CTX(c);
     if (!nodes || !instanceIdx || !instances || nodeCount == 0 || instanceCount == 0) return fail_invalid("nxhip_set_tlas: empty input");
+    if (instanceCount > kHitInstMask) return fail_invalid("nxhip_set_tlas: more than 2^29 - 1 instances (a hit record keeps the instance in 29 bits)");
     NX_HIP(hipSetDevice(c->device));
     for (uint32_t i = 0; i < instanceCount; i++) {
         if (instanceIdx[i] >= instanceCount) return fail_invalid("nxhip_set_tlas: instance index out of range");
@@ -1506,10 +1547,11 @@ struct Launch {
     // argument storage (pointers into this struct are handed to HIP)
     const DeviceState* s;
     int bounce;
+    int type;  // nargs 3: (S, bounce, type)
     const float4* src;
     uint32_t count, slices, sliceStride, firstFrame;
     const uint32_t* dstMap;
-    int nargs;  // 1: (S), 2: (S, bounce), 7: accumulate
+    int nargs;  // 1: (S), 2: (S, bounce), 3: (S, bounce, type), 7: accumulate
 };
 
 Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceState* s, int bounce = -1)
@@ -1610,6 +1652,28 @@ int tail_bounce(const nxhip_ctx* c)
     return bounce;
 }
 
+// What else shapes a pass graph besides the launch geometry: the pipeline, whether a miss can contribute (SCAN pipeline: the miss
+// kernel is in the graph only for a scene with an environment map or a background that is not exactly black — PathTracer.cu:
+// 152-164 adds throughput x background, and +0 changes nothing), and the logic kernel's variant (one item per thread under an
+// environment map).  Part of a graph instance's key, so a change of any of them picks or builds the matching instance.
+constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4;
+int pass_flavor(const nxhip_ctx* c)
+{
+    int f = 0;
+    if (scan_pipeline(c)) f |= kFlavorScan;
+    if (c->hdrMap.texels.p) f |= kFlavorEnvMap;
+    const nx_render_settings& s = c->h.settings;
+    bool black = true;
+    for (int k = 0; k < 3; k++) {
+        const float v = s.backgroundColor[k] * s.backgroundIntensity;  // (the device's own product: sample_background)
+        uint32_t bits;
+        std::memcpy(&bits, &v, 4);
+        black = black && bits == 0u;
+    }
+    if (c->hdrMap.texels.p || !black) f |= kFlavorMissKernel;
+    return f;
+}
+
 // The per-frame kernel sequence, in dependency "levels": launches of one level may run concurrently, a level
 // starts after the previous one has finished.  Reference DAG: Renderer/PathTracer.cpp:114-124, :259-278.
 std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
@@ -1631,6 +1695,37 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int og = whole_regions(c->shadeBlocksPerCU * c->numCUs), ob = ordered ? kShadeBlockOrderedThreads : kShadeBlockThreads;
     const int lg = whole_regions(c->logicBlocksPerCU * c->numCUs), lb = kLogicBlockThreads;
     const int tailFrom = tail_bounce(c);
+    auto in_use = [&](int type) { return (c->materialTypeMask >> type) & 1u; };
+    if (scan_pipeline(c)) {
+        // SCAN pipeline (nx_wavefront.hip): the closest-hit launch leaves the logic step's decision in its hit records, the material
+        // kernels find their items there.  Per bounce: [miss kernel, only when a miss can contribute] -> the material kernels of the
+        // types in use, one after the other -> trace || shadow trace.  One launch less per bounce than the reference's DAG.
+        levels[1][0].bounce = 0 | kTraceScanFlag;
+        const bool misses = pass_flavor(c) & kFlavorMissKernel;
+        for (int bounce = 1; bounce <= pathLength; bounce++) {
+            if (bounce == tailFrom) {  // the rest of the pass in one launch
+                levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce | kTraceScanFlag)});
+                break;
+            }
+            if (misses) levels.push_back({make_launch(miss_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce)});
+            std::vector<Launch> shade;
+            if (in_use(NX_MAT_DIFFUSE)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIFFUSE), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
+            if (in_use(NX_MAT_PLASTIC)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_PLASTIC), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
+            if (in_use(NX_MAT_DIELECTRIC)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIELECTRIC), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
+            if (in_use(NX_MAT_CONDUCTOR) && c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_CONDUCTOR), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
+            if (shade.empty()) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIFFUSE), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));  // (a level cannot be empty)
+            if (in_use(NX_MAT_CONDUCTOR) && c->h.conductorMode != NX_CONDUCTOR_EXTENDED) {  // (counted, not shaded: count_scan_kernel)
+                Launch l = make_launch(count_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce);
+                l.type = NX_MAT_CONDUCTOR;
+                l.nargs = 3;
+                shade.push_back(l);
+            }
+            for (auto& l : shade) levels.push_back({l});
+            levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce | kTraceScanFlag),
+                              make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
+        }
+        return levels;
+    }
     for (int bounce = 1; bounce <= pathLength; bounce++) {
         if (bounce == tailFrom) {  // the rest of the pass in one launch
             levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce)});
@@ -1640,7 +1735,6 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         // graph insertion order of the reference: Diffuse, Plastic, Dielectric, Conductor (PathTracer.cpp:116-120)
         // (only the types some material of the scene has: a queue no material feeds stays empty)
         std::vector<Launch> shade;
-        auto in_use = [&](int type) { return (c->materialTypeMask >> type) & 1u; };
         if (in_use(NX_MAT_DIFFUSE)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIFFUSE, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
         if (in_use(NX_MAT_PLASTIC)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_PLASTIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
         if (in_use(NX_MAT_DIELECTRIC)) shade.push_back(make_launch(shade_kernel_ptr(NX_MAT_DIELECTRIC, ordered), og, ob, NXHIP_K_SHADE, S, bounce));
@@ -1659,7 +1753,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
 void fill_args(Launch& l, void** args)
 {
     args[0] = (void*)&l.s;
-    if (l.nargs == 2) args[1] = (void*)&l.bounce;
+    if (l.nargs == 2 || l.nargs == 3) args[1] = (void*)&l.bounce;
+    if (l.nargs == 3) args[2] = (void*)&l.type;
     if (l.nargs == 7) {
         args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.slices; args[4] = (void*)&l.sliceStride;
         args[5] = (void*)&l.firstFrame; args[6] = (void*)&l.dstMap;
@@ -1691,14 +1786,14 @@ int launch_now(nxhip_ctx* c, Launch& l)
 // The pass graph of one slot for the shape the context asks for right now, built on first use and kept (a handful of shapes
 // exist: small / large pass, passes in flight, tail kernel on or off).  Timing nodes (event records around every kernel) exist
 // only in slot 0, and only one such instance at a time: kernel timing runs one pass at a time and the events are the context's.
-constexpr size_t kMaxGraphInstances = 6;
+constexpr size_t kMaxGraphInstances = 8;
 
 static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
 {
     const bool serial = serial_shade(c);
-    const int blocks = trace_blocks(c, c->traceBlocks), tail = tail_bounce(c);
+    const int blocks = trace_blocks(c, c->traceBlocks), tail = tail_bounce(c), flavor = pass_flavor(c);
     for (auto& g : q->graphs)
-        if (g.serialShade == serial && g.traceBlocks == blocks && g.tailBounce == tail) {
+        if (g.serialShade == serial && g.traceBlocks == blocks && g.tailBounce == tail && g.flavor == flavor) {
             *execOut = g.exec;
             return NXHIP_OK;
         }
@@ -1716,6 +1811,7 @@ static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
     inst.serialShade = serial;
     inst.traceBlocks = blocks;
     inst.tailBounce = tail;
+    inst.flavor = flavor;
     NX_HIP(hipGraphCreate(&inst.graph, 0));
     auto fail = [&](int rc) {
         if (inst.exec) (void)hipGraphExecDestroy(inst.exec);
@@ -1793,7 +1889,7 @@ try {
     if (c->nextSlot >= R) c->nextSlot = 0;
     PassSlot* q = render_slot(c, R, c->nextSlot);
     c->nextSlot = (c->nextSlot + 1) % R;
-    if (q->pathCapacity < c->queueCapacity || q->pathCapacity == 0) {
+    if (!slot_queues_ready(c, q)) {
         rc = ensure_slot_queues(c, q);
         if (rc != NXHIP_OK) return rc;
         rc = upload_state(c);
