@@ -203,4 +203,5 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t materialTypeMask = 0xfu;
     // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
     bool classicPipeline = false;
+    bool scanSeparate = false;  // NX_SCAN_SEPARATE=1 (measurement only): one material launch per type instead of one for all
 };

@@ -951,26 +951,35 @@ __global__ void __launch_bounds__(ORDERED ? kShadeBlockOrderedThreads : kShadeBl
 // region home) and appends to the same region of the output queues, so a region never holds more than it did the bounce before
 // (the primary pieces are even), and no batch mixes regions.  Fast compaction only (slot order = order of the atomics); the
 // ordered mode keeps the classic pipeline, which is the reference's serial-slot semantics.
-constexpr int kScanTile = 1024;  // rays per scan step of a workgroup: four per thread
 constexpr int kScanRing = 2048;  // LDS ring of found slots: fewer than 256 left over + 1 024 new ones at most
-static_assert(kScanTile == 4 * kShadeBlock && kScanRing >= kShadeBlock + kScanTile && (kScanRing & (kScanRing - 1)) == 0, "scan geometry");
+static_assert(kScanRing >= kShadeBlock + 4 * kShadeBlock && (kScanRing & (kScanRing - 1)) == 0, "scan geometry");
 
+// One material type's share of a workgroup's work.  Tiles of `tileRays` rays (1 024: four instance words per thread in one 16-byte
+// load; 256 when the region holds too few rays to give every workgroup a large tile — late bounces, whose launches are as long as
+// their longest workgroup): tile `firstTile` is this workgroup's by its rank (-1: none, it comes over from another type), tiles
+// from `staticTiles` on are handed out by ticket — one returning atomic per tile on the region's own word.  The share of a tile
+// that is this type's to shade varies from none to all with what the camera sees there, so a static split leaves most workgroups
+// waiting for the few whose tiles were full (measured: +40 % on the kernels).
 template <int TYPE>
-__global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel(const DeviceState* __restrict__ S, const int bounce)
+NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, const int region, const int inRegion, const int per, const int firstTile, const int staticTiles,
+                         int* const sRing, int* const sHead, int* const sTicket)
 {
-    __shared__ int sRing[kScanRing];
-    __shared__ int sHead, sTicket;
     Counters* C = S->counters;
-    const int region = (int)(blockIdx.x & (kQueueShards - 1));
-    const int inRegion = C->region[region].traceSize[bounce - 1];  // rays of this region after trace(bounce - 1)
-    // Tiles: the region's workgroups take one each by their rank, the rest are handed out by ticket (one returning atomic per tile
-    // on the region's own word) — the share of a tile that is this kernel's to shade varies from none to all with what the camera
-    // sees there, so a static split leaves most workgroups waiting for the few whose tiles were full (measured: +40 % on the kernels).
-    // A launch with fewer tiles than workgroups (late bounces) does no atomic at all.
-    const int tiles = (inRegion + kScanTile - 1) / kScanTile;
-    const int rank = (int)(blockIdx.x >> 3), ranks = max(1, (int)(gridDim.x >> 3));
-    if (rank >= tiles) return;
+    const int tileRays = per * kShadeBlock;
+    const int tiles = (inRegion + tileRays - 1) / tileRays;
     int* const ticket = &C->region[region].scanTile[TYPE][bounce];
+    int t = firstTile;
+    if (t < 0 && tiles <= staticTiles) return;  // every tile has a workgroup of this type's own
+    __syncthreads();  // the previous type is done with the ticket word and the ring
+    if (threadIdx.x == 0) {
+        *sHead = 0;
+        if (t < 0) *sTicket = staticTiles + atomicAdd(ticket, 1);
+    }
+    __syncthreads();
+    if (t < 0) {
+        t = *sTicket;
+        if (t >= tiles) return;
+    }
     const uint32_t frame = S->frame->frameNumber;
     const int regionBase = region * (int)S->queueShardCap;
     const TraceRays in = S->trace.rays[(bounce - 1) & 1], out = S->trace.rays[bounce & 1];
@@ -980,8 +989,6 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
     slots.init(S, &C->region[0].traceShadowSize[bounce], -kMaxBounceSlots, 1 + TYPE, bounce, inRegion);
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
-    if (threadIdx.x == 0) sHead = 0;
-    __syncthreads();
     int tail = 0, head = 0;  // ring positions [tail, head) hold found slots not shaded yet (uniform)
 
     // shades `take` <= 256 slots from the ring's tail
@@ -1006,8 +1013,8 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
             if (bounce != 1) {
                 const float4 tp = in.tp[at];
                 const f3 throughput = mk3(tp.x, tp.y, tp.z);
-                const f3 t = throughput / maxcomp3(throughput);
-                tpdf = make_float4(t.x, t.y, t.z, tp.w);
+                const f3 tq = throughput / maxcomp3(throughput);
+                tpdf = make_float4(tq.x, tq.y, tq.z, tp.w);
             }
             // ... and the path's previous vertex, for hits that can need it (keep_previous_vertex)
             const uint32_t typeAndFlag = *(const NX_G uint32_t*)((const NX_G char*)&S->shadeInst[instanceIdx].material + kMaterialTypeOffset);
@@ -1048,10 +1055,10 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
         }
     };
 
-    for (int t = rank;;) {
+    for (;;) {
         // ---- find: which of this tile's rays does this kernel shade
-        {
-            const int r0 = t * kScanTile + 4 * (int)threadIdx.x;
+        if (per == 4) {
+            const int r0 = t * tileRays + 4 * (int)threadIdx.x;
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
             if (r0 + 3 < inRegion) w = *(const NX_G uint4*)(codes + r0);
             else {
@@ -1066,27 +1073,77 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
             const int total = n0 + n1 + n2 + n3;
             if (total) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&sHead, total);  // (an LDS atomic: the ring's head)
+                if (lane == 0) base = atomicAdd(sHead, total);  // (an LDS atomic: the ring's head)
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (m0) sRing[(base + __popcll(b0 & laneLt)) & (kScanRing - 1)] = r0;
                 if (m1) sRing[(base + n0 + __popcll(b1 & laneLt)) & (kScanRing - 1)] = r0 + 1;
                 if (m2) sRing[(base + n0 + n1 + __popcll(b2 & laneLt)) & (kScanRing - 1)] = r0 + 2;
                 if (m3) sRing[(base + n0 + n1 + n2 + __popcll(b3 & laneLt)) & (kScanRing - 1)] = r0 + 3;
             }
+        } else {
+            const int r0 = t * tileRays + (int)threadIdx.x;
+            const bool m0 = r0 < inRegion && (codes[r0] >> kHitCodeShift) == (uint32_t)(TYPE + 1);
+            const unsigned long long b0 = __ballot(m0);
+            if (b0) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(sHead, __popcll(b0));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (m0) sRing[(base + __popcll(b0 & laneLt)) & (kScanRing - 1)] = r0;
+            }
         }
         __syncthreads();
-        head = sHead;
+        head = *sHead;
         // the next tile: by ticket (issued here, needed only after this tile's batches)
-        if (threadIdx.x == 0) sTicket = tiles > ranks ? ranks + atomicAdd(ticket, 1) : tiles;
+        if (threadIdx.x == 0) *sTicket = tiles > staticTiles ? staticTiles + atomicAdd(ticket, 1) : tiles;
         // ---- shade: full batches; what is left over waits for the next tile's finds, or goes last
         while (head - tail >= kShadeBlock) shade_batch(kShadeBlock);
         __syncthreads();  // the ticket is there; and nobody appends to the ring before everybody has read its head
-        t = sTicket;
+        t = *sTicket;
         if (t >= tiles) break;
     }
     if (head - tail > 0) shade_batch(head - tail);
     // the items this workgroup shaded, for nxhip_read_queue_sizes (the reference's per-type queue sizes, D_QueueSize)
     if (threadIdx.x == 0 && head) atomicAdd(&C->region[region].materialSize[TYPE][bounce], head);
+}
+
+// All material types of a bounce in ONE launch (`typeMask`: bit NX_MAT_* = that type has a kernel in this pass).  The region's
+// workgroups start on different types (rank modulo the number of types) and move on to the next type when theirs has no tile
+// left, so the types run side by side, the launch ends when the last tile of the last type does, and a bounce costs one material
+// launch instead of one per type (the reference: four, PathTracer.cpp:116-120).  A single-bit mask is a per-type launch.
+__global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel(const DeviceState* __restrict__ S, const int bounce, const int typeMask)
+{
+    __shared__ int sRing[kScanRing];
+    __shared__ int sHead, sTicket;
+    const int region = (int)(blockIdx.x & (kQueueShards - 1));
+    const int inRegion = S->counters->region[region].traceSize[bounce - 1];  // rays of this region after trace(bounce - 1)
+    const int rank = (int)(blockIdx.x >> 3), ranks = max(1, (int)(gridDim.x >> 3));
+    const int nTypes = __popc((uint32_t)typeMask & 0xfu);
+    if (inRegion <= 0 || nTypes == 0) return;
+    // this workgroup's place among those that start on the same type, and how many of them there are
+    const int myStart = rank % nTypes, myIndex = rank / nTypes;
+    // four rays per thread while that still gives every starter a tile, else one (see shade_scan_type)
+    const int per = inRegion >= 4 * kShadeBlock * ((ranks + nTypes - 1) / nTypes) ? 4 : 1;
+    const int tiles = (inRegion + per * kShadeBlock - 1) / (per * kShadeBlock);
+    if (myIndex >= tiles) return;  // more workgroups than tiles (late bounces): the surplus leaves before any barrier or atomic
+    // the types in graph order of the reference (Diffuse, Plastic, Dielectric, Conductor: PathTracer.cpp:116-120), rotated so that
+    // this workgroup begins with its own
+    constexpr int kOrder[4] = {NX_MAT_DIFFUSE, NX_MAT_PLASTIC, NX_MAT_DIELECTRIC, NX_MAT_CONDUCTOR};
+    for (int step = 0; step < nTypes; step++) {
+        const int want = (myStart + step) % nTypes;  // index among the types present
+        int type = -1, seen = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((typeMask >> kOrder[k]) & 1) { if (seen == want) type = kOrder[k]; seen++; }
+        const int starters = (ranks - want + nTypes - 1) / nTypes;  // workgroups whose first type this is: each takes the tile of its index
+        const int first = step == 0 ? myIndex : -1;
+        switch (type) {
+        case NX_MAT_DIFFUSE: shade_scan_type<NX_MAT_DIFFUSE>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
+        case NX_MAT_PLASTIC: shade_scan_type<NX_MAT_PLASTIC>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
+        case NX_MAT_DIELECTRIC: shade_scan_type<NX_MAT_DIELECTRIC>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
+        case NX_MAT_CONDUCTOR: shade_scan_type<NX_MAT_CONDUCTOR>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
+        default: break;
+        }
+    }
 }
 
 // The reference's queue sizes count the hits of a material type whether or not a kernel shades them (its conductor kernel's body is
@@ -1403,15 +1460,7 @@ const void* shade_kernel_ptr(int type, bool ordered)
     default: return ordered ? (const void*)shade_kernel<NX_MAT_CONDUCTOR, true> : (const void*)shade_kernel<NX_MAT_CONDUCTOR, false>;
     }
 }
-const void* shade_scan_kernel_ptr(int type)
-{
-    switch (type) {
-    case NX_MAT_DIFFUSE: return (const void*)shade_scan_kernel<NX_MAT_DIFFUSE>;
-    case NX_MAT_DIELECTRIC: return (const void*)shade_scan_kernel<NX_MAT_DIELECTRIC>;
-    case NX_MAT_PLASTIC: return (const void*)shade_scan_kernel<NX_MAT_PLASTIC>;
-    default: return (const void*)shade_scan_kernel<NX_MAT_CONDUCTOR>;
-    }
-}
+const void* shade_scan_kernel_ptr() { return (const void*)shade_scan_kernel; }
 const void* miss_scan_kernel_ptr() { return (const void*)miss_scan_kernel; }
 const void* count_scan_kernel_ptr() { return (const void*)count_scan_kernel; }
 const void* tail_kernel_ptr() { return (const void*)tail_kernel; }

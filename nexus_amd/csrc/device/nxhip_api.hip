@@ -19,7 +19,7 @@ const void* trace_kernel_ptr(bool anyHit, bool stats);
 const void* tail_kernel_ptr();
 const void* logic_kernel_ptr(bool ordered, int items);
 const void* shade_kernel_ptr(int type, bool ordered);
-const void* shade_scan_kernel_ptr(int type);
+const void* shade_scan_kernel_ptr();
 const void* miss_scan_kernel_ptr();
 const void* count_scan_kernel_ptr();
 const void* inst_code_kernel_ptr();
@@ -481,6 +481,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
             }
+            if (const char* e = std::getenv("NX_SCAN_SEPARATE")) c->scanSeparate = std::atoi(e) != 0;  // measurement only: one material launch per type in the SCAN pipeline
             if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
             if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
             if (const char* e = std::getenv("NX_SHADE_PARALLEL")) c->parallelShade = std::atoi(e);    // tuning experiments only
@@ -1709,11 +1710,21 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
             }
             if (misses) levels.push_back({make_launch(miss_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce)});
             std::vector<Launch> shade;
-            if (in_use(NX_MAT_DIFFUSE)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIFFUSE), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
-            if (in_use(NX_MAT_PLASTIC)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_PLASTIC), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
-            if (in_use(NX_MAT_DIELECTRIC)) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIELECTRIC), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
-            if (in_use(NX_MAT_CONDUCTOR) && c->h.conductorMode == NX_CONDUCTOR_EXTENDED) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_CONDUCTOR), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));
-            if (shade.empty()) shade.push_back(make_launch(shade_scan_kernel_ptr(NX_MAT_DIFFUSE), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce));  // (a level cannot be empty)
+            // the material kernels of the types in use: ONE launch for all of them (shade_scan_kernel), or — NX_SCAN_SEPARATE, measurement
+            // only — one per type in the reference's graph order
+            int mask = (int)(c->materialTypeMask & 0xfu);
+            if (c->h.conductorMode != NX_CONDUCTOR_EXTENDED) mask &= ~(1 << NX_MAT_CONDUCTOR);
+            if (mask == 0) mask = 1 << NX_MAT_DIFFUSE;  // (a level cannot be empty)
+            auto scan_launch = [&](int m) {
+                Launch l = make_launch(shade_scan_kernel_ptr(), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce);
+                l.type = m;
+                l.nargs = 3;
+                return l;
+            };
+            if (c->scanSeparate) {
+                for (int type : {NX_MAT_DIFFUSE, NX_MAT_PLASTIC, NX_MAT_DIELECTRIC, NX_MAT_CONDUCTOR})
+                    if ((mask >> type) & 1) shade.push_back(scan_launch(1 << type));
+            } else shade.push_back(scan_launch(mask));
             if (in_use(NX_MAT_CONDUCTOR) && c->h.conductorMode != NX_CONDUCTOR_EXTENDED) {  // (counted, not shaded: count_scan_kernel)
                 Launch l = make_launch(count_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce);
                 l.type = NX_MAT_CONDUCTOR;
