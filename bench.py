@@ -88,7 +88,12 @@ COUNTERS_JSON = os.path.join(ROOT, "profiles", "trace_counters.json")
 
 def build_workload(args):
     t0 = time.time()
-    if args.config == 2:
+    if args.config == 1:
+        sc = workloads.config1(os.path.join(ROOT, "tests", "golden", "cornell_box.glb"), args.width, args.height, args.path_length)
+        name = ("configs[0]: the reference's cornell_box.glb (%d triangles in %d BLASes / instances, BVH8 %d nodes, read by the product's glTF reader), all materials DIFFUSE "
+                "with the file's base colours, light emissive (1,1,1) x 35, %dx%d, pathLength %d, MIS on, black background, frames 1..K"
+                % (sc.triangles, len(sc.instances), sc.bvh8_nodes, args.width, args.height, args.path_length))
+    elif args.config == 2:
         sc = workloads.config2(args.width, args.height, args.nu, args.nv, args.path_length)
         name = ("configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
                 % (sc.triangles, sc.bvh8_nodes, args.width, args.height, args.path_length))
@@ -104,7 +109,7 @@ def build_workload(args):
                 "intersection records: beyond the 256 MiB Infinity Cache), all four material types, textured emissive panels, %dx%d, pathLength %d"
                 % (sc.triangles, sc.unique_triangles, sc.bvh8_nodes, sc.scene_bytes() / 1e6, args.width, args.height, args.path_length))
     else:
-        raise SystemExit("--config must be 2, 4 or 5")
+        raise SystemExit("--config must be 1, 2, 4 or 5")
     return sc, name, time.time() - t0
 
 
@@ -149,6 +154,47 @@ def trace_algorithmic_bytes(st):
     """SURVEY.md section 8d, closest-hit kernel: 44 B per ray (24 in + 20 out), 80 B per node visited, 40 B per triangle
     tested (4 index + 36 positions), 104 B per instance entered."""
     return 44 * st["rays"] + 80 * st["nodes"] + 40 * st["tris"] + 104 * st["instances"]
+
+
+def cpu_bvh2_baseline(sc, width, height, threads, passes):
+    """configs[0]'s "CPU BVH2 intersect reference path" (SURVEY.md section 8c / 8d): the scene flattened to world-space triangles, the
+    reference's binned-SAH BVH2 over them (Geometry/BVH/BVH.h:45-65, BVH.cpp:65-210) and the ordered two-child descent of its
+    un-included Cuda/BVH/BVH2Traversal.cuh:7-52, as the oracle restates them, on the primary rays of the view: build time and
+    Mrays/s on all host threads of the box and on one."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests import oracle_lib as O  # test infrastructure, used here only as the reported CPU baseline
+
+    world = workloads.world_triangles(sc)
+    rays = workloads.pixel_centre_rays(sc.camera, width, height)
+    t0 = time.time()
+    b = O._Bvh2()
+    assert O.lib().orc_bvh2_build(O._ptr(world), len(world), C.byref(b)) == 0
+    t_build = time.time() - t0
+    hits = np.zeros(len(rays), dtype=pod.HIT_DT)
+
+    fn, bref, wptr = O.lib().orc_bvh2_trace_closest, C.byref(b), O._ptr(world)
+    ray_size, hit_size = rays.dtype.itemsize, hits.dtype.itemsize
+
+    def run(lo, hi):  # one thread's share of the rays, `passes` times over (ctypes releases the GIL during the call)
+        for _ in range(passes):
+            fn(bref, wptr, rays.ctypes.data + lo * ray_size, hi - lo, hits.ctypes.data + lo * hit_size)
+
+    def timed(nthreads):
+        cuts = np.linspace(0, len(rays), nthreads + 1).astype(int)
+        t0 = time.time()
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(lambda k: run(int(cuts[k]), int(cuts[k + 1])), range(nthreads)))
+        return time.time() - t0
+
+    dt_all, dt_one = timed(threads), timed(1)
+    nodes = int(b.nodeCount)
+    O.lib().orc_bvh2_free(C.byref(b))
+    return {"what": "BVH2 over the %d world-space triangles of the scene, closest hit of the %d pixel-centre primary rays, %d passes" % (len(world), len(rays), passes),
+            "build_ms": round(t_build * 1e3, 3), "nodes": nodes,
+            "Mrays_per_s": round(len(rays) * passes / dt_all / 1e6, 3), "cores": threads,
+            "single_core_Mrays_per_s": round(len(rays) * passes / dt_one / 1e6, 3), "hit_fraction": round(float((hits["hitDistance"] < 1e29).mean()), 4)}
 
 
 def cpu_baseline(sc, width, height, threads, frames, single_core=True):
@@ -217,7 +263,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="frames timed per repetition (default 512; --config 5: 64)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default 64; --config 5: 16)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-frame timed region; the median is reported")
-    ap.add_argument("--config", type=int, default=2, help="2 = BASELINE.json configs[1] (the metric's workload); 4 = configs[3] (instanced TLAS, dielectric, environment NEE / MIS); 5 = configs[4] on one GPU (HBM-resident scene)")
+    ap.add_argument("--config", type=int, default=2, help="1 = configs[0] (the reference's Cornell box, 512x512, pathLength 4, diffuse only; the CPU baseline adds the BVH2 path); 2 = BASELINE.json configs[1] (the metric's workload); 4 = configs[3] (instanced TLAS, dielectric, environment NEE / MIS); 5 = configs[4] on one GPU (HBM-resident scene)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--path-length", type=int, default=None)
@@ -257,9 +303,10 @@ def main():
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
     args = ap.parse_args()
     big = args.config == 5
-    args.width = args.width or (3840 if big else 1920)
-    args.height = args.height or (2160 if big else 1080)
-    args.path_length = args.path_length or (16 if big else 8)
+    cornell = args.config == 1
+    args.width = args.width or (3840 if big else 512 if cornell else 1920)
+    args.height = args.height or (2160 if big else 512 if cornell else 1080)
+    args.path_length = args.path_length or (16 if big else 4 if cornell else 8)
     args.steps = args.steps if args.steps is not None else (64 if big else 512)
     args.warmup = args.warmup if args.warmup is not None else (16 if big else 64)
 
@@ -320,7 +367,9 @@ def main():
     sc, workload_name, t_build = build_workload(args)
     stamp("scene built on the host (%.1f s)" % t_build)
     obj_check = None
-    if args.config == 2 and not args.no_obj_check:
+    if args.config == 2 and not args.no_obj_check and rank == 0:
+        # (rank 0 only: eight ranks writing and reading a 120 MB file at once is 8 x 3 s of host work and file I/O in front of the
+        #  first barrier for a check whose answer does not depend on the rank)
         obj_check = workloads.check_obj_round_trip(sc)
         stamp("mesh written as .obj, read back by OBJLoader and compared")
     if os.environ.get("NX_BENCH_NO_MIS"):  # experiment only: how much of the shade kernels is next-event estimation
@@ -357,7 +406,7 @@ def main():
     else:
         ctx = capi.Context(W, H, device=0)
     stamp("device context created")
-    args.device_bvh = not args.host_bvh
+    args.device_bvh = not args.host_bvh and not cornell  # (configs[0]: the host builders — the reference's algorithm, the bytes the oracle's builders produce)
     upload(ctx, sc, device_bvh=args.device_bvh, device_tlas=args.device_bvh and not args.host_tlas)
     stamp("scene uploaded")
 
@@ -570,6 +619,7 @@ def main():
             "frames_per_step": F, "frames_timed": n_frames, "samples_timed": int(W) * int(H) * n_frames,
             "timing": "median of %d repetitions of the %d-step = %d-frame region, each bracketed by barrier + device sync" % (args.reps, args.steps, n_frames),
             "rep_ms": [round(x * 1e3, 3) for x in rep_s],
+            "mean_rep_ms": round(statistics.mean(rep_s) * 1e3, 3), "value_from_the_mean": round(W * H * n_frames / statistics.mean(rep_s) / 1e6, 3),
             "pass_sizes": schedule(n_frames), "frames_rendered_by_the_timed_loop": frames_rendered[0],
             "host_scene_build_s": round(t_build, 2), "tlas_builder": "device (nxhip_rebuild_tlas)" if (args.device_bvh and not args.host_tlas) else "host: agglomerative clustering + SAH-DP collapse (the reference's algorithm)",
             "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
@@ -587,6 +637,53 @@ def main():
             "gather_bytes_per_rank_and_pass": int(n_local * 16), "backend": backend}
     if strong:
         out["config"]["strong_scaling"] = strong
+    if dist_mode and world > 1:
+        # both meanings of a step as top-level keys, so that one SCALE record shows the two curves: weak = one frame per GPU and step
+        # (K x N frames, every GPU keeps the 1-GPU run's work), strong = one frame per step in total, tile-split (the definition of
+        # rounds 1-3 and of north_star's "frames are tiled across the GPUs")
+        out["value_weak"] = out["value"] if args.scaling == "weak" else None
+        out["value_strong"] = strong["value"] if strong else (out["value"] if args.scaling == "strong" else None)
+        # ... and the same K steps on ONE GPU inside this job (rank 0 alone, full frame, the others wait at a barrier), so that
+        # the line carries its own denominator: efficiency = value_N / (N x value_1)
+        single = None
+        if rank == 0:
+            ctx.sync()
+            full_map = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W) if args.pixel_order == "tiles" else None
+            S1, _, _ = plan_schedule(args.steps, max(1, min(args.frames_per_pass or (16 if big else 64), 512)), 1, explicit_fpp, 1.0, W * H)
+            ctx.set_pixel_map(full_map)
+            ctx.set_frames_per_pass(S1)
+            ctx.set_passes_in_flight(1)
+            sizes1 = [S1] * (args.steps // S1) + ([args.steps % S1] if args.steps % S1 else [])
+
+            def run1(sizes):
+                for n in sizes:
+                    if ctx.frames_per_pass != n:
+                        ctx.set_frames_per_pass(n)
+                    ctx.render_frame()
+                    ctx.accumulate()
+                ctx.sync()
+
+            run1(sizes1[:1])
+            ctx.reset_frame_number()
+            run1([S1] * (args.warmup // S1) + ([args.warmup % S1] if args.warmup % S1 else []))
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                run1(sizes1)
+                ts.append(time.perf_counter() - t0)
+            med1 = statistics.median(ts)
+            v1 = W * H * args.steps / med1 / 1e6
+            single = {"what": "the same K steps rendered by rank 0 alone on its one GPU (full frame, one frame per step, median of 3 repetitions), inside this job",
+                      "value": round(v1, 3), "ms_per_step": round(med1 / args.steps * 1e3, 4), "rep_ms": [round(x * 1e3, 3) for x in ts]}
+            out["single_gpu_in_this_job"] = single
+            out["efficiency_weak"] = round(out["value_weak"] / (world * v1), 4) if out["value_weak"] else None
+            out["efficiency_strong"] = round(out["value_strong"] / (world * v1), 4) if out["value_strong"] else None
+            # back to rank 0's tiles for the roofline section
+            ctx.set_pixel_map(pm)
+            ctx.set_frames_per_pass(S)
+            if R > 1:
+                ctx.set_passes_in_flight(R)
+        dist.barrier()
     if reference_mode:
         out["config"]["reference_mode"] = reference_mode
     if emulated:
@@ -597,37 +694,70 @@ def main():
     # ---- roofline of the dominant kernel (closest-hit trace), on rank 0: at N > 1 these are rank 0's launches on ITS tiles (rays per
     # launch, durations, fractions per GPU); the section runs no collective, the other ranks wait at the closing barrier
     if rank == 0 and not args.no_roofline:
-        stamp("roofline: counting variant + in-graph kernel timing")
+        stamp("roofline: in-graph kernel timing over the frames of the timed repetitions + counting variant on the median one")
         if ctx.frames_per_pass != S:
             ctx.set_frames_per_pass(S)
-        passes = max(1, min(n_frames // S, 4))
-        frames = passes * S
-        # (a) units: the counting variant of the same kernel over `frames` frames
+        rep_sizes = schedule(n_frames)
+        warm_sizes = schedule(n_warm, S)
+
+        def run_passes(sizes):
+            # (no collective here: at N > 1 the other ranks wait at the closing barrier while rank 0 measures its own launches)
+            for n in sizes:
+                if ctx.frames_per_pass != n:
+                    ctx.set_frames_per_pass(n)
+                ctx.render_frame()
+                ctx.accumulate()
+
+        # (b) durations: hipEvent pair around every kernel of the production graph (event-record nodes inside the hipGraph, so the
+        # closest-hit and shadow traces of a bounce overlap exactly as in the timed region), over THE SAME FRAME NUMBERS as the
+        # timed repetitions: the image starts over, the warm-up frames are rendered again, then one series of replays per
+        # repetition; the events of a repetition's last replay are read after it.  Which frames a pass renders decides how long
+        # it takes (some frame ranges hold rays of thousands of traversal steps: DESIGN.md section 6), so the block below is
+        # computed from the repetition whose wall time was the MEDIAN of the timed region — the run `value` comes from.
+        order = sorted(range(len(rep_s)), key=lambda k: rep_s[k])
+        med_rep = order[len(order) // 2]
+        ctx.reset_frame_number()
+        run_passes(warm_sizes)
+        ctx.sync()
+        ctx.enable_kernel_timing(True, in_graph=True, last_replay_only=True)
+        ctx.read_kernel_times(reset=True)
+        run_passes(rep_sizes[:1])  # (builds the instrumented graph; its frames are rendered again below)
+        ctx.sync()
+        ctx.read_kernel_times(reset=True)
+        ctx.set_frame_number(n_warm)
+        timed = []
+        for k in range(len(rep_s)):
+            t0 = time.perf_counter()
+            run_passes(rep_sizes)
+            ctx.sync()
+            wall = time.perf_counter() - t0
+            tl = ctx.read_graph_timeline()
+            kt_k = ctx.read_kernel_times(reset=True)
+            span = max((s0 + d0) for _, s0, d0 in tl) if tl else 0.0
+            timed.append({"wall_ms": wall * 1e3, "kt": kt_k, "timeline": tl, "span_ms": span})
+        ctx.enable_kernel_timing(False)
+        kt = timed[med_rep]["kt"]
+        # (a) units: the counting variant of the same kernel over the frames of that repetition
+        ctx.set_frame_number(n_warm + med_rep * n_frames)
         ctx.enable_trace_stats(True)
         ctx.read_trace_stats(reset=True)
-        for _ in range(passes):
+        for n in rep_sizes:
+            if ctx.frames_per_pass != n:
+                ctx.set_frames_per_pass(n)
             ctx.render_frame()
         closest, shadow = ctx.read_trace_stats(reset=True)
         ctx.enable_trace_stats(False)
-        q = ctx.read_queue_sizes()
-        # (b) durations: hipEvent pair around every kernel of the production graph (event-record nodes inside the hipGraph, so
-        # the closest-hit and shadow traces of a bounce overlap exactly as in the timed region).  The replays run back to back
-        # like the timed region and the events of the LAST replay are read.  NB the closest-hit launch of a bounce shares the GPU
-        # with the shadow launch of the same bounce: its duration includes that time-sharing.
-        ctx.enable_kernel_timing(True, in_graph=True, last_replay_only=True)
-        ctx.read_kernel_times(reset=True)
-        for _ in range(max(passes, 3)):
-            ctx.render_frame()
-            ctx.accumulate()
-        kt = ctx.read_kernel_times(reset=True)
-        ctx.enable_kernel_timing(False)
+        q = ctx.read_queue_sizes()  # (of the repetition's last pass)
+        passes = len(rep_sizes)
+        frames = n_frames
+        last_pass_frames = rep_sizes[-1]
         launches = max(1, kt["trace"]["launches"])        # closest-hit launches of one replay (pathLength + 1)
         avg_ms = kt["trace"]["ms"] / launches
         dur_s = max(avg_ms * 1e-3, 1e-12)
         rays_per_launch = closest["rays"] / (launches * passes)                        # the counting run covered `passes` replays
         alg_bytes_per_launch = trace_algorithmic_bytes(closest) / (launches * passes)
         alg_gbs = alg_bytes_per_launch / dur_s / 1e9
-        frames_timed = {k: (S * max(passes, 3) if k == "accumulate" else S) for k in kt}  # accumulate is launched outside the graph
+        frames_timed = {k: (n_frames if k == "accumulate" else last_pass_frames) for k in kt}  # the instrumented replay is the repetition's last pass; accumulate is launched outside the graph, once per pass
         # Counter-side constants of this workload, per ray, from the committed rocprofv3 --pmc passes (profiles/README.md):
         # HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE), VALU wave-instructions and the clock under the profiler.  Per ray they
         # do not depend on the pass size (measured equal within 4 % at 1 and 20 frames per pass), so the driver's pass size
@@ -674,6 +804,18 @@ def main():
                             "frac_of_l2_peak": round(alg_gbs / L2_PEAK_GBS, 4), "l2_peak_GBs": L2_PEAK_GBS,
                             "caches": {k: ck[k] for k in ("l1_hit_rate", "l2_hit_rate") if k in ck} if ck else None},
             "avg_launch_ms": round(avg_ms, 5), "launches": launches, "rays_per_launch": int(rays_per_launch),
+            # where the durations come from: the timed repetitions' own frames, rendered again with event nodes around every kernel
+            "timing": {
+                "what": "event-record nodes around every kernel of the production graph; the image starts over, the warm-up frames are rendered again and every repetition of the "
+                        "timed region is replayed on its own frame numbers; `avg_launch_ms`, `kernel_ms_per_frame` and every fraction of this block come from the repetition "
+                        "whose wall time was the MEDIAN of the timed region (`repetition`, 0-based), i.e. from the frames `value` was measured on; a repetition of several passes: its last pass",
+                "repetition": med_rep,
+                "timed_region_rep_ms": [round(x * 1e3, 3) for x in rep_s],
+                "instrumented_rep_ms": [round(t["wall_ms"], 3) for t in timed],
+                "instrumented_replay_span_ms": [round(t["span_ms"], 3) for t in timed],
+                "closest_hit_launch_ms_by_repetition": [[round(d0, 4) for kk, _, d0 in t["timeline"] if kk == "trace"] for t in timed],
+                "critical_path_ms_per_frame": round(timed[med_rep]["span_ms"] / max(1, last_pass_frames), 4),
+            },
             "rays_per_frame": closest["rays"] // frames, "nodes_per_ray": round(closest["nodes"] / max(1, closest["rays"]), 2),
             "tris_per_ray": round(closest["tris"] / max(1, closest["rays"]), 2),
             "instances_per_ray": round(closest["instances"] / max(1, closest["rays"]), 2),
@@ -688,8 +830,8 @@ def main():
             "shadow": {"rays_per_frame": shadow["rays"] // frames, "avg_launch_ms": round(kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]), 5),
                        "algorithmic_GBs": round((trace_algorithmic_bytes(shadow) / max(1, kt["shadow"]["launches"] * passes)) / max(1e-12, kt["shadow"]["ms"] / max(1, kt["shadow"]["launches"]) * 1e-3) / 1e9, 2)},
             "kernel_ms_per_frame": {k: round(v["ms"] / frames_timed[k], 4) for k, v in kt.items()},
-            "items_per_frame": {"logic": int(sum(int(x) for x in q["traceSize"][: args.path_length]) // S),
-                                "shade": int(sum(int(sum(q[m][1: args.path_length + 1])) for m in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize")) // S)},
+            "items_per_frame": {"logic": int(sum(int(x) for x in q["traceSize"][: args.path_length]) // last_pass_frames) if kt["logic"]["launches"] else 0,
+                                "shade": int(sum(int(sum(q[m][1: args.path_length + 1])) for m in ("diffuseSize", "plasticSize", "dielectricSize", "conductorSize")) // last_pass_frames)},
             "live_rays_by_bounce": [int(x) for x in q["traceSize"][: args.path_length + 1]],
         }
 
@@ -733,8 +875,10 @@ def main():
         # a 1-GPU box's CPU share is 16 hardware threads
         stamp("cpu baseline (oracle on the host cores)")
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-        cb = cpu_baseline(sc, W, H, threads, 2 if big else 12, single_core=not big)  # about 10-15 s of CPU work on the box's 16 threads
+        cb = cpu_baseline(sc, W, H, threads, 2 if big else 100 if cornell else 12, single_core=not big)  # about 10-15 s of CPU work on the box's 16 threads
         cb["value"] = round(cb["value"], 4)
+        if cornell:
+            cb["bvh2_primary_rays"] = cpu_bvh2_baseline(sc, W, H, threads, 100)
         out["cpu_baseline"] = cb
 
     if rank == 0 and args.png:

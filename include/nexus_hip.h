@@ -34,7 +34,7 @@ enum {
 };
 
 /* Bumped whenever an entry point changes its signature or meaning, or a struct of this header / nexus_pod.h its layout. */
-#define NXHIP_API_VERSION 4
+#define NXHIP_API_VERSION 5
 
 /* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
 const char *nxhip_last_error(void);
@@ -330,6 +330,11 @@ typedef struct nxhip_kernel_times {
 } nxhip_kernel_times;
 int nxhip_enable_kernel_timing(nxhip_ctx *ctx, int enable);
 int nxhip_read_kernel_times(nxhip_ctx *ctx, nxhip_kernel_times *out, int reset);
+/* With enable = 2 or 3: the kernels of the LAST timed replay one by one, in graph order — class (NXHIP_K_*), start relative to
+ * the replay's first kernel and duration, both in ms — so that a caller can set the launches of one pass beside that pass's wall
+ * time (bench.py: the nine closest-hit launches of the repetition its roofline is computed from).  Up to `capacity` entries are
+ * written, *count receives the number of kernels in the graph.  Call it before nxhip_read_kernel_times(reset). */
+int nxhip_read_graph_timeline(nxhip_ctx *ctx, int32_t *klass, float *startMs, float *durationMs, uint32_t capacity, uint32_t *count);
 
 /* Build-time facts for tests: 1 if the library was compiled with device code for gfx950. */
 int nxhip_has_gfx950_code(void);

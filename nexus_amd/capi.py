@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
+    "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
@@ -72,7 +72,7 @@ class KernelTimes(C.Structure):
 
 KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate")
 
-API_VERSION = 4  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
+API_VERSION = 5  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
 
 
 def abi_words():
@@ -176,6 +176,7 @@ def lib():
     L.nxhip_read_trace_stats.argtypes = [vp, C.POINTER(TraceStats), C.POINTER(TraceStats), C.c_int]
     L.nxhip_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.nxhip_read_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.c_int]
+    L.nxhip_read_graph_timeline.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32)]
     L.nxhip_set_instance_transforms.argtypes = [vp, vp, vp, u32]
     L.nxhip_read_tlas.argtypes = [vp, vp, u32, vp, u32]
     L.nxhip_tile_pixel_map.argtypes = [u32, u32, C.c_int, C.c_int, u32, C.c_int, vp, C.POINTER(u32)]
@@ -799,6 +800,18 @@ class Context:
         replays, read_kernel_times returns the last replay of the series"""
         mode = 0 if not on else (3 if (in_graph and last_replay_only) else 2 if in_graph else 1)
         check(self.L.nxhip_enable_kernel_timing(self.h, mode), "nxhip_enable_kernel_timing")
+
+    def read_graph_timeline(self):
+        """the kernels of the last timed replay (enable_kernel_timing(in_graph=True)) in graph order:
+        [(class name, start ms since the replay's first kernel, duration ms), ...]"""
+        n = C.c_uint32(0)
+        check(self.L.nxhip_read_graph_timeline(self.h, None, None, None, 0, C.byref(n)), "nxhip_read_graph_timeline")
+        k = np.zeros(n.value, np.int32)
+        s = np.zeros(n.value, np.float32)
+        d = np.zeros(n.value, np.float32)
+        if n.value:
+            check(self.L.nxhip_read_graph_timeline(self.h, _ptr(k), _ptr(s), _ptr(d), n.value, C.byref(n)), "nxhip_read_graph_timeline")
+        return [(KERNEL_CLASSES[int(k[i])], float(s[i]), float(d[i])) for i in range(n.value)]
 
     def read_kernel_times(self, reset=False):
         t = KernelTimes()

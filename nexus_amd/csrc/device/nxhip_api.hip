@@ -2548,6 +2548,26 @@ int nxhip_enable_kernel_timing(nxhip_ctx* c, int enable)
     return NXHIP_OK;
 }
 
+int nxhip_read_graph_timeline(nxhip_ctx* c, int32_t* klass, float* startMs, float* durationMs, uint32_t capacity, uint32_t* count)
+{
+    NX_CHECK_CTX(c);
+    if (!count) return fail_invalid("nxhip_read_graph_timeline: null count");
+    if (capacity && (!klass || !startMs || !durationMs)) return fail_invalid("nxhip_read_graph_timeline: null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    *count = (uint32_t)c->graphTimers.size();
+    if (c->graphTimers.empty() || !c->lastRendered) return NXHIP_OK;
+    for (size_t i = 0; i < c->graphTimers.size() && i < capacity; i++) {
+        float s = 0.0f, d = 0.0f;
+        NX_HIP(hipEventElapsedTime(&s, c->graphTimers[0].start, c->graphTimers[i].start));
+        NX_HIP(hipEventElapsedTime(&d, c->graphTimers[i].start, c->graphTimers[i].stop));
+        klass[i] = c->graphTimerClass[i];
+        startMs[i] = s;
+        durationMs[i] = d;
+    }
+    return NXHIP_OK;
+}
+
 int nxhip_read_kernel_times(nxhip_ctx* c, nxhip_kernel_times* out, int reset)
 {
     NX_CHECK_CTX(c);

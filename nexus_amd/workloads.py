@@ -124,6 +124,52 @@ def _look(eye, target, hfov, width, height):
     return capi.camera_init(eye, fwd, hfov, width, height, 5.0, 0.0)
 
 
+def config1(glb_path, width=512, height=512, path_length=4, force_diffuse=True, use_mis=True, cls=Workload):
+    """BASELINE.json configs[0]: the reference's cornell_box.glb (8 primitives -> 8 BLAS / instances, node rotated +90 deg
+    about X), all materials DIFFUSE with the glb base colours, light emissive (1,1,1) x 35, camera at (0,1,3.9) looking
+    down -z with a 40 degree horizontal FOV, focus 5, no defocus (the file carries no camera; SURVEY.md section 8d fixes
+    these numbers), pathLength 4, MIS on, black background."""
+    from . import loaders
+
+    ls = loaders.load_glb(glb_path)
+    mats = ls.materials.copy()
+    if force_diffuse:
+        mats["type"] = pod.MAT_DIFFUSE
+    placements = [(inst["mesh"], inst["material"], capi.mat4_from_trs(inst["position"], inst["rotation"], inst["scale"])) for inst in ls.instances]
+    cam = capi.camera_init((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, width, height, 5.0, 0.0)
+    sc = cls(ls.meshes, placements, materials=mats, camera=cam,
+             settings=make_settings(use_mis=use_mis, path_length=path_length, background=(1, 1, 1), background_intensity=0.0))
+    sc.lights = mesh_lights(sc.instances, sc.materials)
+    return sc
+
+
+def world_triangles(sc):
+    """every instance's triangles in world space, concatenated: what a single-level BVH2 over the whole scene is built from
+    (configs[0]'s "CPU BVH2 intersect reference path")"""
+    out = []
+    for inst in sc.instances:
+        tris = sc.blas[int(inst["bvhIdx"])][1].copy()
+        M = inst["transform"].reshape(4, 4).astype(np.float64)
+        for k in ("pos0", "pos1", "pos2"):
+            tris[k] = (tris[k].astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+        out.append(tris)
+    return np.concatenate(out)
+
+
+def pixel_centre_rays(camera, width, height):
+    """the camera's rays through the pixel centres (no lens, no jitter), in row-major pixel order"""
+    jj, ii = np.mgrid[0:height, 0:width]
+    x = ((ii + 0.5) / width).reshape(-1, 1)
+    y = ((jj + 0.5) / height).reshape(-1, 1)
+    target = camera["lowerLeftCorner"].astype(np.float64) + camera["viewportX"].astype(np.float64) * x + camera["viewportY"].astype(np.float64) * y
+    d = target - camera["position"].astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(width * height, dtype=pod.RAY_DT)
+    rays["origin"] = camera["position"]
+    rays["direction"] = d.astype(np.float32)
+    return rays
+
+
 def config2(width=1920, height=1080, nu=1024, nv=512, path_length=8, cls=Workload):
     """configs[1]: seeded displaced torus (2*nu*nv triangles) resting on a 2-triangle floor under a 2-triangle emissive
     quad; mesh = CONDUCTOR (ior (0.2,0.9,1.1), k (3.9,2.4,2.2), roughness 0.3), floor = DIFFUSE 0.7, light intensity 20."""

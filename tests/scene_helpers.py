@@ -49,21 +49,7 @@ def cornell_scene(width=512, height=512, path_length=4, force_diffuse=True, use_
     """BASELINE.json configs[0]: the reference's cornell_box.glb (8 primitives -> 8 BLAS/instances, node rotated +90 deg
     about X), all materials DIFFUSE with the glb base colours, light emissive (1,1,1) x 35, camera at (0,1,3.9) looking
     down -z with a 40 degree horizontal FOV (the file carries no camera; SURVEY.md section 8d fixes these numbers)."""
-    from nexus_amd import loaders
-
-    ls = loaders.load_glb(os.path.join(GOLDEN, "cornell_box.glb"))
-    mats = ls.materials.copy()
-    if force_diffuse:
-        mats["type"] = pod.MAT_DIFFUSE
-    placements = []
-    for inst in ls.instances:
-        xf = capi.mat4_from_trs(inst["position"], inst["rotation"], inst["scale"])
-        placements.append((inst["mesh"], inst["material"], xf))
-    cam = capi.camera_init((0.0, 1.0, 3.9), (0.0, 0.0, -1.0), 40.0, width, height, 5.0, 0.0)
-    settings = O.make_settings(use_mis=use_mis, path_length=path_length, background=(1, 1, 1), background_intensity=0.0)
-    sc = BuiltScene(ls.meshes, placements, materials=mats, camera=cam, settings=settings)
-    sc.lights = mesh_lights(sc.instances, sc.materials)
-    return sc
+    return workloads.config1(os.path.join(GOLDEN, "cornell_box.glb"), width, height, path_length, force_diffuse, use_mis, cls=BuiltScene)
 
 
 def glb_scene(path, width, height, path_length=4, eye=(0.0, 1.0, 3.9), forward=(0.0, 0.0, -1.0), hfov=40.0, use_mis=True):

@@ -94,3 +94,91 @@ def test_bench_two_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
     assert abs(line["value"] - cfg["samples_timed"] / (line["ms_per_step"] * 5 * 1e-3) / 1e6) < 1e-2 * line["value"]
     # the strong-scaling region of the same command is timed as well, as a second figure
     assert cfg["strong_scaling"]["frames_timed"] == 5 and cfg["strong_scaling"]["value"] > 0
+
+
+def test_bench_partition_for_eight_ranks_covers_the_image_in_equal_shares():
+    """The 8-way split bench.py --gpus 8 would use (its own tile_pixel_map + the 8x8 path order), at the metric's 1080p, at
+    configs[4]'s 4K and at the 320 x 200 of the rehearsals: every rank the same number of pixels, every pixel exactly once,
+    whole 5-row tiles, and rank r's rows interleaved with the others'."""
+    import bench
+
+    for W, H in ((1920, 1080), (3840, 2160), (320, 200)):
+        seen = np.zeros(W * H, dtype=np.int32)
+        sizes = set()
+        for r in range(8):
+            pm = bench.tile_pixel_map(W, H, r, 8)
+            tiled = multigpu.tiled_order(pm, W)
+            assert np.array_equal(np.sort(tiled), np.sort(pm)), "the 8x8 path order is a permutation of the rank's pixels"
+            rows = np.unique(pm // W)
+            assert len(pm) == len(rows) * W, "whole rows"
+            t = multigpu.tile_rows_for(H, 8, (bench.TILE_ROWS, 8, 4, 6, 3, 2, 1))
+            assert np.all((rows // t) % 8 == r), "interleaved tiles: row // tileRows % 8 == rank"
+            seen[pm] += 1
+            sizes.add(len(pm))
+        assert len(sizes) == 1 and np.all(seen == 1)
+
+
+@pytest.mark.gpu
+def test_eight_way_split_rendered_rank_by_rank_reassembles_to_the_single_gpu_image(gpu_ctx_factory):
+    """The eight shares of bench.py's 8-way split (same maps, same 8x8 path order, the pass-size change of a step budget that is
+    not a multiple of the pass size), rendered one after the other on the box's one GPU and put together on the host: equal to
+    the full-frame render bit for bit.  (Eight PROCESSES on one GPU are beyond this pool's process guard — at most 6 may hold the
+    device — so the multi-process rehearsal below stops at 4 ranks; this one covers the 8-way partition itself.)"""
+    import bench
+
+    W, H, G = 320, 200, 8
+    scene = SH.cornell_scene(W, H, path_length=4)
+
+    def render(ctx, pm):
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+        ctx.set_pixel_map(pm)
+        ctx.reset_frame_number()
+        for n in (2, 2, 1):  # five frames in passes of 2, 2, 1
+            ctx.set_frames_per_pass(n)
+            ctx.render_frame()
+            ctx.accumulate()
+        return ctx.read_accumulation()
+
+    ctx = gpu_ctx_factory(W, H)
+    scene.upload(ctx)
+    ctx.set_frames_per_pass(2)
+    full_map = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)
+    want = np.zeros((W * H, 3), np.float32)
+    want[full_map] = render(ctx, full_map)[: W * H]
+    got = np.zeros_like(want)
+    for r in range(G):
+        pm = multigpu.tiled_order(bench.tile_pixel_map(W, H, r, G), W)
+        got[pm] = render(ctx, pm)[: len(pm)]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_gpu_render_the_single_rank_image(tmp_path):
+    """bench.py --gpus 4 as four child processes sharing the box's GPU over gloo (with the test process that is 5 of the 6 the
+    pool allows on one device): the weak run's PNG equals the 1-rank run with four times the steps, the strong run's that of the
+    same command; the line carries both values, the 1-GPU figure measured by rank 0 inside the job and the two efficiencies."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NX_BENCH_BACKEND="gloo", NX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    size = ["--reps", "1", "--frames-per-pass", "2", "--width", "320", "--height", "200", "--no-cpu-baseline", "--no-roofline", "--no-obj-check"]
+    k3, k12 = ["--steps", "3", "--warmup", "1"], ["--steps", "12", "--warmup", "4"]
+
+    def run(cmd_prefix, extra, png):
+        r = subprocess.run(cmd_prefix + [os.path.join(ROOT, "bench.py")] + extra + size + ["--png", png], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+
+    four = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", _free_port()]
+    one3, one12, strong, weak = (str(tmp_path / n) for n in ("one3.png", "one12.png", "strong.png", "weak.png"))
+    run([sys.executable], k3, one3)
+    run([sys.executable], k12, one12)
+    line = run(four, ["--gpus", "4"] + k3, weak)
+    assert open(one12, "rb").read() == open(weak, "rb").read()
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["config"]["frames_timed"] == 12
+    assert line["value_weak"] == line["value"] and line["value_strong"] == line["config"]["strong_scaling"]["value"] > 0
+    assert line["single_gpu_in_this_job"]["value"] > 0 and line["efficiency_weak"] > 0 and line["efficiency_strong"] > 0
+    assert len(line["config"]["per_rank"]["median_ms_by_rank"]) == 4
+    four[-1] = _free_port()
+    line = run(four, ["--gpus", "4", "--scaling", "strong"] + k3, strong)
+    assert open(one3, "rb").read() == open(strong, "rb").read()
+    assert line["value_weak"] is None and line["value_strong"] == line["value"]
