@@ -140,6 +140,9 @@ void orc_brute_any(const orc_scene *s, const nx_ray *rays, const float *tmax, ui
 /* "CPU BVH2 intersect reference path" of BASELINE.json configs[0]: ordered two-child descent over a
  * BVH2 of ONE mesh in object space (the reference's BVH2Traversal.cuh:7-52 is dead code that does
  * not compile; this follows its algorithm). */
+/* diagnostic logs of the closest-hit traversal (tools/lane_sim.py, tools/entry_point_probe.py): see orc_trace.c */
+void orc_trace_set_node_log(uint64_t *buf, uint64_t capWords);
+uint64_t orc_trace_node_log_length(void);
 void orc_bvh2_trace_closest(const orc_bvh2 *b, const nx_triangle *tris, const nx_ray *rays, uint32_t n, nx_hit *hits);
 
 /* Decode one node against one ray: returns the two stack entries of ChildTrace. */

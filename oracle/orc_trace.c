@@ -147,6 +147,18 @@ static __thread uint64_t g_stepLogCap = 0, g_stepLogLen = 0;
 void orc_trace_set_step_log(uint8_t *buf, uint64_t cap) { g_stepLog = buf; g_stepLogCap = cap; g_stepLogLen = 0; }
 uint64_t orc_trace_step_log_length(void) { return g_stepLogLen; }
 static inline void log_step(uint8_t kind) { if (g_stepLog && g_stepLogLen < g_stepLogCap) g_stepLog[g_stepLogLen++] = kind; }
+/* Optional second log, for tools/entry_point_probe.py: per NODE step of the closest-hit traversal three words — which node
+ * (instance + 1 in the high half, 0 = TLAS), and the two hit masks ChildTrace produced for this ray (inner children, leaf
+ * primitives) — and per ray a terminating triple of zeros.  Two rays whose triples agree up to some step have, up to there,
+ * visited the same nodes and hold the same traversal stack. */
+static __thread uint64_t *g_nodeLog = NULL;
+static __thread uint64_t g_nodeLogCap = 0, g_nodeLogLen = 0;
+void orc_trace_set_node_log(uint64_t *buf, uint64_t capWords) { g_nodeLog = buf; g_nodeLogCap = capWords; g_nodeLogLen = 0; }
+uint64_t orc_trace_node_log_length(void) { return g_nodeLogLen; }
+static inline void log_node(uint64_t id, uint32_t inner, uint32_t leaf)
+{
+    if (g_nodeLog && g_nodeLogLen + 3 <= g_nodeLogCap) { g_nodeLog[g_nodeLogLen++] = id; g_nodeLog[g_nodeLogLen++] = inner; g_nodeLog[g_nodeLogLen++] = leaf; }
+}
 
 static int clz32(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 static int popc32(uint32_t x) { return __builtin_popcount(x); }
@@ -184,11 +196,14 @@ static int trace_one(const orc_scene *s, f3 org, f3 dir, int anyHit, float tmaxI
             const int nodeSlot = (nodeOffset - 24) ^ (int)invOctant;
             const int relativeNodeIdx = popc32(nodeEntry.y & ~(0xffffffffu << nodeSlot));
             uint32_t ie[2], te[2];
-            child_trace(&nodes[nodeEntry.x + (uint32_t)relativeNodeIdx], &ray, invOctant4, hitDistance, ie, te);
+            const uint32_t nodeLogIndex = nodeEntry.x + (uint32_t)relativeNodeIdx;
+            child_trace(&nodes[nodeLogIndex], &ray, invOctant4, hitDistance, ie, te);
             nodeEntry.x = ie[0]; nodeEntry.y = ie[1];
             triangleEntry.x = te[0]; triangleEntry.y = te[1];
             nNodes++;
             log_step(1);
+            if (g_nodeLog && !anyHit)
+                log_node(((uint64_t)(instanceStackDepth == -1 ? 0u : instanceIdx + 1u) << 32) | (uint64_t)nodeLogIndex, ie[1], te[1]);
         } else {
             triangleEntry = nodeEntry;
             nodeEntry.x = 0; nodeEntry.y = 0;
@@ -245,6 +260,7 @@ static int trace_one(const orc_scene *s, f3 org, f3 dir, int anyHit, float tmaxI
         }
     }
     log_step(0);
+    if (g_nodeLog && !anyHit) log_node(0, 0, 0);
     if (hit) {
         hit->hitDistance = hitDistance;
         hit->u = hu; hit->v = hv;
