@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--no-reference-mode", action="store_true",
                     help="skip the second measurement: the same timed region with the REFERENCE's semantics — random numbers keyed by queue slot, slots handed out in "
                          "serial order (grid-wide ordered compaction), no conductor kernel — reported as config.reference_mode beside the headline")
+    ap.add_argument("--no-entry-points", action="store_true",
+                    help="start every primary ray at the TLAS root, as the reference does, instead of at the state the first node steps of its run of 64 paths provably "
+                         "share (nxhip_set_entry_points; hit records are the same bit for bit either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--png", type=str, default="", help="write the accumulated image here (rank 0)")
@@ -408,6 +411,8 @@ def main():
     stamp("device context created")
     args.device_bvh = not args.host_bvh and not cornell  # (configs[0]: the host builders — the reference's algorithm, the bytes the oracle's builders produce)
     upload(ctx, sc, device_bvh=args.device_bvh, device_tlas=args.device_bvh and not args.host_tlas)
+    if not args.no_entry_points:
+        ctx.set_entry_points(True)
     stamp("scene uploaded")
 
     if dist_mode:
@@ -613,7 +618,7 @@ def main():
         "config": {
             "workload": workload_name,
             "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved %d-row tiles, scene replicated, per-rank accumulation, one RCCL gather of accumulated tiles per pass" % (world, TILE_ROWS),
-            "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "launch": "one hipGraph replay per pass of up to %d frames" % S,
+            "rng": "pixel-keyed", "compaction": "workgroup-aggregated atomics", "entry_points": not args.no_entry_points, "launch": "one hipGraph replay per pass of up to %d frames" % S,
             "frames_per_pass": S, "passes_in_flight": R, "pixel_order": args.pixel_order, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "step": "one frame" if F == 1 else "%d frames (one per GPU), each tile-split over the %d GPUs" % (F, world),
             "frames_per_step": F, "frames_timed": n_frames, "samples_timed": int(W) * int(H) * n_frames,

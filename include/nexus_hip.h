@@ -173,6 +173,15 @@ int nxhip_set_passes_in_flight(nxhip_ctx *ctx, uint32_t passes);
  * variant is enabled (those passes use the level-by-level graph). */
 #define NXHIP_TAIL_AUTO 0xffffffffu
 int nxhip_set_tail_bounce(nxhip_ctx *ctx, uint32_t bounce);
+/* Entry points of the primary rays (off by default).  on != 0: every pass first walks, once per run of 64 consecutive paths, the
+ * node steps whose outcome is provably the same for every primary ray the run can contain (conservative bundle-against-box tests:
+ * nx_entry.hip), and the closest-hit launch of the primary rays starts each ray from that state instead of the TLAS root — the
+ * reference starts every ray at the root (Cuda/BVH/BVH8Traversal.cuh:165-192).  Hit records are unchanged bit for bit; the node
+ * visit counts of nxhip_read_trace_stats drop by the steps saved.  Takes effect for a pinhole camera (lens radius 0). */
+int nxhip_set_entry_points(nxhip_ctx *ctx, int on);
+/* The entry states of the last rendered pass, 80 bytes each (nx_device.h EntryState: six stack entries, node group, leaf group,
+ * then int32 sp, instSp, leafSlot, steps) — a test hook: how many node steps the walk saved per run.  *count = number of runs. */
+int nxhip_read_entry_states(nxhip_ctx *ctx, void *out, uint32_t capacityRuns, uint32_t *count);
 
 /* ---- rendering ----------------------------------------------------------------------------------- */
 

@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
-    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_set_entry_points", "nxhip_read_entry_states", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
 ]
@@ -671,6 +671,21 @@ class Context:
     def set_env_sampling(self, on=True):
         self.L.nxhip_set_env_sampling.argtypes = [C.c_void_p, C.c_int]
         check(self.L.nxhip_set_env_sampling(self.h, 1 if on else 0), "nxhip_set_env_sampling")
+
+    def set_entry_points(self, on=True):
+        """primary rays start from the state their run's first node steps provably share (include/nexus_hip.h)"""
+        self.L.nxhip_set_entry_points.argtypes = [C.c_void_p, C.c_int]
+        check(self.L.nxhip_set_entry_points(self.h, 1 if on else 0), "nxhip_set_entry_points")
+
+    def read_entry_states(self):
+        """(runs, 20) int32: the entry states of the last pass; column 19 = node steps saved, 16 = stack entries, 18 = instance record"""
+        self.L.nxhip_read_entry_states.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        n = C.c_uint32(0)
+        check(self.L.nxhip_read_entry_states(self.h, None, 0, C.byref(n)), "nxhip_read_entry_states")
+        out = np.zeros((n.value, 20), np.int32)
+        if n.value:
+            check(self.L.nxhip_read_entry_states(self.h, _ptr(out), n.value, C.byref(n)), "nxhip_read_entry_states")
+        return out
 
     TAIL_AUTO = 0xFFFFFFFF
 

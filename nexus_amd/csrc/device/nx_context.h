@@ -203,5 +203,8 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t materialTypeMask = 0xfu;
     // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
     bool classicPipeline = false;
+    bool entryPoints = false;   // nxhip_set_entry_points
+    nxd::DevBuf entryTable;     // [ceil(localCount / 64)] EntryState, allocated when entry points are on
+    uint32_t entryRuns = 0;
     bool scanSeparate = false;  // NX_SCAN_SEPARATE=1 (measurement only): one material launch per type instead of one for all
 };

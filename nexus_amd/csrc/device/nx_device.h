@@ -156,6 +156,28 @@ constexpr uint32_t kHitCodeMiss = 7u;
 // the trace kernels' `bounce` argument: bounce | kTraceScanFlag = the SCAN pipeline's launch (ray set by bounce parity, codes in
 // the hit records); without the flag: rays[0], plain hit records (classic pipeline, ray-batch hooks)
 constexpr int kTraceScanFlag = 0x100;
+// ... | kTraceEntryFlag: the primary launch of a pass whose rays carry the number of their ENTRY STATE in rayO.w (bits 2 and up,
+// 0 = none): the traversal of a run of 64 consecutive paths starts from the state their first node steps provably share (below)
+constexpr int kTraceEntryFlag = 0x200;
+constexpr int kRayEntryShift = 2;
+
+// Entry state of a run of 64 consecutive primary paths (nx_entry.hip).  The 64 rays of an 8 x 8 pixel tile visit the same nodes
+// with the same hit masks for their first ~4 of ~10 node steps (tools/entry_point_probe.py) — the same arithmetic done 64 times
+// for one answer.  entry_state_kernel walks those steps ONCE per run with a conservative test of the run's whole ray bundle
+// against every child box (hit by all rays of the bundle / missed by all / undecided: stop), and records the loop-top state the
+// traversal has reached — stack, node group, leaf group, instance — which the closest-hit kernel installs at refill instead of
+// starting at the root.  Every step it takes is one whose outcome is the same for every ray the bundle can contain, so each
+// ray's hit record is what the full traversal gives (bit for bit: tests/test_gpu_entry.py); only the visit counts drop.
+constexpr int kEntryMaxStack = 6;
+struct __attribute__((aligned(16))) EntryState {
+    uint2 stack[kEntryMaxStack];
+    uint2 ng, tg;
+    int32_t sp;        // stack entries in use
+    int32_t instSp;    // -1: in the TLAS
+    int32_t leafSlot;  // instance record (TLAS leaf order) the state is inside of, -1: none
+    int32_t steps;     // node steps taken (0: the state is the root's; the kernel then starts as usual)
+};
+static_assert(sizeof(EntryState) == 80, "EntryState layout");
 struct ShadowQueue {
     NX_G float4* rayO;
     NX_G float4* rayD;
@@ -297,6 +319,7 @@ struct DeviceState {
     NX_G FrameState* frame;
     NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
     NX_G unsigned long long* scanStatus;  // [tiles of the largest queue][kScanWords]: ordered compaction (nx_wavefront.hip OrderedScan)
+    NX_G EntryState* entry;          // [ceil(localCount / 64)]: entry states of the primary rays' runs, nullptr: off (nxhip_set_entry_points)
 };
 
 // What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
@@ -314,7 +337,7 @@ constexpr uint64_t layout_stamp()
     const uint64_t w[] = {
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
-        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(RegionCounters, scanTile), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),

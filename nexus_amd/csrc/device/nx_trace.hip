@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // record says what the path does next (see the flush below); without the flag: rays[0] and plain hit records
     const int bounce = bounceArg & 0xff;
     const bool scan = !ANY_HIT && (bounceArg & kTraceScanFlag) != 0;
+    // ... | kTraceEntryFlag: the rays name the entry state of their run (rayO.w): installed at refill instead of the root's
+    const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
+    const NX_G EntryState* const entryTable = S->entry;
     const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
     // the world-space ray (origin, direction, 1 / direction) of a lane that is inside a transformed instance: parked here on
@@ -236,6 +239,32 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     xformed = false;
                     nodes = tlasNodes;
                     if (STATS) nRays++;
+                    if (!ANY_HIT && entryLaunch) {
+                        // the state the first node steps of this ray's run provably lead to (nx_entry.hip), instead of the root's
+                        const uint32_t en = __float_as_uint(o.w) >> kRayEntryShift;
+                        if (en != 0u) {
+                            const NX_G EntryState* es = entryTable + (en - 1u);
+                            const int4 hdr = *(const NX_G int4*)&es->sp;  // sp, instSp, leafSlot, steps
+                            if (hdr.w > 0) {
+                                const uint4 g = *(const NX_G uint4*)&es->ng;
+                                ng = make_uint2(g.x, g.y);
+                                tg = make_uint2(g.z, g.w);
+#pragma unroll
+                                for (int k = 0; k < kEntryMaxStack; k += 2) {
+                                    const uint4 sk = *(const NX_G uint4*)&es->stack[k];
+                                    if (k < hdr.x) stack_push(stackLds, stackSpill, sp, make_uint2(sk.x, sk.y));
+                                    if (k + 1 < hdr.x) stack_push(stackLds, stackSpill, sp, make_uint2(sk.z, sk.w));
+                                }
+                                instSp = hdr.y;
+                                if (hdr.z >= 0) {  // inside an (identity) instance: its BLAS arrays and index
+                                    const NX_G InstTrav* rec = instTrav + hdr.z;
+                                    nodes = rec->nodes;
+                                    isect = rec->isect;
+                                    instIdx = rec->instIdx;
+                                }
+                            }
+                        }
+                    }
                 }
                 rngCur += min(__popcll(needMask), avail);
             }

@@ -437,7 +437,9 @@ __global__ void __launch_bounds__(kWideBlock) generate_kernel(const DeviceState*
         const uint32_t region = index / piece, slot = region * cap + (index - region * piece);
         // w: kRaySurvives — the bounce-1 logic step draws against a throughput of 1, and rng_next() < 1 always (PathTracer.cu:167-175
         // with the implicit throughput of :149)
-        S->trace.rays[0].rayO[slot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kRaySurvives));
+        // ... and, with entry points on, the number of the entry state of the path's run of 64 (nx_entry.hip)
+        const uint32_t entryBits = S->entry ? ((id.pixel >> 6) + 1u) << kRayEntryShift : 0u;
+        S->trace.rays[0].rayO[slot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kRaySurvives | entryBits));
         S->trace.rays[0].rayD[slot] = make_float4(direction.x, direction.y, direction.z, __uint_as_float(index));
     }
 }

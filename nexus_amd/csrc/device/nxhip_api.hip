@@ -23,6 +23,7 @@ const void* shade_scan_kernel_ptr();
 const void* miss_scan_kernel_ptr();
 const void* count_scan_kernel_ptr();
 const void* inst_code_kernel_ptr();
+const void* entry_state_kernel_ptr();
 const void* begin_frame_kernel_ptr();
 const void* hook_sizes_kernel_ptr();
 const void* generate_kernel_ptr();
@@ -33,6 +34,7 @@ uint64_t layout_stamp_wavefront();
 uint64_t layout_stamp_refit();
 uint64_t layout_stamp_lbvh();
 uint64_t layout_stamp_multigpu();
+uint64_t layout_stamp_entry();
 const void* bsdf_hook_kernel_ptr();
 const void* fmath_hook_kernel_ptr();
 const void* tex2d_hook_kernel_ptr();
@@ -114,7 +116,7 @@ static int check_layouts()
 {
     const struct { const char* unit; uint64_t stamp; } units[] = {
         {"nx_trace.hip", layout_stamp_trace()}, {"nx_wavefront.hip", layout_stamp_wavefront()}, {"nx_refit.hip", layout_stamp_refit()},
-        {"nx_lbvh.hip", layout_stamp_lbvh()}, {"nxhip_multigpu.hip", layout_stamp_multigpu()},
+        {"nx_lbvh.hip", layout_stamp_lbvh()}, {"nxhip_multigpu.hip", layout_stamp_multigpu()}, {"nx_entry.hip", layout_stamp_entry()},
     };
     for (const auto& u : units) {
         if (u.stamp != layout_stamp()) {
@@ -1549,6 +1551,7 @@ struct Launch {
     const DeviceState* s;
     int bounce;
     int type;  // nargs 3: (S, bounce, type)
+    void* ptr;  // nargs 30: (S, ptr, count)
     const float4* src;
     uint32_t count, slices, sliceStride, firstFrame;
     const uint32_t* dstMap;
@@ -1657,7 +1660,7 @@ int tail_bounce(const nxhip_ctx* c)
 // kernel is in the graph only for a scene with an environment map or a background that is not exactly black — PathTracer.cu:
 // 152-164 adds throughput x background, and +0 changes nothing), and the logic kernel's variant (one item per thread under an
 // environment map).  Part of a graph instance's key, so a change of any of them picks or builds the matching instance.
-constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4;
+constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4, kFlavorEntry = 8;
 int pass_flavor(const nxhip_ctx* c)
 {
     int f = 0;
@@ -1672,6 +1675,7 @@ int pass_flavor(const nxhip_ctx* c)
         black = black && bits == 0u;
     }
     if (c->hdrMap.texels.p || !black) f |= kFlavorMissKernel;
+    if (c->entryPoints && c->entryTable.p) f |= kFlavorEntry;
     return f;
 }
 
@@ -1686,8 +1690,16 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int wideThreads = kWideBlockThreads;
     std::vector<std::vector<Launch>> levels;
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
+    const bool entry = (pass_flavor(c) & kFlavorEntry) != 0;
+    if (entry) {  // beside the generate kernel: the entry states of the primary rays' runs (nx_entry.hip), read by the launch below
+        Launch l = make_launch(entry_state_kernel_ptr(), (int)((c->entryRuns + 63u) / 64u), 64, NXHIP_K_GENERATE, S);
+        l.ptr = c->entryTable.p;
+        l.count = c->entryRuns;
+        l.nargs = 30;
+        levels.back().push_back(l);
+    }
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
-    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, 0)});
+    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, entry ? kTraceEntryFlag : 0)});
     const int pathLength = c->h.settings.pathLength;
     // (grids of the producer kernels stay multiples of the queue regions: harmless, and what a round-robin tile-to-region mapping
     //  would need)
@@ -1701,7 +1713,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         // SCAN pipeline (nx_wavefront.hip): the closest-hit launch leaves the logic step's decision in its hit records, the material
         // kernels find their items there.  Per bounce: [miss kernel, only when a miss can contribute] -> the material kernels of the
         // types in use, one after the other -> trace || shadow trace.  One launch less per bounce than the reference's DAG.
-        levels[1][0].bounce = 0 | kTraceScanFlag;
+        levels[1][0].bounce |= kTraceScanFlag;
         const bool misses = pass_flavor(c) & kFlavorMissKernel;
         for (int bounce = 1; bounce <= pathLength; bounce++) {
             if (bounce == tailFrom) {  // the rest of the pass in one launch
@@ -1766,6 +1778,7 @@ void fill_args(Launch& l, void** args)
     args[0] = (void*)&l.s;
     if (l.nargs == 2 || l.nargs == 3) args[1] = (void*)&l.bounce;
     if (l.nargs == 3) args[2] = (void*)&l.type;
+    if (l.nargs == 30) { args[1] = (void*)&l.ptr; args[2] = (void*)&l.count; }
     if (l.nargs == 7) {
         args[1] = (void*)&l.src; args[2] = (void*)&l.count; args[3] = (void*)&l.slices; args[4] = (void*)&l.sliceStride;
         args[5] = (void*)&l.firstFrame; args[6] = (void*)&l.dstMap;
@@ -1891,6 +1904,17 @@ try {
     if (c->shadeInstDirty) {
         rc = refresh_shade_inst(c);
         if (rc != NXHIP_OK) return rc;
+    }
+    if (c->entryPoints) {  // the entry-state table follows the pixel set (one state per run of 64 local pixels)
+        const uint32_t runs = (c->localCount + 63u) / 64u;
+        if (c->entryRuns != runs || !c->entryTable.p) {
+            NX_SYNC_ALL(c);
+            NX_ALLOC(c->entryTable, (size_t)std::max(1u, runs) * sizeof(EntryState));
+            NX_HIP(hipMemset(c->entryTable.p, 0, (size_t)std::max(1u, runs) * sizeof(EntryState)));  // (steps 0: "start at the root")
+            c->entryRuns = runs;
+            c->h.entry = c->entryTable.as<EntryState>();
+            c->stateDirty = true;
+        }
     }
     rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
@@ -2026,6 +2050,33 @@ int nxhip_set_tail_bounce(nxhip_ctx* c, uint32_t bounce)
     if (bounce != NXHIP_TAIL_AUTO && (bounce == 1u || bounce > (uint32_t)NX_PATH_MAX_LENGTH))
         return fail_invalid("nxhip_set_tail_bounce: bounce must be 0 (off), NXHIP_TAIL_AUTO or in [2, NX_PATH_MAX_LENGTH]");
     c->tailBounce = bounce == NXHIP_TAIL_AUTO ? -1 : (int)bounce;  // the graphs notice at their next use (render_frame compares tail_bounce())
+    return NXHIP_OK;
+}
+
+int nxhip_set_entry_points(nxhip_ctx* c, int on)
+{
+    NX_CHECK_CTX(c);
+    if ((on != 0) == c->entryPoints) return NXHIP_OK;
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    c->entryPoints = on != 0;
+    if (!c->entryPoints) {
+        c->entryTable.release();
+        c->entryRuns = 0;
+        c->h.entry = nullptr;
+    }
+    c->stateDirty = true;  // (nxhip_render_frame allocates the table for the current pixel set and publishes it)
+    return NXHIP_OK;
+}
+
+int nxhip_read_entry_states(nxhip_ctx* c, void* out, uint32_t capacityRuns, uint32_t* count)
+{
+    NX_CHECK_CTX(c);
+    if (!count) return fail_invalid("nxhip_read_entry_states: null count");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    *count = c->entryTable.p ? c->entryRuns : 0u;
+    if (out && c->entryTable.p) NX_HIP(hipMemcpy(out, c->entryTable.p, (size_t)std::min(capacityRuns, c->entryRuns) * sizeof(EntryState), hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
 
