@@ -331,8 +331,9 @@ int nxhip_read_trace_stats(nxhip_ctx *ctx, nxhip_trace_stats *closest, nxhip_tra
  * frame graph is rebuilt with an event-record node before and after every kernel node, so each kernel is timed under the
  * conditions of the production replay (closest-hit and shadow traces of a bounce run concurrently); the events are read
  * after every replay.  enable = 3: the same graph, but replays are NOT separated by a sync: nxhip_read_kernel_times then
- * returns the kernels of the LAST replay only, timed under the sustained clocks of a back-to-back series.  0: off.  Classes: 0 generate, 1 trace, 2 shadow, 3 logic, 4 shade, 5 accumulate. */
-enum { NXHIP_K_GENERATE = 0, NXHIP_K_TRACE = 1, NXHIP_K_SHADOW = 2, NXHIP_K_LOGIC = 3, NXHIP_K_SHADE = 4, NXHIP_K_ACCUMULATE = 5, NXHIP_K_COUNT = 6 };
+ * returns the kernels of the LAST replay only, timed under the sustained clocks of a back-to-back series.  0: off.  Classes: 0 generate, 1 trace, 2 shadow, 3 logic, 4 shade, 5 accumulate,
+ * 6 thin (the launch behind the two trace launches of a level that finishes the last long rays of their dry waves: nx_trace.hip thin_kernel). */
+enum { NXHIP_K_GENERATE = 0, NXHIP_K_TRACE = 1, NXHIP_K_SHADOW = 2, NXHIP_K_LOGIC = 3, NXHIP_K_SHADE = 4, NXHIP_K_ACCUMULATE = 5, NXHIP_K_THIN = 6, NXHIP_K_COUNT = 7 };
 typedef struct nxhip_kernel_times {
     double ms[NXHIP_K_COUNT];
     uint64_t launches[NXHIP_K_COUNT];

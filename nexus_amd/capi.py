@@ -67,10 +67,10 @@ class TraceStats(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_uint64 * 6)]
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_uint64 * 7)]
 
 
-KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate")
+KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate", "thin")
 
 API_VERSION = 5  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
 

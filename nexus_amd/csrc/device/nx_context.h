@@ -94,6 +94,7 @@ struct PassSlot {
     DevBuf mqHit[4], mqDirInst[4], mqTp[4];
     DevBuf counters, frame, dState;
     DevBuf scanStatus;        // ordered compaction: tile status words (allocated with the queues)
+    DevBuf thinLists;         // 2 x kThinListEntries queue slots: the rays the trace launches of a level hand to the thin kernel (allocated with the queues)
     uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
     size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
     // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in
@@ -203,6 +204,7 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t materialTypeMask = 0xfu;
     // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
     bool classicPipeline = false;
+    bool thinWaves = true;  // the trace launches of a pass finish the last long rays of a dry wave cooperatively (NX_NO_THIN=1 with NX_TUNING_KNOBS=1: off)
     bool entryPoints = false;   // nxhip_set_entry_points
     nxd::DevBuf entryTable;     // [ceil(localCount / 64)] EntryState, allocated when entry points are on
     uint32_t entryRuns = 0;

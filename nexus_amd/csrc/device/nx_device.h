@@ -160,6 +160,8 @@ constexpr int kTraceScanFlag = 0x100;
 // 0 = none): the traversal of a run of 64 consecutive paths starts from the state their first node steps provably share (below)
 constexpr int kTraceEntryFlag = 0x200;
 constexpr int kRayEntryShift = 2;
+// ... | kTraceThinFlag: the launch may finish the last long rays of a dry wave cooperatively (nx_trace.hip thin_wave_bound)
+constexpr int kTraceThinFlag = 0x400;
 
 // Entry state of a run of 64 consecutive primary paths (nx_entry.hip).  The 64 rays of an 8 x 8 pixel tile visit the same nodes
 // with the same hit masks for their first ~4 of ~10 node steps (tools/entry_point_probe.py) — the same arithmetic done 64 times
@@ -230,6 +232,7 @@ struct Counters {
     // ordered compaction (nx_wavefront.hip OrderedScan): tiles of a logic / material launch handed out so far, one word per
     // launch of a pass — kernel kind (0 logic, 1 + NX_MAT_* material) x bounce
     int32_t scanTicket[kScanKinds][kMaxBounceSlots];
+    int32_t thinCount[2][kMaxBounceSlots];  // rays handed to the thin kernel by the closest-hit [0] / any-hit [1] launch of a bounce (may exceed thinCapacity: the lists hold min(count, capacity))
 };
 
 struct FrameState {
@@ -320,6 +323,10 @@ struct DeviceState {
     NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
     NX_G unsigned long long* scanStatus;  // [tiles of the largest queue][kScanWords]: ordered compaction (nx_wavefront.hip OrderedScan)
     NX_G EntryState* entry;          // [ceil(localCount / 64)]: entry states of the primary rays' runs, nullptr: off (nxhip_set_entry_points)
+    // the last long rays of dry trace waves, handed to thin_kernel (nx_trace.hip): queue slots (closest hit: | roulette bit 31)
+    NX_G uint32_t* thinClosest;
+    NX_G uint32_t* thinAny;
+    uint32_t thinCapacity;           // entries per list
 };
 
 // What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
@@ -337,7 +344,7 @@ constexpr uint64_t layout_stamp()
     const uint64_t w[] = {
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
-        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), offsetof(DeviceState, thinClosest), offsetof(DeviceState, thinCapacity), offsetof(Counters, thinCount), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(RegionCounters, scanTile), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),

@@ -149,20 +149,18 @@ NXD bool bundle_child_trace(const Bundle& b, const NX_G uint4* node, const uint3
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __restrict__ S, EntryState* out, const uint32_t runs)
+// the state of run `run`: the root's when a condition is not met
+NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
 {
-    const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
-    if (run >= runs) return;
     EntryState st;
     for (int k = 0; k < kEntryMaxStack; k++) st.stack[k] = make_uint2(0u, 0u);
     st.ng = make_uint2(0u, 0x80000000u);
     st.tg = make_uint2(0u, 0u);
     st.sp = 0; st.instSp = -1; st.leafSlot = -1; st.steps = 0;
-    NX_G EntryState* dst = (NX_G EntryState*)out + run;
-    *dst = st;  // (the root's state: what a run that meets none of the conditions below keeps)
+    const EntryState root = st;
 
     const nx_camera cam = S->camera;
-    if (cam.lensRadius != 0.0f) return;
+    if (cam.lensRadius != 0.0f) return root;
     // the run's pixels: their bounding rectangle, in pixels
     const uint32_t resX = cam.resolution[0], resY = cam.resolution[1];
     uint32_t imin = 0xffffffffu, imax = 0u, jmin = 0xffffffffu, jmax = 0u;
@@ -173,14 +171,14 @@ __global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __re
         const uint32_t j = g / resX, i = g - j * resX;
         imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j);
     }
-    if (imin > imax) return;
+    if (imin > imax) return root;
     Bundle b;
     b.org = D3{(double)cam.position[0], (double)cam.position[1], (double)cam.position[2]};
     {
         // NaN, +-inf, -0, +-denormal.  (+0 is fine: such a ray is not "ordinary" for nx_traverse.h's enter_instance, which then takes it
         // through the identity's rows — 1 * x + 0 * y + 0 * z + 0 — and that returns x bit for bit unless x is a NEGATIVE zero)
         constexpr int kSpecial = 0x003 | 0x004 | 0x200 | 0x020 | 0x010 | 0x080;
-        if (__builtin_amdgcn_classf(cam.position[0], kSpecial) || __builtin_amdgcn_classf(cam.position[1], kSpecial) || __builtin_amdgcn_classf(cam.position[2], kSpecial)) return;
+        if (__builtin_amdgcn_classf(cam.position[0], kSpecial) || __builtin_amdgcn_classf(cam.position[1], kSpecial) || __builtin_amdgcn_classf(cam.position[2], kSpecial)) return root;
     }
     const double eps = 0.01;  // of a pixel: the generate kernel's float x, y and direction are within 1e-4 of a pixel of the exact ones
     const double xs[4] = {((double)imin - eps) / resX, ((double)imax + 1.0 + eps) / resX, ((double)imax + 1.0 + eps) / resX, ((double)imin - eps) / resX};
@@ -202,7 +200,7 @@ __global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __re
             if (c < -1.0e-6 * len) neg++;
             else if (c > 1.0e-6 * len) pos++;
         }
-        if (neg != 4 && pos != 4) return;
+        if (neg != 4 && pos != 4) return root;
         if (neg == 4) oct |= (a == 0 ? 4u : (a == 1 ? 2u : 1u));
     }
     const uint32_t invOct4 = (7u - oct) * 0x01010101u;
@@ -251,7 +249,17 @@ __global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __re
         }
         st = next;
     }
-    *dst = st;
+    return st;
+}
+
+// One thread per run.  The state is computed in registers and stored ONCE: with passes in flight the kernel runs in every pass's
+// graph and rewrites the table while another pass's closest-hit launch reads it — with the same bytes (camera, scene and pixel
+// map are the same for all passes in flight: a change of any of them waits for them), so a reader can never see a mixture.
+__global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __restrict__ S, EntryState* out, const uint32_t runs)
+{
+    const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+    if (run >= runs) return;
+    ((NX_G EntryState*)out)[run] = walk_run(S, run);
 }
 
 const void* entry_state_kernel_ptr() { return (const void*)entry_state_kernel; }

@@ -44,6 +44,196 @@ constexpr int kReserve = NX_RESERVE;  // most rays reserved per fetch atomic (me
 static_assert((kRaySurvives << 30) == 0x80000000u, "the roulette bit of rayO.w moves to bit 31 of the lane's ray index");
 constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
+// ------------------------------------------------------------------------------------------------------
+// The last long rays of a dry wave, all 64 lanes on ONE ray.
+//
+// A launch ends with its slowest ray, and a ray that skims the displaced surface visits thousands of records at one record per
+// ~microsecond: every level of a pass has a floor of a few hundred microseconds of one-to-four-lane waves, and some frame ranges
+// hold a ray that adds two milliseconds to its level (dropping such rays — wrong results — makes every
+// repetition of the driver's command 18.4 ms instead of 19.1 ... 21.3).  Splitting a ray INSIDE the loop was tried in round 3 and
+// cost the loop 11 % by its live values; the search below as a part of this kernel cost it 15 % out of line and 160 % inlined
+// (round 5: its registers around the refill point, not its execution).  So the trace kernels only HAND OVER: when the queue is
+// dry, at most kThinLanes lanes of a wave are still busy and they have been for kThinIters iterations, the wave appends those rays
+// to a list and ends.  thin_kernel — one launch per level, behind the closest-hit and any-hit launches — puts a whole wave on each
+// listed ray: all 64 lanes search the ray's tree TOGETHER, in any order: a pool of work items (node, instance entry, triangle) in
+// LDS; every round each lane takes one item, tests it against the ray with the loop's own functions and puts the children the ray
+// enters back; the smallest triangle distance found so far prunes, as the ray's own hit distance would.
+//   * Any-hit ray: occluded is occluded whatever the order.
+//   * Closest-hit ray: the reference's result (BVH8Traversal.cuh:148-322) is what ITS visiting order finds, and that depends on
+//     the order in exactly one situation: two triangles whose distances differ by less than the rounding of the slab test (the
+//     traversal may or may not prune the box of the slightly closer one, depending on which it met first; at equal distances the
+//     first met wins).  So the search keeps the two smallest distances it sees, accepting and pruning with a WINDOW above the
+//     smallest (1e-3 of distance + coordinate magnitude: thousands of times the slab test's rounding).  A closest triangle with
+//     nothing else inside its window is what every visiting order returns — no box on its path can have been pruned by a hit that
+//     far behind it — with the t, u, v the ordinary loop computes (same frame, same arithmetic): that is the ray's record.
+//     Anything else inside the window: the ray is traversed again from the root in the reference's own order (traverse_wave).
+//   * A pool that would overflow ends the search; the ray is traversed in order likewise.
+// Launches of the pass graph only (kTraceThinFlag), never the counting variant or the ray-batch hooks.
+#ifndef NX_THIN_LANES
+#define NX_THIN_LANES 4
+#endif
+#ifndef NX_THIN_ITERS
+#define NX_THIN_ITERS 64
+#endif
+constexpr int kThinLanes = NX_THIN_LANES, kThinIters = NX_THIN_ITERS;
+#ifdef NX_NO_THIN_CODE
+constexpr bool kThinCode = false;  // (measurement: the kernel without the search's text)
+#else
+constexpr bool kThinCode = true;
+#endif
+constexpr int kPoolSlots = 1024;  // work items per wave of the thin kernel (8 KiB of LDS)
+constexpr uint32_t kItemNode = 0u, kItemInst = 1u, kItemTri = 2u;  // item.y = kind << 30 | frame (instance record + 1, 0 = TLAS); item.x = index
+
+struct ThinResult {
+    float t, u, v;
+    uint32_t tri, inst;
+    int count;        // closest hit: 1 = a closest triangle was found (t, u, v, tri, inst), 0 = none; any hit: 1 = occluded
+    float second;     // closest hit: the second smallest distance seen (3e38: none)
+    float window;     // ... and how far above t a second one makes the result depend on the visiting order
+    bool complete;    // the whole tree was searched
+};
+
+// Searches ray (o, d) with the whole wave.  `bound`: closest hit — the ray's current hit distance (triangles at t <= bound count);
+// any hit — its tmax (a triangle at 0 < t < bound occludes).  `pool`: kPoolSlots LDS entries of the wave's own.
+// Everything in the result is wave-uniform.
+template <bool ANY_HIT>
+NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* const pool, const f3 o, const f3 d, const float bound, const bool sceneIdentity)
+{
+    GU4 tlasNodes = S->tlasNodes;
+    const NX_G InstTrav* instTrav = S->instTrav;
+    const int lane = threadIdx.x & (kWave - 1);
+    const f3 idirW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const uint32_t oct = ((d.x < 0.0f ? 1u : 0u) << 2) | ((d.y < 0.0f ? 1u : 0u) << 1) | (d.z < 0.0f ? 1u : 0u);
+    const uint32_t invOct4 = (7u - oct) * 0x01010101u;
+    ThinResult r;
+    r.t = bound; r.u = 0.0f; r.v = 0.0f; r.tri = 0xffffffffu; r.inst = 0xffffffffu; r.count = 0; r.second = 3.0e38f; r.complete = true;
+    const float magnitude = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    r.window = ANY_HIT ? 0.0f : 1.0e-3f * (fminf(bound, 1.0e30f) + magnitude);
+    int n = 1;  // items in the pool (uniform)
+    if (lane == 0) pool[0] = (unsigned long long)kItemNode << 62;  // the TLAS root
+    uint32_t rounds = 0u;
+    while (n > 0) {
+        if (++rounds > (1u << 16)) { r.complete = false; break; }  // (a tree that is not a tree: the ordinary loop's stall guard deals with it)
+        const int take = min(n, kWave);
+        const bool have = lane < take;
+        const int at = n - 1 - lane;
+        const unsigned long long item = have ? pool[at] : 0ull;
+        n -= take;
+        const uint32_t idx = (uint32_t)item, tag = (uint32_t)(item >> 32);
+        const uint32_t kind = tag >> 30;
+        uint32_t frame = tag & 0x3fffffffu;  // instance record + 1 whose frame the item lives in
+        if (have && kind == kItemInst) frame = idx + 1u;
+        // the ray in the item's frame (BVH8Traversal.cuh:259-264, as enter_instance computes it)
+        f3 ro = o, rd = d, ri = idirW;
+        GU4 nodes = tlasNodes;
+        GF4 isect = nullptr;
+        uint32_t instIdx = 0u;
+        if (have && frame != 0u) {
+            const unsigned long long recAddr = (unsigned long long)&instTrav[frame - 1u];
+            InstFetch fi;
+            fetch_instance(recAddr, sceneIdentity, fi);
+            nodes = fi.nodes();
+            isect = fi.isect();
+            instIdx = fi.instIdx;
+            f3 o2, d2;
+            if (enter_instance(fi, sceneIdentity, o, d, o2, d2)) {
+                ro = o2;
+                rd = d2;
+                ri = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            }
+        }
+        unsigned long long recAddr = 0ull;
+        if (have) {
+            if (kind == kItemNode) recAddr = (unsigned long long)(nodes + (size_t)idx * (unsigned)kNodeStride);
+            else if (kind == kItemInst) recAddr = (unsigned long long)&instTrav[idx] + 80ull;  // the copy of the BLAS's root node
+            else recAddr = (unsigned long long)(isect + (size_t)idx * (unsigned)kTriStride);
+        }
+        const bool isNode = have && kind != kItemTri, isTri = have && kind == kItemTri;
+        uint4 rc[5];
+        fetch_record(isNode, isTri, recAddr, rc);
+        uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+        float ct = 3.0e38f, cu = 0.0f, cv = 0.0f;  // this lane's candidate of the round
+        bool cand = false;
+        if (isNode) child_trace(rc, ro, rd, ri, invOct4, r.t + r.window, ng, tg);
+        if (isTri) {
+            const f3 p0 = mk3(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z));
+            const f3 edge0 = mk3(__uint_as_float(rc[1].x), __uint_as_float(rc[1].y), __uint_as_float(rc[1].z));
+            const f3 edge1 = mk3(__uint_as_float(rc[2].x), __uint_as_float(rc[2].y), __uint_as_float(rc[2].z));
+            const f3 rayCrossEdge1 = cross3(rd, edge1);
+            const float det = dot3(edge0, rayCrossEdge1);
+            const float invDet = 1.0f / det;
+            const f3 sv = ro - p0;
+            const float u = invDet * dot3(sv, rayCrossEdge1);
+            const f3 sCrossEdge0 = cross3(sv, edge0);
+            const float v = invDet * dot3(rd, sCrossEdge0);
+            const float t = invDet * dot3(edge1, sCrossEdge0);
+            // (closest hit: "at or below" the distance found so far, so that a second triangle at the same distance is noticed)
+            cand = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && t > 0.0f && (ANY_HIT ? t < r.t : t <= r.t + r.window);
+            if (cand) { ct = t; cu = u; cv = v; }
+        }
+        // the children the ray enters go back into the pool
+        const bool inTlas = isNode && kind == kItemNode && frame == 0u;
+        int mine = isNode ? __popc(ng.y & 0xff000000u) + __popc(tg.y) : 0;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        if (n + total > kPoolSlots) { r.complete = false; mine = 0; }
+        if (mine) {
+            int w = n + incl - mine;
+            uint32_t inner = ng.y;
+            while (inner & 0xff000000u) {
+                const int nodeOffset = 31 - __clz((int)inner);
+                inner &= ~(1u << nodeOffset);
+                const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
+                const int rel = __popc(inner & ~(0xffffffffu << slot));
+                pool[w] = ((unsigned long long)((kItemNode << 30) | frame) << 32) | (unsigned long long)(ng.x + (uint32_t)rel);
+                w++;
+            }
+            uint32_t leaves = tg.y;
+            while (leaves) {
+                const int off = 31 - __clz((int)leaves);
+                leaves &= ~(1u << off);
+                const uint32_t leafTag = inTlas ? (kItemInst << 30) : ((kItemTri << 30) | frame);
+                pool[w] = ((unsigned long long)leafTag << 32) | (unsigned long long)(tg.x + (uint32_t)off);
+                w++;
+            }
+        }
+        if (r.complete) n += total;
+        // the round's closest candidate
+        const unsigned long long anyCand = __ballot(cand);
+        if (anyCand != 0ull) {
+            if (ANY_HIT) { r.count = 1; break; }
+            float m = ct;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            const unsigned long long atMin = __ballot(cand && ct == m);
+            const int winner = __ffsll((long long)atMin) - 1;
+            // the round's second smallest: the same distance again if two lanes hold it, else the smallest of the others
+            float m2 = (cand && lane != winner) ? ct : 3.0e38f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m2 = fminf(m2, __shfl_xor(m2, off));
+            if (r.count == 0 || m < r.t) {
+                r.second = r.count ? fminf(r.t, m2) : m2;
+                r.t = m;
+                r.u = __shfl(cu, winner);
+                r.v = __shfl(cv, winner);
+                r.tri = __shfl(rc[0].w, winner);
+                r.inst = __shfl(instIdx, winner);
+                r.count = 1;
+                r.window = 1.0e-3f * (m + magnitude);
+            } else {
+                r.second = fminf(r.second, m);
+            }
+        }
+        if (!r.complete) break;
+    }
+    return r;
+}
+
 template <bool ANY_HIT, bool STATS>
 // 5 waves per SIMD for both variants (96 VGPRs, no spills in the loop).  Before an instance entry also carried its BLAS
 // root (17 more live registers in the fetch), 6 waves at 80 VGPRs was the best point (5: -3 %, 7: -0.3 %, 8: -1.5 %); with it,
@@ -60,6 +250,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const bool scan = !ANY_HIT && (bounceArg & kTraceScanFlag) != 0;
     // ... | kTraceEntryFlag: the rays name the entry state of their run (rayO.w): installed at refill instead of the root's
     const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
+    // ... | kTraceThinFlag: the last long rays of a dry wave may be handed to the thin kernel (below)
+    bool thinAllowed = !STATS && kThinCode && (bounceArg & kTraceThinFlag) != 0;
     const NX_G EntryState* const entryTable = S->entry;
     const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
@@ -425,6 +617,22 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 rngCur = rngEnd = 0;
             }
 #endif
+            if (!STATS && kThinCode && thinAllowed && exhausted && rngCur >= rngEnd && activeMask != 0ull && __popcll(activeMask) <= kThinLanes && spins >= (uint32_t)kThinIters) {
+                // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
+                // a wave on each of them; this wave is done
+                NX_G int* const count = &C->thinCount[ANY_HIT ? 1 : 0][bounce];
+                int base = 0;
+                const int leader = __ffsll((long long)activeMask) - 1, n = (int)__popcll(activeMask);
+                if (lane == leader) base = atomicAdd(count, n);
+                base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+                const int place = base + (int)__popcll(activeMask & laneLt);
+                if (active && place < (int)S->thinCapacity) {  // (every entry below min(count, capacity) is written)
+                    (ANY_HIT ? S->thinAny : S->thinClosest)[place] = rayIdx;
+                    active = false;
+                }
+                activeMask = __ballot(active);
+                thinAllowed = false;  // (lanes the list had no room for: this wave finishes them itself)
+            }
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
     }
 
@@ -458,6 +666,75 @@ template __global__ void trace_kernel<false, false>(const DeviceState*, int);
 template __global__ void trace_kernel<false, true>(const DeviceState*, int);
 template __global__ void trace_kernel<true, false>(const DeviceState*, int);
 template __global__ void trace_kernel<true, true>(const DeviceState*, int);
+
+// The listed rays of one level (closest-hit first, then any-hit), one wave per ray, grid-stride.  `bounceArg` as the trace
+// launches got it: the ray set and the meaning of the closest-hit record follow kTraceScanFlag.
+__global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __restrict__ S, const int bounceArg)
+{
+    __shared__ unsigned long long sPool[(kTraceBlock / kWave) * kPoolSlots];
+    __shared__ unsigned long long sStack[kLdsDepth * kTraceBlock];  // (for the rare in-order traversal: traverse_wave)
+    const int bounce = bounceArg & 0xff;
+    const bool scan = (bounceArg & kTraceScanFlag) != 0;
+    const int raySet = scan ? (bounce & 1) : 0;
+    NX_G Counters* C = S->counters;
+    const int cap = (int)S->thinCapacity;
+    const int nClosest = min(C->thinCount[0][bounce], cap), nAny = min(C->thinCount[1][bounce], cap);
+    if (nClosest + nAny <= 0) return;
+    const bool sceneIdentity = (S->sceneFlags & kSceneAllIdentity) != 0u;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    lds_u64* const pool = (lds_u64*)&sPool[wave * kPoolSlots];
+    lds_u64* const stackLds = (lds_u64*)&sStack[threadIdx.x];
+    const int waves = (int)gridDim.x * (kTraceBlock / kWave);
+    for (int e = (int)blockIdx.x * (kTraceBlock / kWave) + wave; e < nClosest + nAny; e += waves) {
+        if (e < nClosest) {
+            const uint32_t word = S->thinClosest[e];
+            const uint32_t slot = word & 0x7fffffffu;
+            const float4 o = S->trace.rays[raySet].rayO[slot], d = S->trace.rays[raySet].rayD[slot];
+            const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
+            ThinResult r = thin_wave_search<false>(S, pool, org, dir, 1e30f, sceneIdentity);
+            const bool ambiguous = r.count != 0 && r.second <= r.t + r.window;
+            float hitT = r.count ? r.t : 1e30f, hitU = r.u, hitV = r.v;
+            uint32_t hitTri = r.count ? r.tri : 0xffffffffu, hitInst = r.inst;
+            if (!r.complete || ambiguous) {
+                // the reference's own order, one lane at work (rare: a second triangle within rounding of the closest, or a pool that ran over)
+                traverse_wave<false>(S, stackLds, lane == 0, org, dir, hitT, hitU, hitV, hitTri, hitInst);
+                hitT = __shfl(hitT, 0); hitU = __shfl(hitU, 0); hitV = __shfl(hitV, 0);
+                hitTri = __shfl(hitTri, 0); hitInst = __shfl(hitInst, 0);
+                if (hitTri != 0xffffffffu) {  // (traverse_wave returns the bare instance: its material code again, as inst_code_kernel writes it)
+                    const int type = (int)S->shadeInst[hitInst].material.type;
+                    hitInst |= (type >= 0 && type <= 3) ? (uint32_t)(type + 1) << kHitCodeShift : 0u;
+                }
+            }
+            if (lane == 0) {  // the record the closest-hit kernel's flush writes
+                const bool missed = hitTri == 0xffffffffu;
+                S->trace.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float(hitTri));
+                S->trace.hitInst[slot] = scan ? (missed ? (kHitCodeMiss << kHitCodeShift) : ((word >> 31) ? hitInst : 0u))
+                                              : (missed ? 0xffffffffu : (hitInst & kHitInstMask));
+            }
+        } else {
+            const uint32_t slot = S->thinAny[e - nClosest];
+            const float4 o = S->shadow.rayO[slot], d = S->shadow.rayD[slot];
+            const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
+            const ThinResult r = thin_wave_search<true>(S, pool, org, dir, o.w, sceneIdentity);
+            bool occluded = r.count != 0;
+            if (!occluded && !r.complete) {
+                float t = o.w, u, v;
+                uint32_t tri, inst;
+                occluded = traverse_wave<true>(S, stackLds, lane == 0, org, dir, t, u, v, tri, inst);
+                occluded = __shfl((int)occluded, 0) != 0;
+            }
+            if (!occluded && lane == 0) {  // pathRadiance[pixelIdx] += radiance, as the any-hit kernel's flush (BVH8Traversal.cuh:515-516)
+                const float4 rad = S->shadow.radiance[slot];
+                NX_G float4* dst = &S->radiance[__float_as_uint(d.w)];
+                float4 cur = *dst;
+                cur.x += rad.x; cur.y += rad.y; cur.z += rad.z;
+                *dst = cur;
+            }
+        }
+    }
+}
+
+const void* thin_kernel_ptr() { return (const void*)thin_kernel; }
 
 const void* trace_kernel_ptr(bool anyHit, bool stats)
 {

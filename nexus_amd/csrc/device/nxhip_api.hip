@@ -24,6 +24,7 @@ const void* miss_scan_kernel_ptr();
 const void* count_scan_kernel_ptr();
 const void* inst_code_kernel_ptr();
 const void* entry_state_kernel_ptr();
+const void* thin_kernel_ptr();
 const void* begin_frame_kernel_ptr();
 const void* hook_sizes_kernel_ptr();
 const void* generate_kernel_ptr();
@@ -190,6 +191,9 @@ static void invalidate_graph(nxhip_ctx* c)
 // may run over it; a queue buffer holds kQueueShards regions.
 static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) / (kQueueShards * 64)) * 64 + kQueueShardSlack; }
 static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
+// entries per list of rays handed to the thin kernel (nx_trace.hip): a launch hands over at most kThinLanes rays per wave, 20 480 for a
+// full grid; a list that runs over only makes the waves it has no room for finish their rays themselves
+constexpr uint32_t kThinListEntries = 1u << 16;
 static size_t scan_status_tiles(size_t n) { return n / (size_t)std::min(kLogicBlockThreads, kShadeBlockThreads) + 2; }
 
 // Which pipeline a pass runs (nx_wavefront.hip): SCAN — the logic step's decision rides in the hit records and the material kernels
@@ -222,6 +226,9 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     v.counters = s->counters.as<Counters>();
     v.frame = s->frame.as<FrameState>();
     v.scanStatus = s->scanStatus.as<unsigned long long>();
+    v.thinClosest = s->thinLists.as<uint32_t>();
+    v.thinAny = s->thinLists.p ? s->thinLists.as<uint32_t>() + kThinListEntries : nullptr;
+    v.thinCapacity = s->thinLists.p ? kThinListEntries : 0u;
     // queue regions: eight, or one spanning the buffer when slots are handed out in the reference's serial order
     const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
     v.queueShards = ordered ? 1u : (uint32_t)kQueueShards;
@@ -268,11 +275,14 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     const size_t statusBytes = scan_status_tiles(n) * kScanWords * sizeof(unsigned long long);
     if (!freshStatus.alloc(statusBytes)) return NXHIP_ERR_HIP;
     NX_HIP(hipMemset(freshStatus.p, 0, statusBytes));
+    DevBuf freshThin;  // (contents: whatever the trace launches of a level write before the thin kernel of that level reads)
+    if (!freshThin.alloc((size_t)2 * kThinListEntries * sizeof(uint32_t))) return NXHIP_ERR_HIP;
     NX_HIP(hipMemset(fresh[0].p, 0, n * 16));  // radiance
     NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
     q->scanStatus = std::move(freshStatus);
+    q->thinLists = std::move(freshThin);
     q->scanEpoch = 0;
     q->pathCapacity = n;
     q->queuesScan = scan;
@@ -297,6 +307,7 @@ static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
                             &q->mqHit[3], &q->mqDirInst[3], &q->mqTp[3], &q->trRayO2, &q->trRayD2, &q->trTp2};
     for (DevBuf* b : bufs) b->release();
     q->scanStatus.release();
+    q->thinLists.release();
     q->pathCapacity = 0;
     if (q == static_cast<PassSlot*>(c)) {
         DeviceState& h = c->h;
@@ -483,6 +494,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
             }
+            if (const char* e = std::getenv("NX_NO_THIN")) c->thinWaves = std::atoi(e) == 0;  // measurement only: no cooperative finish of a dry wave's last rays
             if (const char* e = std::getenv("NX_SCAN_SEPARATE")) c->scanSeparate = std::atoi(e) != 0;  // measurement only: one material launch per type in the SCAN pipeline
             if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
             if (const char* e = std::getenv("NX_SHADE_SERIAL")) c->serialShade = std::atoi(e) != 0;  // tuning experiments only
@@ -1699,7 +1711,14 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         levels.back().push_back(l);
     }
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
-    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, entry ? kTraceEntryFlag : 0)});
+    // (every trace launch of a pass may finish the last long rays of its dry waves cooperatively: nx_trace.hip thin_wave_bound)
+    const int thinFlag = (c->thinWaves && !stats) ? kTraceThinFlag : 0;
+    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
+    // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
+    const int thinBlocks = 3 * c->numCUs;
+    auto thin_level = [&](int bounceArg) {
+        if (thinFlag) levels.push_back({make_launch(thin_kernel_ptr(), thinBlocks, kTraceBlockThreads, NXHIP_K_THIN, S, bounceArg)});
+    };
     const int pathLength = c->h.settings.pathLength;
     // (grids of the producer kernels stay multiples of the queue regions: harmless, and what a round-robin tile-to-region mapping
     //  would need)
@@ -1714,6 +1733,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         // kernels find their items there.  Per bounce: [miss kernel, only when a miss can contribute] -> the material kernels of the
         // types in use, one after the other -> trace || shadow trace.  One launch less per bounce than the reference's DAG.
         levels[1][0].bounce |= kTraceScanFlag;
+        thin_level(0 | kTraceScanFlag);
         const bool misses = pass_flavor(c) & kFlavorMissKernel;
         for (int bounce = 1; bounce <= pathLength; bounce++) {
             if (bounce == tailFrom) {  // the rest of the pass in one launch
@@ -1744,11 +1764,13 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
                 shade.push_back(l);
             }
             for (auto& l : shade) levels.push_back({l});
-            levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce | kTraceScanFlag),
-                              make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
+            levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce | kTraceScanFlag | thinFlag),
+                              make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce | thinFlag)});
+            thin_level(bounce | kTraceScanFlag);
         }
         return levels;
     }
+    thin_level(0);
     for (int bounce = 1; bounce <= pathLength; bounce++) {
         if (bounce == tailFrom) {  // the rest of the pass in one launch
             levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce)});
@@ -1767,8 +1789,9 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         // for four hardware queues per slot (the material kernels of one bounce serialise on the CUs anyway: each grid fills them)
         if (ordered || serial_shade(c)) for (auto& l : shade) levels.push_back({l});
         else levels.push_back(shade);
-        levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce),
-                          make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce)});
+        levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, bounce | thinFlag),
+                          make_launch(trace_kernel_ptr(true, stats), shadowBlocks, kTraceBlockThreads, NXHIP_K_SHADOW, S, bounce | thinFlag)});
+        thin_level(bounce);
     }
     return levels;
 }

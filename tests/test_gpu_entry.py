@@ -126,3 +126,31 @@ def test_a_camera_inside_the_geometry_and_axis_parallel_views(gpu_ctx_factory):
         for k in range(2):
             assert np.array_equal(got[k].view(np.uint32), base[k].view(np.uint32)), (eye, fwd)
         assert np.array_equal(got_acc.view(np.uint32), base_acc.view(np.uint32))
+
+
+def test_passes_in_flight_share_the_entry_table(gpu_ctx_factory):
+    """Several passes in flight: every pass's graph rewrites the one entry table while the others' closest-hit launches read it.  The
+    kernel stores each state once, from registers (same bytes every time); a version that first stored the root's state and then the
+    walked one let a concurrent reader see a mixture (round 5: bench.py with 6 passes in flight rendered another image)."""
+    W, H = 320, 200
+    scene = _torus_scene(W, H, nu=256, nv=128)
+    pm = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)
+
+    def render(entry, in_flight, per_pass):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+        ctx.set_pixel_map(pm)
+        ctx.set_entry_points(entry)
+        ctx.set_frames_per_pass(per_pass)
+        ctx.set_passes_in_flight(in_flight)
+        ctx.reset_frame_number()
+        for _ in range(24 // per_pass):
+            ctx.render_frame()
+            ctx.accumulate()
+        return ctx.read_accumulation()
+
+    want = render(False, 1, 2)
+    for in_flight, per_pass in ((6, 2), (4, 1), (2, 8)):
+        got = render(True, in_flight, per_pass)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (in_flight, per_pass)
