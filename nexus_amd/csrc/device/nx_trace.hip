@@ -75,7 +75,10 @@ constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer t
 #ifndef NX_THIN_ITERS
 #define NX_THIN_ITERS 64
 #endif
-constexpr int kThinLanes = NX_THIN_LANES, kThinIters = NX_THIN_ITERS;
+#ifndef NX_THIN_FACTOR
+#define NX_THIN_FACTOR 4
+#endif
+constexpr int kThinLanes = NX_THIN_LANES, kThinIters = NX_THIN_ITERS, kThinFactor = NX_THIN_FACTOR;
 #ifdef NX_NO_THIN_CODE
 constexpr bool kThinCode = false;  // (measurement: the kernel without the search's text)
 #else
@@ -252,6 +255,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
     // ... | kTraceThinFlag: the last long rays of a dry wave may be handed to the thin kernel (below)
     bool thinAllowed = !STATS && kThinCode && (bounceArg & kTraceThinFlag) != 0;
+    uint32_t itersTotal = 0u, taken = 0u, thinAfter = (uint32_t)kThinIters;  // (wave-uniform: loop iterations and rays of this wave so far)
     const NX_G EntryState* const entryTable = S->entry;
     const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
@@ -402,7 +406,12 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         }
                         best = __builtin_amdgcn_readfirstlane(best);
                         bestLeft = __builtin_amdgcn_readfirstlane(bestLeft);
-                        if (bestLeft <= 0) exhausted = true;
+                        if (bestLeft <= 0) {
+                            exhausted = true;
+                            // how long "long" is for this launch: kThinFactor times what a ray of this wave took on average (a wave
+                            // iteration advances its busy lanes — about 40 of 64 — by one record each), at least kThinIters
+                            thinAfter = max((uint32_t)kThinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u)));
+                        }
                         else shard = best;
                         continue;
                     }
@@ -459,6 +468,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     }
                 }
                 rngCur += min(__popcll(needMask), avail);
+                taken += (uint32_t)min(__popcll(needMask), avail);
             }
         }
         unsigned long long activeMask = __ballot(active);
@@ -617,7 +627,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 rngCur = rngEnd = 0;
             }
 #endif
-            if (!STATS && kThinCode && thinAllowed && exhausted && rngCur >= rngEnd && activeMask != 0ull && __popcll(activeMask) <= kThinLanes && spins >= (uint32_t)kThinIters) {
+            if (!STATS && kThinCode && thinAllowed && exhausted && rngCur >= rngEnd && activeMask != 0ull && __popcll(activeMask) <= kThinLanes && spins >= thinAfter) {
                 // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
                 // a wave on each of them; this wave is done
                 NX_G int* const count = &C->thinCount[ANY_HIT ? 1 : 0][bounce];
@@ -634,6 +644,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 thinAllowed = false;  // (lanes the list had no room for: this wave finishes them itself)
             }
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
+        itersTotal += spins;
     }
 
 #ifdef NX_EXTRA_VALU

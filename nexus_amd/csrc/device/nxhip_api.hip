@@ -1672,7 +1672,7 @@ int tail_bounce(const nxhip_ctx* c)
 // kernel is in the graph only for a scene with an environment map or a background that is not exactly black — PathTracer.cu:
 // 152-164 adds throughput x background, and +0 changes nothing), and the logic kernel's variant (one item per thread under an
 // environment map).  Part of a graph instance's key, so a change of any of them picks or builds the matching instance.
-constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4, kFlavorEntry = 8;
+constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4, kFlavorEntry = 8, kFlavorThin = 16;
 int pass_flavor(const nxhip_ctx* c)
 {
     int f = 0;
@@ -1688,6 +1688,11 @@ int pass_flavor(const nxhip_ctx* c)
     }
     if (c->hdrMap.texels.p || !black) f |= kFlavorMissKernel;
     if (c->entryPoints && c->entryTable.p) f |= kFlavorEntry;
+    // The thin kernel (nx_trace.hip) pays when ONE pass runs at a time: the lanes a dry wave leaves idle are then idle SIMD time, and
+    // a level ends with its slowest ray (driver command: mean of five repetitions 19.9 -> 19.0 ms, 512 frames in 64-frame passes one at a
+    // time +2.9 %).  With several passes in flight the other passes' waves fill those lanes anyway and the hand-over is extra work
+    // (four in flight: -2.4 %, configs[4] -1.1 %): off.
+    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
     return f;
 }
 
@@ -1712,7 +1717,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     }
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
     // (every trace launch of a pass may finish the last long rays of its dry waves cooperatively: nx_trace.hip thin_wave_bound)
-    const int thinFlag = (c->thinWaves && !stats) ? kTraceThinFlag : 0;
+    const int thinFlag = (pass_flavor(c) & kFlavorThin) ? kTraceThinFlag : 0;
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
     const int thinBlocks = 3 * c->numCUs;
