@@ -153,6 +153,7 @@ constexpr uint32_t kRaySurvives = 2u;     // SCAN pipeline: the Russian-roulette
 constexpr int kHitCodeShift = 29;
 constexpr uint32_t kHitInstMask = (1u << kHitCodeShift) - 1u;
 constexpr uint32_t kHitCodeMiss = 7u;
+constexpr int kScanMiss = 4;  // the misses' place among the types of shade_scan_kernel (typeMask bit, ticket row)
 // the trace kernels' `bounce` argument: bounce | kTraceScanFlag = the SCAN pipeline's launch (ray set by bounce parity, codes in
 // the hit records); without the flag: rays[0], plain hit records (classic pipeline, ray-batch hooks)
 constexpr int kTraceScanFlag = 0x100;
@@ -218,8 +219,8 @@ struct RegionCounters {
     int32_t shadowHead[kMaxBounceSlots];
     // SCAN pipeline (nx_wavefront.hip shade_scan_kernel): tiles of this region's trace queue handed out so far to the material
     // kernel of a type, beyond the one every workgroup takes by its rank
-    int32_t scanTile[4][kMaxBounceSlots];
-    int32_t pad_[2048 - 12 * kMaxBounceSlots];
+    int32_t scanTile[5][kMaxBounceSlots];  // [NX_MAT_*], [kScanMiss]: the misses (a fifth "type" of the one material launch)
+    int32_t pad_[2048 - 13 * kMaxBounceSlots];
 };
 static_assert(sizeof(RegionCounters) == 8192, "one region's counters per 8 KiB");
 constexpr int kRegionStride = (int)(sizeof(RegionCounters) / sizeof(int32_t));  // distance between the same word of two regions

@@ -966,6 +966,10 @@ template <int TYPE>
 NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, const int region, const int inRegion, const int per, const int firstTile, const int staticTiles,
                          int* const sRing, int* const sHead, int* const sTicket)
 {
+    // TYPE == kScanMiss: the rays that missed (code kHitCodeMiss) — what is left of the logic step when a miss can contribute: the
+    // environment (flat colour or map, MIS-weighted against the environment sampler) added to the path's radiance, PathTracer.cu:152-164
+    constexpr bool kMiss = TYPE == kScanMiss;
+    constexpr uint32_t kCode = kMiss ? kHitCodeMiss : (uint32_t)(TYPE + 1);
     Counters* C = S->counters;
     const int tileRays = per * kShadeBlock;
     const int tiles = (inRegion + tileRays - 1) / tileRays;
@@ -988,7 +992,7 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
     const NX_G uint32_t* const codes = S->trace.hitInst + regionBase;
     SlotAllocator<false, 2> slots;  // 0: shadow requests, 1: continuation rays
     static_assert(offsetof(RegionCounters, traceSize) + kMaxBounceSlots * sizeof(int32_t) == offsetof(RegionCounters, traceShadowSize), "traceShadowSize follows traceSize");
-    slots.init(S, &C->region[0].traceShadowSize[bounce], -kMaxBounceSlots, 1 + TYPE, bounce, inRegion);
+    slots.init(S, &C->region[0].traceShadowSize[bounce], -kMaxBounceSlots, 1 + (kMiss ? 0 : TYPE), bounce, inRegion);
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     int tail = 0, head = 0;  // ring positions [tail, head) hold found slots not shaded yet (uniform)
@@ -998,6 +1002,24 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
         const bool have = (int)threadIdx.x < take;
         const int at = regionBase + (have ? sRing[(tail + (int)threadIdx.x) & (kScanRing - 1)] : 0);
         tail += take;
+        if constexpr (kMiss) {
+            if (have) {
+                const float4 dirPix = in.rayD[at];
+                const uint32_t pixelIdx = __float_as_uint(dirPix.w);
+                const float4 tp = bounce == 1 ? make_float4(1.0f, 1.0f, 1.0f, 1.0e10f) : in.tp[at];
+                bool miss, survived, needsPrevVertex;
+                f3 bg = mk3(0.0f), t = mk3(0.0f);
+                uint32_t inst = 0;
+                logic_path(S, bounce, frame, (uint32_t)at, pixelIdx, 1e30f, mk3(dirPix.x, dirPix.y, dirPix.z), tp, [&]() { return 0u; }, miss, bg, survived, t, inst, needsPrevVertex);
+                if ((__float_as_uint(bg.x) | __float_as_uint(bg.y) | __float_as_uint(bg.z)) != 0u) {  // (as the logic kernel: +0 changes nothing)
+                    float4 r = bounce == 1 ? make_float4(0, 0, 0, 0) : S->radiance[pixelIdx];
+                    r.x += bg.x; r.y += bg.y; r.z += bg.z;
+                    if (bounce == 1) r = make_float4(bg.x, bg.y, bg.z, 0.0f);
+                    S->radiance[pixelIdx] = r;
+                }
+            }
+            return;
+        } else {
         bool wantShadow = false, wantTrace = false, updatePath = false;
         ShadowPayload sh;
         f3 nextOrigin = mk3(0.0f), nextDir = mk3(0.0f), nextThroughput = mk3(0.0f);
@@ -1055,6 +1077,7 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
             out.rayD[traceSlot] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(pixelIdx));
             out.tp[traceSlot] = tpNext;
         }
+        }
     };
 
     for (;;) {
@@ -1068,8 +1091,8 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
                 if (r0 + 1 < inRegion) w.y = codes[r0 + 1];
                 if (r0 + 2 < inRegion) w.z = codes[r0 + 2];
             }
-            const bool m0 = (w.x >> kHitCodeShift) == (uint32_t)(TYPE + 1), m1 = (w.y >> kHitCodeShift) == (uint32_t)(TYPE + 1);
-            const bool m2 = (w.z >> kHitCodeShift) == (uint32_t)(TYPE + 1), m3 = (w.w >> kHitCodeShift) == (uint32_t)(TYPE + 1);
+            const bool m0 = (w.x >> kHitCodeShift) == kCode, m1 = (w.y >> kHitCodeShift) == kCode;
+            const bool m2 = (w.z >> kHitCodeShift) == kCode, m3 = (w.w >> kHitCodeShift) == kCode;
             const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2), b3 = __ballot(m3);
             const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
             const int total = n0 + n1 + n2 + n3;
@@ -1084,7 +1107,7 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
             }
         } else {
             const int r0 = t * tileRays + (int)threadIdx.x;
-            const bool m0 = r0 < inRegion && (codes[r0] >> kHitCodeShift) == (uint32_t)(TYPE + 1);
+            const bool m0 = r0 < inRegion && (codes[r0] >> kHitCodeShift) == kCode;
             const unsigned long long b0 = __ballot(m0);
             if (b0) {
                 int base = 0;
@@ -1105,10 +1128,11 @@ NXD void shade_scan_type(const DeviceState* __restrict__ S, const int bounce, co
     }
     if (head - tail > 0) shade_batch(head - tail);
     // the items this workgroup shaded, for nxhip_read_queue_sizes (the reference's per-type queue sizes, D_QueueSize)
-    if (threadIdx.x == 0 && head) atomicAdd(&C->region[region].materialSize[TYPE][bounce], head);
+    if (!kMiss && threadIdx.x == 0 && head) atomicAdd(&C->region[region].materialSize[kMiss ? 0 : TYPE][bounce], head);
 }
 
-// All material types of a bounce in ONE launch (`typeMask`: bit NX_MAT_* = that type has a kernel in this pass).  The region's
+// All material types of a bounce in ONE launch (`typeMask`: bit NX_MAT_* = that type has a kernel in this pass; bit kScanMiss = the
+// misses contribute — an environment map or a background that is not black — and are handled here as a fifth type).  The region's
 // workgroups start on different types (rank modulo the number of types) and move on to the next type when theirs has no tile
 // left, so the types run side by side, the launch ends when the last tile of the last type does, and a bounce costs one material
 // launch instead of one per type (the reference: four, PathTracer.cpp:116-120).  A single-bit mask is a per-type launch.
@@ -1119,7 +1143,7 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
     const int region = (int)(blockIdx.x & (kQueueShards - 1));
     const int inRegion = S->counters->region[region].traceSize[bounce - 1];  // rays of this region after trace(bounce - 1)
     const int rank = (int)(blockIdx.x >> 3), ranks = max(1, (int)(gridDim.x >> 3));
-    const int nTypes = __popc((uint32_t)typeMask & 0xfu);
+    const int nTypes = __popc((uint32_t)typeMask & 0x1fu);
     if (inRegion <= 0 || nTypes == 0) return;
     // this workgroup's place among those that start on the same type, and how many of them there are
     const int myStart = rank % nTypes, myIndex = rank / nTypes;
@@ -1129,12 +1153,12 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
     if (myIndex >= tiles) return;  // more workgroups than tiles (late bounces): the surplus leaves before any barrier or atomic
     // the types in graph order of the reference (Diffuse, Plastic, Dielectric, Conductor: PathTracer.cpp:116-120), rotated so that
     // this workgroup begins with its own
-    constexpr int kOrder[4] = {NX_MAT_DIFFUSE, NX_MAT_PLASTIC, NX_MAT_DIELECTRIC, NX_MAT_CONDUCTOR};
+    constexpr int kOrder[5] = {NX_MAT_DIFFUSE, NX_MAT_PLASTIC, NX_MAT_DIELECTRIC, NX_MAT_CONDUCTOR, kScanMiss};
     for (int step = 0; step < nTypes; step++) {
         const int want = (myStart + step) % nTypes;  // index among the types present
         int type = -1, seen = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 5; k++)
             if ((typeMask >> kOrder[k]) & 1) { if (seen == want) type = kOrder[k]; seen++; }
         const int starters = (ranks - want + nTypes - 1) / nTypes;  // workgroups whose first type this is: each takes the tile of its index
         const int first = step == 0 ? myIndex : -1;
@@ -1143,6 +1167,7 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
         case NX_MAT_PLASTIC: shade_scan_type<NX_MAT_PLASTIC>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
         case NX_MAT_DIELECTRIC: shade_scan_type<NX_MAT_DIELECTRIC>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
         case NX_MAT_CONDUCTOR: shade_scan_type<NX_MAT_CONDUCTOR>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
+        case kScanMiss: shade_scan_type<kScanMiss>(S, bounce, region, inRegion, per, first, min(starters, tiles), sRing, &sHead, &sTicket); break;
         default: break;
         }
     }

@@ -1745,13 +1745,14 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
                 levels.push_back({make_launch(tail_kernel_ptr(), c->tailBlocks, kTraceBlockThreads, NXHIP_K_SHADE, S, bounce | kTraceScanFlag)});
                 break;
             }
-            if (misses) levels.push_back({make_launch(miss_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce)});
+            if (misses && c->scanSeparate) levels.push_back({make_launch(miss_scan_kernel_ptr(), lg, kWideBlockThreads, NXHIP_K_LOGIC, S, bounce)});
             std::vector<Launch> shade;
             // the material kernels of the types in use: ONE launch for all of them (shade_scan_kernel), or — NX_SCAN_SEPARATE, measurement
             // only — one per type in the reference's graph order
             int mask = (int)(c->materialTypeMask & 0xfu);
             if (c->h.conductorMode != NX_CONDUCTOR_EXTENDED) mask &= ~(1 << NX_MAT_CONDUCTOR);
             if (mask == 0) mask = 1 << NX_MAT_DIFFUSE;  // (a level cannot be empty)
+            if (misses && !c->scanSeparate) mask |= 1 << kScanMiss;  // the misses: a fifth type of the one launch
             auto scan_launch = [&](int m) {
                 Launch l = make_launch(shade_scan_kernel_ptr(), og, kShadeBlockThreads, NXHIP_K_SHADE, S, bounce);
                 l.type = m;
