@@ -122,8 +122,8 @@ def tile_pixel_map(width, height, rank, world):
     return multigpu.tile_pixel_map(width, height, rank, world, multigpu.tile_rows_for(height, world, (TILE_ROWS, 8, 4, 6, 3, 2, 1)))
 
 
-KERNEL_SOURCES = {"trace": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"),
-                  "wavefront": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h")}
+KERNEL_SOURCES = {"trace": ("nx_trace.hip", "nx_traverse.h", "nx_entry.hip", "nx_queue.h", "nx_device.h", "nx_math.h"),
+                  "wavefront": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_traverse.h", "nx_queue.h", "nx_device.h", "nx_math.h")}
 
 
 def kernel_source_hash(which):

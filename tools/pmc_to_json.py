@@ -19,26 +19,22 @@ ap.add_argument("passes", nargs="+")
 a = ap.parse_args()
 
 # kernel classes: name pattern -> the unit its counters are divided by (rays traced; queue items processed)
-KERNELS = {"trace_closest": "trace_kernel<false, false", "trace_shadow": "trace_kernel<true, false", "logic": "logic_kernel<", "shade": "shade_kernel<"}
+# (shade: the one material launch of the SCAN pipeline, or the classic per-type kernels; logic: the classic logic kernel, or what the SCAN pipeline keeps of it
+#  under NX_SCAN_SEPARATE; thin: the launch behind a level's trace launches that finishes the rays their dry waves handed over)
+KERNELS = {"trace_closest": ("trace_kernel<false, false",), "trace_shadow": ("trace_kernel<true, false",), "logic": ("logic_kernel<", "miss_scan_kernel"),
+           "shade": ("shade_kernel<", "shade_scan_kernel"), "thin": ("thin_kernel",)}
 bench = json.load(open(a.bench))
 rf = bench["roofline"]
 rays = {"trace_closest": rf["rays_per_frame"] * a.frames, "trace_shadow": rf["shadow"]["rays_per_frame"] * a.frames,
-        "logic": rf.get("items_per_frame", {}).get("logic", 0) * a.frames, "shade": rf.get("items_per_frame", {}).get("shade", 0) * a.frames}
+        "logic": rf.get("items_per_frame", {}).get("logic", 0) * a.frames, "shade": rf.get("items_per_frame", {}).get("shade", 0) * a.frames,
+        "thin": rf["rays_per_frame"] * a.frames}  # (thin: per closest-hit ray of the frame, so that its cost adds to the trace kernel's)
 
 
-def source_hash(files):
-    """sha256 over the kernel sources a class is compiled from: bench.py refuses counter constants measured on other code"""
-    import hashlib
-    h = hashlib.sha256()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f in files:
-        h.update(open(os.path.join(root, "nexus_amd", "csrc", "device", f), "rb").read())
-    return h.hexdigest()[:16]
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (the one definition of "the code these counters were measured on")
 
-
-SOURCES = {"trace_closest": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"), "trace_shadow": ("nx_trace.hip", "nx_traverse.h", "nx_device.h", "nx_math.h"),
-           "logic": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h"),
-           "shade": ("nx_wavefront.hip", "nx_bsdf.h", "nx_rng.h", "nx_texture.h", "nx_device.h", "nx_math.h")}
+CLASS_OF = {"trace_closest": "trace", "trace_shadow": "trace", "thin": "trace", "logic": "wavefront", "shade": "wavefront"}
 
 sums = {k: collections.defaultdict(float) for k in KERNELS}
 frames_of = {}  # counter name -> frames the run that collected it rendered
@@ -58,8 +54,8 @@ for d in a.passes:
     names = set()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            for k, pat in KERNELS.items():
-                if pat in r["Kernel_Name"]:
+            for k, pats in KERNELS.items():
+                if any(pat in r["Kernel_Name"] for pat in pats):
                     sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
                     names.add(r["Counter_Name"])
                     if r["Dispatch_Id"] not in seen[k]:
@@ -75,8 +71,8 @@ out = json.load(open(a.out)) if os.path.exists(a.out) else {}
 cfg = out.setdefault("config%d" % a.config, {})
 cfg["profile"] = {"tag": a.tag, "command": a.command, "frames": sorted(set(frames_of.values()))[0] if frames_of else a.frames,
                   "pass_dirs": [os.path.basename(os.path.normpath(p)) for p in a.passes]}
-per_frame = {"trace_closest": rf["rays_per_frame"], "trace_shadow": rf["shadow"]["rays_per_frame"],
-             "logic": rf.get("items_per_frame", {}).get("logic", 0), "shade": rf.get("items_per_frame", {}).get("shade", 0)}
+per_frame = {"trace_closest": rf["rays_per_frame"], "trace_shadow": rf["shadow"]["rays_per_frame"], "thin": rf["rays_per_frame"],
+             "logic": rf.get("items_per_frame", {}).get("logic", 0) or rf["rays_per_frame"], "shade": rf.get("items_per_frame", {}).get("shade", 0)}
 for k in KERNELS:
     s, n = dict(sums[k]), max(1, rays[k])
     if not s:
@@ -88,7 +84,7 @@ for k in KERNELS:
         raise SystemExit("counter passes rendered different numbers of frames: %s" % seen_frames)
     n = max(1, per_frame[k] * seen_frames[0])
     rays[k] = n
-    e = {"rays_profiled": int(rays[k]), "unit": "ray" if k.startswith("trace") else "queue item", "source_sha16": source_hash(SOURCES[k])}
+    e = {"rays_profiled": int(rays[k]), "unit": "ray" if k.startswith("trace") else "queue item", "source_sha16": kernel_source_hash(CLASS_OF[k])}
     if "FETCH_SIZE" in s:
         e["hbm_read_bytes_per_ray"] = round(2.0 * s["FETCH_SIZE"] * 1024.0 / n, 2)
     if "WRITE_SIZE" in s:
