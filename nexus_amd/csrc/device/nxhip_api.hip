@@ -1692,7 +1692,9 @@ int pass_flavor(const nxhip_ctx* c)
     // a level ends with its slowest ray (driver command: mean of five repetitions 19.9 -> 19.0 ms, 512 frames in 64-frame passes one at a
     // time +2.9 %).  With several passes in flight the other passes' waves fill those lanes anyway and the hand-over is extra work
     // (four in flight: -2.4 %, configs[4] -1.1 %): off.
-    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
+    // ... nor for small passes (up to 8 frames' worth of paths, the share of a rank of 4 or 8 in the driver's 20 frames: its levels are
+    // a few hundred microseconds each and the extra launch per level costs more than the drain it saves: 4.57 -> 4.71 ms)
+    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u && pass_size_in_frames(c) > 8.0) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
     return f;
 }
 
