@@ -5,9 +5,10 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --config 5        # configs[4]: the 9.9 M-triangle interior whose traversal streams from HBM (1 GPU)
+    python bench.py --config 1        # configs[0]: the reference's Cornell box, 512x512, 4 bounces, + the CPU BVH2 path
 
 A "step" is one frame = one primary sample per pixel through the whole hot path (generate, trace, then pathLength x
-(logic, shade per material type + NEE, trace || shadow trace), accumulate).  Frames are rendered in passes (one hipGraph
+(the logic step + shade per material type + NEE — one material launch since round 5 —, trace || shadow trace), accumulate).  Frames are rendered in passes (one hipGraph
 replay per pass; each frame keeps its own frame number and RNG streams and the result is bit-identical to rendering them
 one by one); exactly K frames are timed.  plan_schedule() chooses the pass size from measurements: a budget that fits the
 queues (up to 128 full frames' worth of paths) is ONE pass, a longer one is a sequence of --frames-per-pass (64) frame
@@ -25,8 +26,9 @@ strong region too (config.strong_scaling).
 
 Rank 0 prints ONE JSON line.  It also carries
   roofline     : the closest-hit trace kernel against the three ceilings that could bind it, all from live launch durations
-                 (hipEvents recorded by event nodes around every kernel node of the production hipGraph, last replay of a
-                 back-to-back series on the context's stream):
+                 (hipEvents recorded by event nodes around every kernel node of the production hipGraph; every repetition of the
+                 timed region is replayed on its own frame numbers and the block is computed from the MEDIAN repetition's
+                 replay: roofline.timing lists the launch times of all of them):
                    hbm        : memory-side bytes per launch (`traffic`) = this run's rays per launch x the bytes per ray
                                 that `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` measured for this workload (committed under
                                 profiles/, reads doubled per the gfx950 note of MI355X_MICROARCH.md) / duration / 8 TB/s.
@@ -43,8 +45,8 @@ Rank 0 prints ONE JSON line.  It also carries
                                 come from the Infinity Cache, 1.0 from HBM).  VALU issue and the gather share the kernel's
                                 time nearly additively: neither fraction alone can approach 1.
                  `bound` names the ceiling with the larger fraction; `frac`, `achieved`, `peak`, `unit` belong to it.
-  roofline.classes : the second kernel class — logic and the material (shade) kernels — per queue item: HBM-side bytes and VALU
-                 instructions from the same committed counter passes, against 8 TB/s and the issue rate.
+  roofline.classes : the second kernel class — the material launch (and, in the classic pipeline, the logic kernel) — per queue
+                 item: HBM-side bytes and VALU instructions from the same committed counter passes, against 8 TB/s and the issue rate.
   cpu_baseline : the CPU oracle (port of the reference algorithm) on full frames of the same scene, timed on the
                  host cores of this box (trace, logic and shade threaded).  A reported baseline, not a target.
   emulated_rank (--emulate-rank-of N): rank 0's share of an N-way tile split rendered in this process, against full / N.
