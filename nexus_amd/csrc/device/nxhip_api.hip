@@ -1660,6 +1660,10 @@ int tail_bounce(const nxhip_ctx* c)
         const double frames = pass_size_in_frames(c);
         const unsigned slots = effective_slots(c);
         if (slots > 1u) bounce = frames > 4.0 ? 0 : (frames <= 2.5 && slots <= 3u) ? 3 : 5;
+        // (one pass at a time, round 5: the thin level takes the drains out of the trace launches, and the tail kernel — whose waves keep
+        //  64 lanes for as long as their longest path, outlier rays included — only still pays for the smallest passes: one frame 595 ->
+        //  620 Msamples/s with it, four frames 1 335 -> 1 315, a rank of 8 the same median with a 6.3 ms pass in seven instead of none)
+        else if (c->thinWaves) bounce = frames <= 1.5 ? 3 : 0;
         else bounce = frames <= 1.5 ? 3 : frames <= 4.0 ? 4 : frames <= 10.0 ? 5 : 0;
         if (bounce > (int)c->h.settings.pathLength) bounce = 0;
     }
@@ -1692,9 +1696,10 @@ int pass_flavor(const nxhip_ctx* c)
     // a level ends with its slowest ray (driver command: mean of five repetitions 19.9 -> 19.0 ms, 512 frames in 64-frame passes one at a
     // time +2.9 %).  With several passes in flight the other passes' waves fill those lanes anyway and the hand-over is extra work
     // (four in flight: -2.4 %, configs[4] -1.1 %): off.
-    // ... nor for small passes (up to 8 frames' worth of paths, the share of a rank of 4 or 8 in the driver's 20 frames: its levels are
-    // a few hundred microseconds each and the extra launch per level costs more than the drain it saves: 4.57 -> 4.71 ms)
-    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u && pass_size_in_frames(c) > 8.0) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
+    // Small passes one at a time keep it as well: the median of single passes does not show it (a rank of 8's 2.5 frames' worth: 4.57 ->
+    // 4.6-4.7 ms, an extra launch per level), but one pass in seven holds an outlier ray (6.2 ms instead of 4.6) and sequences of small
+    // passes are what a viewer or a rank of a tile split renders: four frames per pass 1 223 -> 1 335 Msamples/s, one frame 602 -> 620.
+    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
     return f;
 }
 
