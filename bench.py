@@ -685,7 +685,9 @@ def main():
             out["single_gpu_in_this_job"] = single
             out["efficiency_weak"] = round(out["value_weak"] / (world * v1), 4) if out["value_weak"] else None
             out["efficiency_strong"] = round(out["value_strong"] / (world * v1), 4) if out["value_strong"] else None
-            # back to rank 0's tiles for the roofline section
+            # back to rank 0's tiles for the roofline section (the pixel-set changes re-allocated the accumulation: the zero-copy view
+            # of it is stale from here on, and nothing below gathers any more)
+            acc_tile = None
             ctx.set_pixel_map(pm)
             ctx.set_frames_per_pass(S)
             if R > 1:

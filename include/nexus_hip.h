@@ -182,6 +182,13 @@ int nxhip_set_entry_points(nxhip_ctx *ctx, int on);
 /* The entry states of the last rendered pass, 80 bytes each (nx_device.h EntryState: six stack entries, node group, leaf group,
  * then int32 sp, instSp, leafSlot, steps) — a test hook: how many node steps the walk saved per run.  *count = number of runs. */
 int nxhip_read_entry_states(nxhip_ctx *ctx, void *out, uint32_t capacityRuns, uint32_t *count);
+/* Test hook for the thin kernel (nx_trace.hip): the hand-over rule — at most `lanes` busy lanes of a dry wave for at least `iters`
+ * iterations (product: 4 / 64; 64 / 0 makes every wave hand over the first rays it takes, after one iteration) — and whether the ray-batch
+ * hooks (nxhip_trace_batch, nxhip_trace_shadow_batch) use the hand-over + thin launch too, so that a test can put arbitrary rays
+ * through the cooperative search and compare the records with the oracle's.  nxhip_debug_thin_counts: the rays the last hook call
+ * handed over (closest-hit, any-hit). */
+int nxhip_debug_set_thin(nxhip_ctx *ctx, uint32_t lanes, uint32_t iters, int inHooks);
+int nxhip_debug_thin_counts(nxhip_ctx *ctx, int32_t counts[2]);
 
 /* ---- rendering ----------------------------------------------------------------------------------- */
 

@@ -53,7 +53,7 @@ constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer t
 // repetition of the driver's command 18.4 ms instead of 19.1 ... 21.3).  Splitting a ray INSIDE the loop was tried in round 3 and
 // cost the loop 11 % by its live values; the search below as a part of this kernel cost it 15 % out of line and 160 % inlined
 // (round 5: its registers around the refill point, not its execution).  So the trace kernels only HAND OVER: when the queue is
-// dry, at most kThinLanes lanes of a wave are still busy and they have been for kThinIters iterations, the wave appends those rays
+// dry, at most 4 lanes of a wave are still busy and they have been for 64 iterations or four average rays, the wave appends those rays
 // to a list and ends.  thin_kernel — one launch per level, behind the closest-hit and any-hit launches — puts a whole wave on each
 // listed ray: all 64 lanes search the ray's tree TOGETHER, in any order: a pool of work items (node, instance entry, triangle) in
 // LDS; every round each lane takes one item, tests it against the ray with the loop's own functions and puts the children the ray
@@ -69,16 +69,10 @@ constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer t
 //     Anything else inside the window: the ray is traversed again from the root in the reference's own order (traverse_wave).
 //   * A pool that would overflow ends the search; the ray is traversed in order likewise.
 // Launches of the pass graph only (kTraceThinFlag), never the counting variant or the ray-batch hooks.
-#ifndef NX_THIN_LANES
-#define NX_THIN_LANES 4
-#endif
-#ifndef NX_THIN_ITERS
-#define NX_THIN_ITERS 64
-#endif
 #ifndef NX_THIN_FACTOR
 #define NX_THIN_FACTOR 4
 #endif
-constexpr int kThinLanes = NX_THIN_LANES, kThinIters = NX_THIN_ITERS, kThinFactor = NX_THIN_FACTOR;
+constexpr int kThinFactor = NX_THIN_FACTOR;  // (the other two numbers of the rule travel in the device state: DeviceState::thinLanes / thinIters)
 #ifdef NX_NO_THIN_CODE
 constexpr bool kThinCode = false;  // (measurement: the kernel without the search's text)
 #else
@@ -255,7 +249,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
     // ... | kTraceThinFlag: the last long rays of a dry wave may be handed to the thin kernel (below)
     bool thinAllowed = !STATS && kThinCode && (bounceArg & kTraceThinFlag) != 0;
-    uint32_t itersTotal = 0u, taken = 0u, thinAfter = (uint32_t)kThinIters;  // (wave-uniform: loop iterations and rays of this wave so far)
+    const int thinLanes = (int)S->thinLanes;
+    const uint32_t thinIters = S->thinIters;
+    uint32_t itersTotal = 0u, taken = 0u, thinAfter = thinIters;  // (wave-uniform: loop iterations and rays of this wave so far)
     const NX_G EntryState* const entryTable = S->entry;
     const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
@@ -410,7 +406,8 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                             exhausted = true;
                             // how long "long" is for this launch: kThinFactor times what a ray of this wave took on average (a wave
                             // iteration advances its busy lanes — about 40 of 64 — by one record each), at least kThinIters
-                            thinAfter = max((uint32_t)kThinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u)));
+                            // (thinIters 0 — a test hook — hands a wave's rays over after their first iteration, dry queue or not)
+                            thinAfter = thinIters ? max(thinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u))) : 0u;
                         }
                         else shard = best;
                         continue;
@@ -627,7 +624,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 rngCur = rngEnd = 0;
             }
 #endif
-            if (!STATS && kThinCode && thinAllowed && exhausted && rngCur >= rngEnd && activeMask != 0ull && __popcll(activeMask) <= kThinLanes && spins >= thinAfter) {
+            if (!STATS && kThinCode && thinAllowed && ((exhausted && rngCur >= rngEnd) || thinIters == 0u) && activeMask != 0ull && __popcll(activeMask) <= thinLanes && spins >= thinAfter) {
                 // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
                 // a wave on each of them; this wave is done
                 NX_G int* const count = &C->thinCount[ANY_HIT ? 1 : 0][bounce];
@@ -711,7 +708,9 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
                 traverse_wave<false>(S, stackLds, lane == 0, org, dir, hitT, hitU, hitV, hitTri, hitInst);
                 hitT = __shfl(hitT, 0); hitU = __shfl(hitU, 0); hitV = __shfl(hitV, 0);
                 hitTri = __shfl(hitTri, 0); hitInst = __shfl(hitInst, 0);
-                if (hitTri != 0xffffffffu) {  // (traverse_wave returns the bare instance: its material code again, as inst_code_kernel writes it)
+                // (traverse_wave returns the bare instance: its material code again, as inst_code_kernel writes it — needed by the SCAN
+                //  pipeline's record only; the ray-batch hooks run without shading records)
+                if (scan && hitTri != 0xffffffffu) {
                     const int type = (int)S->shadeInst[hitInst].material.type;
                     hitInst |= (type >= 0 && type <= 3) ? (uint32_t)(type + 1) << kHitCodeShift : 0u;
                 }

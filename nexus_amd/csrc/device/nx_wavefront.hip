@@ -402,6 +402,7 @@ __global__ void hook_sizes_kernel(DeviceState* __restrict__ S, const uint32_t n,
     NX_G RegionCounters* r = &S->counters->region[k];
     if (anyHit) { r->traceShadowSize[slot] = size; r->shadowHead[slot] = 0; }
     else { r->traceSize[slot] = size; r->traceHead[slot] = 0; }
+    if (k == 0) { S->counters->thinCount[0][slot] = 0; S->counters->thinCount[1][slot] = 0; }  // (the hooks may run with the thin hand-over on: nxhip_debug_set_thin)
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -460,6 +460,8 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         h.settings.backgroundIntensity = 0.0f;
         h.camera.resolution[0] = width;
         h.camera.resolution[1] = height;
+        h.thinLanes = 4u;
+        h.thinIters = 64u;
         h.rngMode = NX_RNG_REFERENCE_SLOT;
         h.compactMode = NX_COMPACT_FAST;
         h.conductorMode = NX_CONDUCTOR_REFERENCE;
@@ -2105,6 +2107,29 @@ int nxhip_set_entry_points(nxhip_ctx* c, int on)
     return NXHIP_OK;
 }
 
+int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHooks)
+{
+    NX_CHECK_CTX(c);
+    if (lanes == 0 || lanes > 64u) return fail_invalid("nxhip_debug_set_thin: lanes must be in [1, 64]");
+    NX_SYNC_ALL(c);
+    c->h.thinLanes = lanes;
+    c->h.thinIters = iters;
+    c->thinInHooks = inHooks != 0;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
+{
+    NX_CHECK_CTX(c);
+    if (!counts) return fail_invalid("nxhip_debug_thin_counts: null destination");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    for (int k = 0; k < 2; k++)
+        NX_HIP(hipMemcpy(&counts[k], &c->counters.as<Counters>()->thinCount[k][kHookBounceSlot], 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
 int nxhip_read_entry_states(nxhip_ctx* c, void* out, uint32_t capacityRuns, uint32_t* count)
 {
     NX_CHECK_CTX(c);
@@ -2423,11 +2448,18 @@ static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
         void* args[4] = {(void*)&S, (void*)&n, (void*)&any, (void*)&slot};
         NX_HIP(hipLaunchKernel(hook_sizes_kernel_ptr(), dim3(1), dim3(64), args, 0, c->stream));
     }
+    const bool thin = c->thinInHooks && !c->statsEnabled;
     Launch l = make_launch(trace_kernel_ptr(anyHit, c->statsEnabled), anyHit ? c->shadowBlocks : c->traceBlocks, kTraceBlockThreads,
-                           anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot);
+                           anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot | (thin ? kTraceThinFlag : 0));
     const size_t before = c->timerPool.size();
-    const int rc = launch_now(c, l);
+    int rc = launch_now(c, l);
     if (rc == NXHIP_OK && c->timerPool.size() > before) c->timerClass.push_back(l.klass);
+    if (rc == NXHIP_OK && thin) {  // (nxhip_debug_set_thin: what the dry waves handed over, a wave each)
+        Launch t = make_launch(thin_kernel_ptr(), 3 * c->numCUs, kTraceBlockThreads, NXHIP_K_THIN, c->dState.as<DeviceState>(), kHookBounceSlot);
+        const size_t before2 = c->timerPool.size();
+        rc = launch_now(c, t);
+        if (rc == NXHIP_OK && c->timerPool.size() > before2) c->timerClass.push_back(t.klass);
+    }
     return rc;
 }
 
