@@ -488,6 +488,14 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 16) { c->traceBlocks = c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
             }
+            if (const char* e = std::getenv("NX_SHADOW_BLOCKS_PER_CU")) {  // tuning experiments only: the any-hit launches' grid alone
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 16) { c->shadowBlocks = n * c->numCUs; c->traceGridForced = true; }
+            }
+            if (const char* e = std::getenv("NX_CLOSEST_BLOCKS_PER_CU")) {  // tuning experiments only: the closest-hit launches' grid alone
+                const int n = std::atoi(e);
+                if (n >= 1 && n <= 16) { c->traceBlocks = n * c->numCUs; c->traceGridForced = true; }
+            }
             if (const char* e = std::getenv("NX_SHADE_BLOCKS_PER_CU")) {  // tuning experiments only
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 64) c->shadeBlocksPerCU = n;
