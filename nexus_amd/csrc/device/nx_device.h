@@ -161,7 +161,7 @@ constexpr int kTraceScanFlag = 0x100;
 // 0 = none): the traversal of a run of 64 consecutive paths starts from the state their first node steps provably share (below)
 constexpr int kTraceEntryFlag = 0x200;
 constexpr int kRayEntryShift = 2;
-// ... | kTraceThinFlag: the launch may finish the last long rays of a dry wave cooperatively (nx_trace.hip thin_wave_bound)
+// ... | kTraceThinFlag: a dry wave of the launch may hand its last long rays to the thin kernel (nx_trace.hip thin_kernel)
 constexpr int kTraceThinFlag = 0x400;
 
 // Entry state of a run of 64 consecutive primary paths (nx_entry.hip).  The 64 rays of an 8 x 8 pixel tile visit the same nodes

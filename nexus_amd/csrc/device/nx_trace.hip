@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         if (bestLeft <= 0) {
                             exhausted = true;
                             // how long "long" is for this launch: kThinFactor times what a ray of this wave took on average (a wave
-                            // iteration advances its busy lanes — about 40 of 64 — by one record each), at least kThinIters
+                            // iteration advances its busy lanes — about 40 of 64 — by one record each), at least thinIters
                             // (thinIters 0 — a test hook — hands a wave's rays over after their first iteration, dry queue or not)
                             thinAfter = thinIters ? max(thinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u))) : 0u;
                         }

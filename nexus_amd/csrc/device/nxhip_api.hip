@@ -191,7 +191,7 @@ static void invalidate_graph(nxhip_ctx* c)
 // may run over it; a queue buffer holds kQueueShards regions.
 static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) / (kQueueShards * 64)) * 64 + kQueueShardSlack; }
 static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
-// entries per list of rays handed to the thin kernel (nx_trace.hip): a launch hands over at most kThinLanes rays per wave, 20 480 for a
+// entries per list of rays handed to the thin kernel (nx_trace.hip): a launch hands over at most DeviceState::thinLanes (4) rays per wave, 20 480 for a
 // full grid; a list that runs over only makes the waves it has no room for finish their rays themselves
 constexpr uint32_t kThinListEntries = 1u << 16;
 static size_t scan_status_tiles(size_t n) { return n / (size_t)std::min(kLogicBlockThreads, kShadeBlockThreads) + 2; }
@@ -1733,7 +1733,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
         levels.back().push_back(l);
     }
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
-    // (every trace launch of a pass may finish the last long rays of its dry waves cooperatively: nx_trace.hip thin_wave_bound)
+    // (the dry waves of a pass's trace launches may hand their last long rays to the thin kernel: nx_trace.hip)
     const int thinFlag = (pass_flavor(c) & kFlavorThin) ? kTraceThinFlag : 0;
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
