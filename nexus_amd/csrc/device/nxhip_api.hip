@@ -1646,7 +1646,9 @@ int trace_blocks(const nxhip_ctx* c, int fullGrid)
     const int R = (int)std::max(1u, effective_slots(c));
     const bool small = pass_size_in_frames(c) <= 8.0;
     int perCU;
-    if (R == 1) perCU = small ? std::min(3, maxPerCU) : maxPerCU;
+    // (round 5, with the thin level taking the drains: 4 per CU for a small single pass — 1 / 2 / 4 / 8 frames per pass 648 / 914 / 1 347 /
+    //  1 740 Msamples/s against 609 / 896 / 1 304 / 1 719 with 3 and 643 / 906 / 1 314 / 1 724 with 5; a rank of 8's share 4.49 against 4.60 ms)
+    if (R == 1) perCU = small ? std::min(4, maxPerCU) : maxPerCU;
     else perCU = ((small ? 2 : 3) * maxPerCU + 2 * R - 1) / (2 * R);
     return std::min(std::max(perCU, 1), maxPerCU) * c->numCUs;
 }
