@@ -163,6 +163,9 @@ constexpr int kTraceEntryFlag = 0x200;
 constexpr int kRayEntryShift = 2;
 // ... | kTraceThinFlag: a dry wave of the launch may hand its last long rays to the thin kernel (nx_trace.hip thin_kernel)
 constexpr int kTraceThinFlag = 0x400;
+// thin_kernel's argument: ... | kThinClosestOnly / kThinAnyOnly = one of the two lists only (the pass graph gives each trace launch of a
+// level its own thin launch, so that the closest-hit rays' searches run beside whatever the any-hit launch still has to do)
+constexpr int kThinClosestOnly = 0x800, kThinAnyOnly = 0x1000;
 
 // Entry state of a run of 64 consecutive primary paths (nx_entry.hip).  The 64 rays of an 8 x 8 pixel tile visit the same nodes
 // with the same hit masks for their first ~4 of ~10 node steps (tools/entry_point_probe.py) — the same arithmetic done 64 times

@@ -675,8 +675,8 @@ template __global__ void trace_kernel<false, true>(const DeviceState*, int);
 template __global__ void trace_kernel<true, false>(const DeviceState*, int);
 template __global__ void trace_kernel<true, true>(const DeviceState*, int);
 
-// The listed rays of one level (closest-hit first, then any-hit), one wave per ray, grid-stride.  `bounceArg` as the trace
-// launches got it: the ray set and the meaning of the closest-hit record follow kTraceScanFlag.
+// The listed rays of one level (closest-hit first, then any-hit; kThinClosestOnly / kThinAnyOnly: one list), one wave per ray,
+// grid-stride.  `bounceArg` as the trace launches got it: the ray set and the meaning of the closest-hit record follow kTraceScanFlag.
 __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __restrict__ S, const int bounceArg)
 {
     __shared__ unsigned long long sPool[(kTraceBlock / kWave) * kPoolSlots];
@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
     const int raySet = scan ? (bounce & 1) : 0;
     NX_G Counters* C = S->counters;
     const int cap = (int)S->thinCapacity;
-    const int nClosest = min(C->thinCount[0][bounce], cap), nAny = min(C->thinCount[1][bounce], cap);
+    const int nClosest = (bounceArg & kThinAnyOnly) ? 0 : min(C->thinCount[0][bounce], cap);
+    const int nAny = (bounceArg & kThinClosestOnly) ? 0 : min(C->thinCount[1][bounce], cap);
     if (nClosest + nAny <= 0) return;
     const bool sceneIdentity = (S->sceneFlags & kSceneAllIdentity) != 0u;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;

@@ -504,6 +504,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 const int n = std::atoi(e);
                 if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
             }
+            if (const char* e = std::getenv("NX_THIN_JOINT")) c->thinJoint = std::atoi(e) != 0;  // measurement only
             if (const char* e = std::getenv("NX_NO_THIN")) c->thinWaves = std::atoi(e) == 0;  // measurement only: no cooperative finish of a dry wave's last rays
             if (const char* e = std::getenv("NX_SCAN_SEPARATE")) c->scanSeparate = std::atoi(e) != 0;  // measurement only: one material launch per type in the SCAN pipeline
             if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
@@ -1574,6 +1575,7 @@ struct Launch {
     int bounce;
     int type;  // nargs 3: (S, bounce, type)
     void* ptr;  // nargs 30: (S, ptr, count)
+    int after;  // -1: depends on the previous level; k: on launch k of ITS OWN level only (a chain inside the level)
     const float4* src;
     uint32_t count, slices, sliceStride, firstFrame;
     const uint32_t* dstMap;
@@ -1590,6 +1592,7 @@ Launch make_launch(const void* fn, int grid, int block, int klass, const DeviceS
     l.s = s;
     l.bounce = bounce;
     l.nargs = bounce >= 0 ? 2 : 1;
+    l.after = -1;
     return l;
 }
 
@@ -1739,9 +1742,22 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int thinFlag = (pass_flavor(c) & kFlavorThin) ? kTraceThinFlag : 0;
     levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
+    // — each trace launch of the level gets its own, chained to it alone, so that the closest-hit rays' searches run beside whatever
+    // the any-hit launch still has to do (it is the longer one of the early levels) and the other way round in the late ones
     const int thinBlocks = 3 * c->numCUs;
     auto thin_level = [&](int bounceArg) {
-        if (thinFlag) levels.push_back({make_launch(thin_kernel_ptr(), thinBlocks, kTraceBlockThreads, NXHIP_K_THIN, S, bounceArg)});
+        if (!thinFlag) return;
+        if (c->thinJoint) {  // (NX_THIN_JOINT, measurement only: one launch for both lists behind the whole level)
+            levels.push_back({make_launch(thin_kernel_ptr(), thinBlocks, kTraceBlockThreads, NXHIP_K_THIN, S, bounceArg)});
+            return;
+        }
+        std::vector<Launch>& level = levels.back();
+        const int n = (int)level.size();  // 1: the primary level (closest-hit only); 2: closest-hit, any-hit
+        for (int k = 0; k < n; k++) {
+            Launch t = make_launch(thin_kernel_ptr(), thinBlocks, kTraceBlockThreads, NXHIP_K_THIN, S, bounceArg | (k == 0 ? kThinClosestOnly : kThinAnyOnly));
+            t.after = k;
+            level.push_back(t);
+        }
     };
     const int pathLength = c->h.settings.pathLength;
     // (grids of the producer kernels stay multiples of the queue regions: harmless, and what a round-robin tile-to-region mapping
@@ -1894,7 +1910,13 @@ static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
     std::vector<hipGraphNode_t> prev;
     for (auto& level : levels) {
         std::vector<hipGraphNode_t> cur;
+        std::vector<hipGraphNode_t> done;  // per launch of this level: the node its dependents wait for
+        std::vector<bool> hasFollower(level.size(), false);
+        for (auto& l : level)
+            if (l.after >= 0) hasFollower[(size_t)l.after] = true;
         for (auto& l : level) {
+            // what this launch waits for: the previous level, or one launch of its own level (Launch::after)
+            std::vector<hipGraphNode_t> deps = l.after >= 0 ? std::vector<hipGraphNode_t>{done[(size_t)l.after]} : prev;
             void* args[8];
             fill_args(l, args);
             hipKernelNodeParams p;
@@ -1912,15 +1934,17 @@ static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
                 c->graphTimerClass.push_back(l.klass);
                 if (!hip_ok(hipEventCreate(&t.start), "hipEventCreate", __FILE__, __LINE__) || !hip_ok(hipEventCreate(&t.stop), "hipEventCreate", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
                 hipGraphNode_t before, after;
-                if (!hip_ok(hipGraphAddEventRecordNode(&before, inst.graph, prev.empty() ? nullptr : prev.data(), prev.size(), t.start), "hipGraphAddEventRecordNode", __FILE__, __LINE__) ||
+                if (!hip_ok(hipGraphAddEventRecordNode(&before, inst.graph, deps.empty() ? nullptr : deps.data(), deps.size(), t.start), "hipGraphAddEventRecordNode", __FILE__, __LINE__) ||
                     !hip_ok(hipGraphAddKernelNode(&node, inst.graph, &before, 1, &p), "hipGraphAddKernelNode", __FILE__, __LINE__) ||
                     !hip_ok(hipGraphAddEventRecordNode(&after, inst.graph, &node, 1, t.stop), "hipGraphAddEventRecordNode", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
-                cur.push_back(after);
+                done.push_back(after);
             } else {
-                if (!hip_ok(hipGraphAddKernelNode(&node, inst.graph, prev.empty() ? nullptr : prev.data(), prev.size(), &p), "hipGraphAddKernelNode", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
-                cur.push_back(node);
+                if (!hip_ok(hipGraphAddKernelNode(&node, inst.graph, deps.empty() ? nullptr : deps.data(), deps.size(), &p), "hipGraphAddKernelNode", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
+                done.push_back(node);
             }
         }
+        for (size_t i = 0; i < level.size(); i++)  // the next level waits for the ends of this level's chains
+            if (!hasFollower[i]) cur.push_back(done[i]);
         prev.swap(cur);
     }
     if (!hip_ok(hipGraphInstantiate(&inst.exec, inst.graph, nullptr, nullptr, 0), "hipGraphInstantiate", __FILE__, __LINE__)) return fail(NXHIP_ERR_HIP);
