@@ -44,6 +44,9 @@ public:
     void SetFramesPerPass(uint32_t frames);
     void SetPassesInFlight(uint32_t passes);
     void SetTailBounce(uint32_t bounce);
+    // Primary rays start from the traversal state the first node steps of their run of 64 paths provably share instead of the TLAS
+    // root (nxhip_set_entry_points: hit records unchanged, pinhole cameras only).  Off by default.
+    void SetEntryPoints(bool on);
     // Multi-GPU extension (no counterpart in the reference): one PathTracer per GPU, each renders and
     // accumulates the interleaved row tiles of its rank; Render() then ends with ONE RCCL gather of the accumulated tiles to
     // rank 0, whose GetPixelBuffer() returns the full frame.  `id128`: the 128 bytes rank 0 obtained from
