@@ -13,13 +13,14 @@
  * Rules of this text (what makes it bit-reproducible across gcc / x86-64 and hipcc / gfx950):
  *   - only + - * / sqrt, fma, rint, floor, fabs, comparisons, conversions and bit casts — each correctly rounded and therefore
  *     uniquely defined by IEEE 754; no libm call, no table;
- *   - every function evaluates in binary64 and rounds ONCE to binary32 where it returns a float, so the float functions are
- *     within 0.5 ulp + 1e-7 of the true value (tests/test_fmath.py measures it against a 50-digit reference); the double ones
- *     within a few ulp of binary64;
+ *   - the double functions (sin / cos of RandomCosineHemisphere, pow of LinearToGamma) are within a few ulp of binary64; the
+ *     float functions (second half of this file, round 5) are binary32 arithmetic within 2 ulp of the true value over every
+ *     binary32 argument — what CUDA's own sinf / cosf / expf / atan2f / asinf promise the reference (tests/test_fmath.py
+ *     measures both against a 50-digit reference, tools/fmath_exhaustive.c the float ones exhaustively);
  *   - both translation units are compiled with floating-point contraction off (Makefile, oracle/Makefile): an fma happens where
  *     nxf_fma is written and nowhere else;
- *   - series in nested form with small exact divisors — no magic coefficient tables to transcribe.
- * Cost is irrelevant where they are called: the material kernels wait on memory.
+ *   - the double functions: series in nested form with small exact divisors; the float functions: minimax polynomials whose
+ *     coefficients tools/fmath_coeffs.py derives — no table transcribed from anywhere.
  *
  * Domain notes: the trigonometric reduction is two-term Cody-Waite, exact to ~1e-16 * |x| (the path's arguments lie in
  * [-2 pi, 2 pi]); beyond 2^30 the result is still the same on both sides, and within [-1, 1], but no longer accurate.
@@ -125,8 +126,6 @@ NXF_FN void nxf_sincos(double x, double *s, double *c)
 }
 NXF_FN double nxf_sin(double x) { double s, c; nxf_sincos(x, &s, &c); return s; }
 NXF_FN double nxf_cos(double x) { double s, c; nxf_sincos(x, &s, &c); return c; }
-NXF_FN float nxf_sinf(float x) { return (float)nxf_sin((double)x); }
-NXF_FN float nxf_cosf(float x) { return (float)nxf_cos((double)x); }
 
 /* ---- exp / log / pow ------------------------------------------------------------------------------------------------- */
 
@@ -160,7 +159,6 @@ NXF_FN double nxf_exp(double x)
     const int k1 = ki / 2, k2 = ki - k1;
     return (t * nxf_pow2i(k1)) * nxf_pow2i(k2);
 }
-NXF_FN float nxf_expf(float x) { return (float)nxf_exp((double)x); }
 
 /* ln x in double.  x = m 2^e with m in [sqrt(1/2), sqrt 2); ln m = 2 atanh s = 2 s (1 + z/3 + z^2/5 + ...), s = (m-1)/(m+1),
  * z = s^2 <= 0.0295, through z^11 / 23 (first dropped term 1e-20 relative). */
@@ -192,7 +190,6 @@ NXF_FN double nxf_log(double x)
     const double de = (double)e;
     return de * NXF_LN2_HI + (lnm + de * NXF_LN2_LO);
 }
-NXF_FN float nxf_logf(float x) { return (float)nxf_log((double)x); }
 
 /* x^y for the cases the path has (a base >= 0, any finite exponent) as exp(y ln x); about 1e-14 relative for |y ln x| < 100 —
  * the callers round the result to float (LinearToGamma, Utils/Utils.h:51-54).  A negative base gives NaN (no integer-exponent
@@ -256,7 +253,6 @@ NXF_FN double nxf_atan2(double y, double x)
     if (nxf_signbit(x)) r = NXF_PI - r;
     return nxf_copysign(r, y);
 }
-NXF_FN float nxf_atan2f(float y, float x) { return (float)nxf_atan2((double)y, (double)x); }
 
 /* asin x = atan2(x, sqrt((1 - x)(1 + x))); NaN outside [-1, 1] */
 NXF_FN double nxf_asin(double x)
@@ -264,7 +260,161 @@ NXF_FN double nxf_asin(double x)
     if (nxf_isnan(x) || nxf_abs(x) > 1.0) return nxf_nan();
     return nxf_atan2(x, nxf_sqrt((1.0 - x) * (1.0 + x)));
 }
-NXF_FN float nxf_asinf(float x) { return (float)nxf_asin((double)x); }
+
+/* ---- the binary32 functions: sinf cosf expf logf atan2f asinf ---------------------------------------------------------- */
+
+/* The reference calls these as float functions (Microfacet.cuh:18, 75; PathTracer.cu:65-83), whose CUDA implementations are good
+ * to 1-3 ulp.  Until round 5 this text evaluated them through the binary64 series above and rounded once (0.5 ulp, at the price
+ * of 20-term series and two divisions in binary64 per call: 3 % of configs[3], whose every miss and light sample looks the
+ * environment up).  Now: binary32 arithmetic throughout — a reduction, one minimax polynomial of the series remainder evaluated with
+ * fmaf, at most one division or square root — each within 2 ulp over EVERY binary32 argument of its domain
+ * (tools/fmath_exhaustive.c: sinf / cosf 1.53 ulp for |x| <= 1e5, expf 1.01, logf 0.84, asinf 1.89, atan2f 1.53).  The coefficients are fitted, not transcribed:
+ * tools/fmath_coeffs.py prints them.  The only binary64 left is the trigonometric reduction (four operations), because a float
+ * pi / 2 in three pieces loses the small remainders near multiples of pi / 2.  Same rule as above for reproducibility: only
+ * correctly rounded IEEE operations, fmaf where written and nowhere else. */
+NXF_FN float nxf_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+NXF_FN float nxf_absf(float x) { return __builtin_fabsf(x); }
+NXF_FN float nxf_nanf(void) { return nxf_from_bitsf(0x7fc00000u); }
+NXF_FN float nxf_inff(void) { return nxf_from_bitsf(0x7f800000u); }
+NXF_FN float nxf_copysignf(float mag, float sgn) { return nxf_from_bitsf((nxf_bitsf(mag) & 0x7fffffffu) | (nxf_bitsf(sgn) & 0x80000000u)); }
+#define NXF_PIO2_HI_F 1.57079637f      /* the binary32 nearest to pi / 2 */
+#define NXF_PIO2_LO_F -4.37113883e-08f /* pi / 2 - NXF_PIO2_HI_F */
+#define NXF_PI_HI_F 3.14159274f
+#define NXF_PI_LO_F -8.74227766e-08f
+#define NXF_PIO4_F 0.785398185f
+#define NXF_LN2_HI_F 0.693115234f      /* ln 2 with the low 12 bits of the significand cleared: k * hi is exact for |k| < 2^12 */
+#define NXF_LN2_LO_F 3.19461833e-05f   /* ln 2 - NXF_LN2_HI_F */
+#define NXF_LOG2E_F 1.44269502f
+
+/* sin x and cos x.  x = k pi/2 + r in binary64 (nxf_reduce_pio2: exact to 1e-16 |x|), r rounded once to binary32, |r| <= pi/4;
+ *   sin r = r + r z (S0 + S1 z + S2 z^2),   cos r = 1 - z/2 + z^2 (C0 + C1 z + C2 z^2),   z = r^2
+ * (fit errors 3.8e-9 / 1.2e-10 relative); 1 - z/2 is rounded to w and what the rounding dropped, (1 - w) - z/2 — exact —, is
+ * added back with the polynomial. */
+NXF_FN void nxf_sincosf(float x, float *s, float *c)
+{
+    if (x != x || nxf_absf(x) == nxf_inff()) { *s = nxf_nanf(); *c = nxf_nanf(); return; }
+    if (x == 0.0f) { *s = x; *c = 1.0f; return; }  /* sin(-0) = -0 */
+    int q;
+    const float r = (float)nxf_reduce_pio2((double)x, &q);
+    const float z = r * r;
+    float ps = nxf_fmaf(z, -0.000195152184f, 0.0083321603f);
+    ps = nxf_fmaf(z, ps, -0.166666552f);
+    const float sr = nxf_fmaf(r * z, ps, r);
+    float pc = nxf_fmaf(z, 2.44330822e-05f, -0.00138873153f);
+    pc = nxf_fmaf(z, pc, 0.0416666456f);
+    const float hz = 0.5f * z, w = 1.0f - hz;
+    const float cr = w + (((1.0f - w) - hz) + (z * z) * pc);
+    *s = (q & 1) ? cr : sr;
+    *c = (q & 1) ? sr : cr;
+    if (q & 2) *s = -*s;
+    if ((q + 1) & 2) *c = -*c;
+}
+NXF_FN float nxf_sinf(float x) { float s, c; nxf_sincosf(x, &s, &c); return s; }
+NXF_FN float nxf_cosf(float x) { float s, c; nxf_sincosf(x, &s, &c); return c; }
+
+/* e^x.  x = k ln 2 + r, |r| <= ln 2 / 2 (k * NXF_LN2_HI_F is exact); e^r = 1 + (r + r^2 (E0 + ... + E4 r^4)) (fit error 3.1e-9);
+ * scaled by 2^k in two exact-or-final steps, so that a subnormal result is rounded once. */
+NXF_FN float nxf_pow2if(int k) { return nxf_from_bitsf((uint32_t)(k + 127) << 23); } /* 2^k, k in [-126, 127] */
+NXF_FN float nxf_expf(float x)
+{
+    if (x != x) return nxf_nanf();
+    if (x > 89.0f) return nxf_inff();  /* (e^88.73 already overflows: the last multiplication below says so) */
+    if (x < -104.0f) return 0.0f;      /* below 2^-150: rounds to zero */
+    const float k = __builtin_rintf(x * NXF_LOG2E_F);
+    float r = nxf_fmaf(-k, NXF_LN2_HI_F, x);
+    r = nxf_fmaf(-k, NXF_LN2_LO_F, r);
+    float p = nxf_fmaf(r, 0.00138145988f, 0.00836871658f);
+    p = nxf_fmaf(r, p, 0.041668389f);
+    p = nxf_fmaf(r, p, 0.166665211f);
+    p = nxf_fmaf(r, p, 0.49999994f);
+    const float t = 1.0f + nxf_fmaf(r * r, p, r);
+    const int ki = (int)k;  /* |k| <= 150 */
+    const int k1 = ki / 2, k2 = ki - k1;
+    return (t * nxf_pow2if(k1)) * nxf_pow2if(k2);
+}
+
+/* ln x.  x = m 2^e, m in [sqrt(1/2), sqrt 2), f = m - 1; ln m = 2 atanh s = 2 s + 2 s z (L0 + L1 z + L2 z^2), s = f / (2 + f),
+ * z = s^2 (fit error 8e-10); e * NXF_LN2_HI_F is exact. */
+NXF_FN float nxf_logf(float x)
+{
+    if (x != x || x < 0.0f) return nxf_nanf();
+    if (x == 0.0f) return -nxf_inff();
+    if (x == nxf_inff()) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x *= 8388608.0f; e = -23; }  /* subnormal: scaled by 2^23 */
+    const uint32_t b = nxf_bitsf(x);
+    e += (int)(b >> 23) - 127;
+    float m = nxf_from_bitsf((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m *= 0.5f; e += 1; }
+    const float f = m - 1.0f;  /* exact */
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = nxf_fmaf(z, 0.149356037f, 0.199887827f);
+    p = nxf_fmaf(z, p, 0.33333388f);
+    /* 2 s = f - s f and s f = f^2/2 - s f^2/2, so ln m = f - (f^2/2 - s (f^2/2 + 2 z P)): the leading term is f itself, exact, and
+     * the rounding of s only touches the small terms */
+    const float hfsq = 0.5f * f * f;
+    const float fe = (float)e;
+    return fe * NXF_LN2_HI_F - ((hfsq - nxf_fmaf(s, hfsq + (z + z) * p, fe * NXF_LN2_LO_F)) - f);
+}
+
+/* atan a for a in [0, 1]: a + a z (A0 + ... + A8 z^8), z = a^2 (fit error 2.6e-9) */
+NXF_FN float nxf_atan01f(float a)
+{
+    const float z = a * a;
+    float p = nxf_fmaf(z, -0.00179362029f, 0.0109145995f);
+    p = nxf_fmaf(z, p, -0.0311778337f);
+    p = nxf_fmaf(z, p, 0.0579575822f);
+    p = nxf_fmaf(z, p, -0.0840344951f);
+    p = nxf_fmaf(z, p, 0.109521858f);
+    p = nxf_fmaf(z, p, -0.142642424f);
+    p = nxf_fmaf(z, p, 0.199985489f);
+    p = nxf_fmaf(z, p, -0.333332986f);
+    return nxf_fmaf(a * z, p, a);
+}
+
+/* atan2(y, x): ONE division, with the C standard's (Annex F.10.1.4) results for zeros and infinities */
+NXF_FN float nxf_atan2f(float y, float x)
+{
+    if (x != x || y != y) return nxf_nanf();
+    const float ax = nxf_absf(x), ay = nxf_absf(y), inf = nxf_inff();
+    float r;
+    if (ay == 0.0f) r = 0.0f;                                       /* +-0 or +-pi */
+    else if (ax == 0.0f) r = NXF_PIO2_HI_F;
+    else if (ax == inf && ay == inf) r = NXF_PIO4_F;
+    else if (ax == inf) r = 0.0f;
+    else if (ay == inf) r = NXF_PIO2_HI_F;
+    else if (ay <= ax) r = nxf_atan01f(ay / ax);
+    else r = (NXF_PIO2_HI_F - nxf_atan01f(ax / ay)) + NXF_PIO2_LO_F;
+    if (nxf_bitsf(x) >> 31) r = (NXF_PI_HI_F - r) + NXF_PI_LO_F;
+    return nxf_copysignf(r, y);
+}
+
+/* asin x.  |x| <= 1/2: x + x z (R0 + ... + R4 z^4), z = x^2 (fit error 4.9e-9); above: pi/2 - 2 asin(sqrt((1 - |x|) / 2)), one
+ * square root; NaN outside [-1, 1] */
+NXF_FN float nxf_asin_poly(float z)
+{
+    float p = nxf_fmaf(z, 0.0421663076f, 0.0241795164f);
+    p = nxf_fmaf(z, p, 0.0454703756f);
+    p = nxf_fmaf(z, p, 0.0749529749f);
+    return nxf_fmaf(z, p, 0.166667521f);
+}
+NXF_FN float nxf_asinf(float x)
+{
+    if (x != x || nxf_absf(x) > 1.0f) return nxf_nanf();
+    const float ax = nxf_absf(x);
+    float r;
+    if (ax <= 0.5f) {
+        const float z = ax * ax;
+        r = nxf_fmaf(ax * z, nxf_asin_poly(z), ax);
+    } else {
+        const float z = (1.0f - ax) * 0.5f;  /* exact */
+        const float s = __builtin_sqrtf(z);
+        const float t = nxf_fmaf(s * z, nxf_asin_poly(z), s);
+        r = (NXF_PIO2_HI_F - (t + t)) + NXF_PIO2_LO_F;
+    }
+    return nxf_copysignf(r, x);
+}
 
 /* ---- batch entry for the tests (oracle: orc_fmath_batch; device: nxhip_fmath_batch) ------------------------------------ */
 

@@ -2,8 +2,8 @@
 oracle (replacing libm's sin / cos / expf / logf / sinf / cosf / atan2f / asinf / pow at
 /root/reference/Nexus/src/Cuda/Random.cuh:119-121, Cuda/BSDF/Microfacet.cuh:18,75, Cuda/PathTracer/PathTracer.cu:65-83, Utils/Utils.h:51-54).
 
-CPU: the oracle's build of the text against a 50-digit reference (mpmath) — float functions within 0.5001 ulp, double ones within
-4 ulp — and the IEEE / C Annex F special cases.  GPU: the device's build gives the same bits as the oracle's on a million arguments
+CPU: the oracle's build of the text against a 50-digit reference (mpmath) — float functions (binary32 arithmetic since round 5;
+exhaustively measured by tools/fmath_exhaustive.c) within 2 ulp, double ones within 4 ulp — and the IEEE / C Annex F special cases.  GPU: the device's build gives the same bits as the oracle's on a million arguments
 per function, specials included: what makes frames comparable with np.array_equal."""
 import numpy as np
 import pytest
@@ -79,7 +79,7 @@ def test_the_shared_functions_against_a_50_digit_reference(name):
         worst = max(worst, float(abs(mp.mpf(float(got[i])) - r) / ulp))
     # sin / cos of arguments up to 1e5: the two-term reduction leaves ~1e-16 * |x| of absolute error; pow = exp(y ln x) carries
     # the rounding of y ln x, i.e. about |y ln x| ulp (the one caller, LinearToGamma, rounds the result to float)
-    bound = 0.5001 if is_float else {"sin": 64.0, "cos": 64.0, "pow": 32.0}.get(name, 4.0)
+    bound = 2.0 if is_float else {"sin": 64.0, "cos": 64.0, "pow": 32.0}.get(name, 4.0)
     print("%s: worst error %.4f ulp over %d arguments" % (name, worst, len(a)))
     assert worst <= bound
 
