@@ -78,7 +78,14 @@ constexpr bool kThinCode = false;  // (measurement: the kernel without the searc
 #else
 constexpr bool kThinCode = true;
 #endif
-constexpr int kPoolSlots = 1024;  // work items per wave of the thin kernel (8 KiB of LDS)
+#ifndef NX_THIN_FRAME_CACHE
+#define NX_THIN_FRAME_CACHE 1
+#endif
+#ifndef NX_POOL_SLOTS
+#define NX_POOL_SLOTS 1024
+#endif
+constexpr int kPoolSlots = NX_POOL_SLOTS;  // work items per wave of the thin kernel (8 KiB of LDS + 4 KiB of gates; most rays stay below 150, one in a few hundred passes 450)
+constexpr int kPoolLimit = kPoolSlots - kWave;
 constexpr uint32_t kItemNode = 0u, kItemInst = 1u, kItemTri = 2u;  // item.y = kind << 30 | frame (instance record + 1, 0 = TLAS); item.x = index
 
 struct ThinResult {
@@ -87,14 +94,17 @@ struct ThinResult {
     int count;        // closest hit: 1 = a closest triangle was found (t, u, v, tri, inst), 0 = none; any hit: 1 = occluded
     float second;     // closest hit: the second smallest distance seen (3e38: none)
     float window;     // ... and how far above t a second one makes the result depend on the visiting order
+    float gate;       // closest hit: the largest computed entry distance of the boxes on the found triangle's path from the root (see thin_wave_search)
     bool complete;    // the whole tree was searched
+    uint32_t rounds;  // rounds of the search
+    int poolMax;      // most items the pool held
 };
 
 // Searches ray (o, d) with the whole wave.  `bound`: closest hit — the ray's current hit distance (triangles at t <= bound count);
 // any hit — its tmax (a triangle at 0 < t < bound occludes).  `pool`: kPoolSlots LDS entries of the wave's own.
 // Everything in the result is wave-uniform.
 template <bool ANY_HIT>
-NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* const pool, const f3 o, const f3 d, const float bound, const bool sceneIdentity)
+NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* const pool, lds_f32* const poolGate, const f3 o, const f3 d, const float bound, const bool sceneIdentity)
 {
     GU4 tlasNodes = S->tlasNodes;
     const NX_G InstTrav* instTrav = S->instTrav;
@@ -106,26 +116,43 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
     r.t = bound; r.u = 0.0f; r.v = 0.0f; r.tri = 0xffffffffu; r.inst = 0xffffffffu; r.count = 0; r.second = 3.0e38f; r.complete = true;
     const float magnitude = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.window = ANY_HIT ? 0.0f : 1.0e-3f * (fminf(bound, 1.0e30f) + magnitude);
+    r.rounds = 0u; r.poolMax = 1; r.gate = 0.0f;
     int n = 1;  // items in the pool (uniform)
-    if (lane == 0) pool[0] = (unsigned long long)kItemNode << 62;  // the TLAS root
+    if (lane == 0) { pool[0] = (unsigned long long)kItemNode << 62; if (!ANY_HIT) poolGate[0] = 0.0f; }  // the TLAS root
+    // the frame the wave derived last (see below; uniform): 0 = none yet
+    uint32_t cFrame = 0u, cInst = 0u;
+    GU4 cNodes = tlasNodes;
+    GF4 cIsect = nullptr;
+    f3 cO = o, cD = d, cI = idirW;
     uint32_t rounds = 0u;
+    bool careful = false;
     while (n > 0) {
         if (++rounds > (1u << 16)) { r.complete = false; break; }  // (a tree that is not a tree: the ordinary loop's stall guard deals with it)
-        const int take = min(n, kWave);
+        // (after a round whose children did not all fit — below — only as many items as can expand whatever they hold: 24 each)
+        const int take = careful ? min(min(n, kWave), max(1, (kPoolLimit - n) / 24)) : min(n, kWave);
         const bool have = lane < take;
         const int at = n - 1 - lane;
         const unsigned long long item = have ? pool[at] : 0ull;
+        const float itemGate = (!ANY_HIT && have) ? poolGate[at] : 0.0f;  // (closest hit: see the push below)
         n -= take;
         const uint32_t idx = (uint32_t)item, tag = (uint32_t)(item >> 32);
         const uint32_t kind = tag >> 30;
         uint32_t frame = tag & 0x3fffffffu;  // instance record + 1 whose frame the item lives in
         if (have && kind == kItemInst) frame = idx + 1u;
-        // the ray in the item's frame (BVH8Traversal.cuh:259-264, as enter_instance computes it)
+        // the ray in the item's frame (BVH8Traversal.cuh:259-264, as enter_instance computes it).  It is ONE ray, and nearly all items
+        // of a round live in one instance: the wave remembers the last frame it derived — BLAS arrays, instance word, the ray in that
+        // frame and its reciprocal direction, all wave-uniform — and an item of that frame takes them from there instead of fetching
+        // the instance record first (a dependent round trip in front of the record fetch of EVERY round) and transforming the ray
+        // again (same values: a function of the record and the ray alone).
         f3 ro = o, rd = d, ri = idirW;
         GU4 nodes = tlasNodes;
         GF4 isect = nullptr;
         uint32_t instIdx = 0u;
-        if (have && frame != 0u) {
+        const bool inFrame = have && frame != 0u;
+        const bool known = NX_THIN_FRAME_CACHE && inFrame && frame == cFrame;  // (NX_THIN_FRAME_CACHE=0: measurement, every item derives its frame)
+        if (known) { nodes = cNodes; isect = cIsect; instIdx = cInst; ro = cO; rd = cD; ri = cI; }
+        const bool derive = inFrame && !known;
+        if (derive) {
             const unsigned long long recAddr = (unsigned long long)&instTrav[frame - 1u];
             InstFetch fi;
             fetch_instance(recAddr, sceneIdentity, fi);
@@ -139,6 +166,20 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
                 ri = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
             }
         }
+        const unsigned long long deriveMask = __ballot(derive);
+        if (deriveMask != 0ull) {  // remember the first such lane's frame
+            const int src = __ffsll((long long)deriveMask) - 1;
+            const auto bcast = [&](const uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+            const auto bcastf = [&](const float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); };
+            cFrame = bcast(frame);
+            const unsigned long long nb = (unsigned long long)nodes, ib = (unsigned long long)isect;
+            cNodes = (GU4)(((unsigned long long)bcast((uint32_t)(nb >> 32)) << 32) | bcast((uint32_t)nb));
+            cIsect = (GF4)(((unsigned long long)bcast((uint32_t)(ib >> 32)) << 32) | bcast((uint32_t)ib));
+            cInst = bcast(instIdx);
+            cO = mk3(bcastf(ro.x), bcastf(ro.y), bcastf(ro.z));
+            cD = mk3(bcastf(rd.x), bcastf(rd.y), bcastf(rd.z));
+            cI = mk3(bcastf(ri.x), bcastf(ri.y), bcastf(ri.z));
+        }
         unsigned long long recAddr = 0ull;
         if (have) {
             if (kind == kItemNode) recAddr = (unsigned long long)(nodes + (size_t)idx * (unsigned)kNodeStride);
@@ -151,7 +192,13 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
         uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
         float ct = 3.0e38f, cu = 0.0f, cv = 0.0f;  // this lane's candidate of the round
         bool cand = false;
-        if (isNode) child_trace(rc, ro, rd, ri, invOct4, r.t + r.window, ng, tg);
+        // closest hit: the children one by one with their computed entry distances (child_trace_gate); any hit: the loop's two masks
+        uint32_t entered = 0u;
+        float tminC[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (isNode) {
+            if constexpr (ANY_HIT) child_trace(rc, ro, rd, ri, invOct4, r.t + r.window, ng, tg);
+            else child_trace_gate(rc, ro, rd, ri, r.t + r.window, entered, tminC);
+        }
         if (isTri) {
             const f3 p0 = mk3(__uint_as_float(rc[0].x), __uint_as_float(rc[0].y), __uint_as_float(rc[0].z));
             const f3 edge0 = mk3(__uint_as_float(rc[1].x), __uint_as_float(rc[1].y), __uint_as_float(rc[1].z));
@@ -171,15 +218,70 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
         // the children the ray enters go back into the pool
         const bool inTlas = isNode && kind == kItemNode && frame == 0u;
         int mine = isNode ? __popc(ng.y & 0xff000000u) + __popc(tg.y) : 0;
+        if constexpr (!ANY_HIT) {
+            // a child's items: one for an inner node, one per primitive of a leaf (the unary count above bit 5 of its meta byte)
+            mine = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t meta = ((c < 4 ? rc[1].z : rc[1].w) >> (8 * (c & 3))) & 0xffu;
+                mine += ((entered >> c) & 1u) ? __popc(meta >> 5) : 0;
+            }
+        }
         int incl = mine;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const int up = __shfl_up(incl, off);
             if (lane >= off) incl += up;
         }
-        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
-        if (n + total > kPoolSlots) { r.complete = false; mine = 0; }
-        if (mine) {
+        int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        // A round whose children do not all fit: the lanes up to the last one that fits push theirs, the others put their OWN item
+        // back (one slot each, on top of those: the 64 slots above kPoolLimit are kept for that) and the search goes on more
+        // carefully.  Only when not even one item can be expanded is the ray given to the in-order replay.
+        const bool fits = n + incl <= kPoolLimit;  // (a prefix of the lanes: incl never decreases)
+        const bool putBack = mine > 0 && !fits;
+        const unsigned long long backMask = __ballot(putBack);
+        if (backMask != 0ull) {
+            const int fitting = (int)__popcll(__ballot(fits));
+            total = fitting > 0 ? __builtin_amdgcn_readlane(incl, fitting - 1) : 0;
+            if (putBack) {
+                const int at2 = n + total + (int)__popcll(backMask & ((1ull << lane) - 1ull));
+                pool[at2] = item;
+                if (!ANY_HIT) poolGate[at2] = itemGate;
+                mine = 0;
+            }
+            total += (int)__popcll(backMask);
+            if (careful && take == 1) r.complete = false;  // (a single item that cannot expand into a pool this full)
+            careful = true;
+        }
+        if (!ANY_HIT && mine) {
+            // Closest hit: every item carries its GATE — the largest computed entry distance (child_trace's tmin, the number its hit test
+            // compares with the ray's current hit distance) among the boxes on its path from the root.  What it is for: see the end
+            // of thin_kernel's closest-hit branch.
+            int w = n + incl - mine;
+            const uint32_t imask = rc[0].w >> 24, baseChild = rc[1].x, basePrim = rc[1].y;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (((entered >> c) & 1u) == 0u) continue;
+                const uint32_t meta = ((c < 4 ? rc[1].z : rc[1].w) >> (8 * (c & 3))) & 0xffu;
+                const float g = fmaxf(itemGate, tminC[c]);
+                if ((meta & (meta << 1)) & 0x10u) {  // an inner node (child_trace: isInner4); its slot among the node's inner children
+                    const uint32_t rel = (uint32_t)__popc(imask & ~(0xffffffffu << (meta & 7u)));
+                    pool[w] = ((unsigned long long)((kItemNode << 30) | frame) << 32) | (unsigned long long)(baseChild + rel);
+                    poolGate[w] = g;
+                    w++;
+                } else {
+                    const uint32_t leafTag = inTlas ? (kItemInst << 30) : ((kItemTri << 30) | frame);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        if (((meta >> (5 + k)) & 1u) == 0u) continue;
+                        pool[w] = ((unsigned long long)leafTag << 32) | (unsigned long long)(basePrim + (meta & 0x1fu) + (uint32_t)k);
+                        poolGate[w] = g;
+                        w++;
+                    }
+                }
+            }
+        }
+        if (ANY_HIT && mine) {
             int w = n + incl - mine;
             uint32_t inner = ng.y;
             while (inner & 0xff000000u) {
@@ -200,6 +302,7 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
             }
         }
         if (r.complete) n += total;
+        r.poolMax = max(r.poolMax, n);
         // the round's closest candidate
         const unsigned long long anyCand = __ballot(cand);
         if (anyCand != 0ull) {
@@ -220,6 +323,7 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
                 r.v = __shfl(cv, winner);
                 r.tri = __shfl(rc[0].w, winner);
                 r.inst = __shfl(instIdx, winner);
+                r.gate = __shfl(itemGate, winner);
                 r.count = 1;
                 r.window = 1.0e-3f * (m + magnitude);
             } else {
@@ -228,6 +332,7 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
         }
         if (!r.complete) break;
     }
+    r.rounds = rounds;
     return r;
 }
 
@@ -680,7 +785,7 @@ template __global__ void trace_kernel<true, true>(const DeviceState*, int);
 __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __restrict__ S, const int bounceArg)
 {
     __shared__ unsigned long long sPool[(kTraceBlock / kWave) * kPoolSlots];
-    __shared__ unsigned long long sStack[kLdsDepth * kTraceBlock];  // (for the rare in-order traversal: traverse_wave)
+    __shared__ float sGate[(kTraceBlock / kWave) * kPoolSlots];
     const int bounce = bounceArg & 0xff;
     const bool scan = (bounceArg & kTraceScanFlag) != 0;
     const int raySet = scan ? (bounce & 1) : 0;
@@ -692,7 +797,10 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
     const bool sceneIdentity = (S->sceneFlags & kSceneAllIdentity) != 0u;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     lds_u64* const pool = (lds_u64*)&sPool[wave * kPoolSlots];
-    lds_u64* const stackLds = (lds_u64*)&sStack[threadIdx.x];
+    lds_f32* const poolGate = (lds_f32*)&sGate[wave * kPoolSlots];
+    // (the rare in-order replay, traverse_wave, keeps its stack in the wave's pool, which the finished search has left: 8 entries x 64 lanes)
+    static_assert(kLdsDepth * kWave <= kPoolSlots, "the replay's stack fits the pool");
+    lds_u64* const stackLds = pool + lane;
     const int waves = (int)gridDim.x * (kTraceBlock / kWave);
     for (int e = (int)blockIdx.x * (kTraceBlock / kWave) + wave; e < nClosest + nAny; e += waves) {
         if (e < nClosest) {
@@ -700,13 +808,31 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
             const uint32_t slot = word & 0x7fffffffu;
             const float4 o = S->trace.rays[raySet].rayO[slot], d = S->trace.rays[raySet].rayD[slot];
             const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
-            ThinResult r = thin_wave_search<false>(S, pool, org, dir, 1e30f, sceneIdentity);
-            const bool ambiguous = r.count != 0 && r.second <= r.t + r.window;
+            ThinResult r = thin_wave_search<false>(S, pool, poolGate, org, dir, 1e30f, sceneIdentity);
+            // Is the closest triangle found (computed distance t, the smallest of all the ray's triangles) what the reference's order
+            // returns?  It is, if that order TESTS it: nothing tested can replace it (acceptance is `t < hit distance`, strictly,
+            // on computed numbers — equal distances: the first met wins, so a second triangle at exactly t is left to the replay
+            // below).  It is tested iff no box on its path is culled, and a box is culled when its parent is decoded and its computed
+            // entry distance exceeds the hit distance of that moment — which is the distance of some triangle accepted earlier,
+            // all of them > t.  With the gate — the largest computed entry distance on the path, the kernel's own numbers — at or
+            // below t, no such moment exists: whatever was accepted before, every box on the path passes.  A gate above t — the ray
+            // meets the triangle in front of where it enters a box around it, by rounding: a triangle IN a face of its box, every
+            // floor and wall — still leaves the path open unless some other triangle of the ray has its distance at or below the
+            // gate.  So: replay only when a second triangle lies at exactly t, or between t and a gate above it; the kernel's own
+            // numbers decide, no tolerance.  (Until the second half of round 5 the rule was a window — "no second triangle within 1e-3
+            // of t" — which sent a few of every level's ~1 500 rays into the one-lane replay, a skimming ray's hundreds of records at
+            // a microsecond each: the 100-230 us of every thin launch.)  The window still bounds the SEARCH (boxes up to t + window are
+            // opened), so that those second triangles are seen: it is thousands of roundings wide, a gate exceeds t by one or two.
+            const float gate = r.gate == r.gate ? r.gate : 3.0e38f;  // (a NaN entry distance never passes child_trace's test; belt and braces)
+            const bool ambiguous = r.count != 0 && (r.second == r.t || (gate > r.t && r.second <= gate));
+#ifdef NX_THIN_PRINTF
+            if (lane == 0 && (e == 0 || r.rounds >= 24u || !r.complete || ambiguous)) printf("thin closest bounce %d list %d ray %d rounds %u pool %d complete %d ambiguous %d t %g gate %g second %g\n", bounce, nClosest, e, r.rounds, r.poolMax, (int)r.complete, (int)ambiguous, r.t, r.gate, r.second);
+#endif
             float hitT = r.count ? r.t : 1e30f, hitU = r.u, hitV = r.v;
             uint32_t hitTri = r.count ? r.tri : 0xffffffffu, hitInst = r.inst;
             if (!r.complete || ambiguous) {
                 // the reference's own order, one lane at work (rare: a second triangle within rounding of the closest, or a pool that ran over)
-                traverse_wave<false>(S, stackLds, lane == 0, org, dir, hitT, hitU, hitV, hitTri, hitInst);
+                traverse_wave<false, kWave>(S, stackLds, lane == 0, org, dir, hitT, hitU, hitV, hitTri, hitInst);
                 hitT = __shfl(hitT, 0); hitU = __shfl(hitU, 0); hitV = __shfl(hitV, 0);
                 hitTri = __shfl(hitTri, 0); hitInst = __shfl(hitInst, 0);
                 // (traverse_wave returns the bare instance: its material code again, as inst_code_kernel writes it — needed by the SCAN
@@ -726,12 +852,15 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
             const uint32_t slot = S->thinAny[e - nClosest];
             const float4 o = S->shadow.rayO[slot], d = S->shadow.rayD[slot];
             const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
-            const ThinResult r = thin_wave_search<true>(S, pool, org, dir, o.w, sceneIdentity);
+            const ThinResult r = thin_wave_search<true>(S, pool, poolGate, org, dir, o.w, sceneIdentity);
             bool occluded = r.count != 0;
+#ifdef NX_THIN_PRINTF
+            if (lane == 0 && (e == nClosest || r.rounds >= 24u || !r.complete)) printf("thin any bounce %d list %d ray %d rounds %u pool %d complete %d occluded %d\n", bounce, nAny, e - nClosest, r.rounds, r.poolMax, (int)r.complete, (int)occluded);
+#endif
             if (!occluded && !r.complete) {
                 float t = o.w, u, v;
                 uint32_t tri, inst;
-                occluded = traverse_wave<true>(S, stackLds, lane == 0, org, dir, t, u, v, tri, inst);
+                occluded = traverse_wave<true, kWave>(S, stackLds, lane == 0, org, dir, t, u, v, tri, inst);
                 occluded = __shfl((int)occluded, 0) != 0;
             }
             if (!occluded && lane == 0) {  // pathRadiance[pixelIdx] += radiance, as the any-hit kernel's flush (BVH8Traversal.cuh:515-516)

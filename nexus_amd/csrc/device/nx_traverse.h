@@ -16,6 +16,7 @@ constexpr int kSpillDepth = 32 - kLdsDepth;  // further entries in scratch; 32 i
 using GU4 = const NX_G uint4*;   // global-memory pointers: global_load_dwordx4, never flat
 using GF4 = const NX_G float4*;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;  // one stack entry (uint2) as a 64-bit scalar
+typedef __attribute__((address_space(3))) float lds_f32;
 
 // Record fetch, ONE per loop iteration for all record kinds: every lane issues the 16-byte global loads of its own record (3
 // or 5 in flight) and the wave waits once.  Must be reached by all lanes of the wave.  (A cooperative LDS-staged form — lanes
@@ -34,17 +35,21 @@ NXD void fetch_record(bool kind5, bool kind3, unsigned long long addr, uint4 (&o
 // a scratch array.  The stack pointer and the LDS base stay in registers: they are deliberately NOT members of a struct
 // together with the scratch array (a struct holding a dynamically indexed array is kept in scratch as a whole, which
 // turned every push / pop into scratch loads of its own stack pointer).
+// (STRIDE: the distance between two entries of a lane — the workgroup's 256 lanes side by side in the trace and tail kernels; the
+//  thin kernel's replay keeps a wave's 64 in that wave's own pool)
+template <int STRIDE = kTraceBlock>
 NXD void stack_push(lds_u64* lds, uint2* spill, int& sp, uint2 e)
 {
-    if (sp < kLdsDepth) lds[sp * kTraceBlock] = ((unsigned long long)e.y << 32) | e.x;
+    if (sp < kLdsDepth) lds[sp * STRIDE] = ((unsigned long long)e.y << 32) | e.x;
     else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = e;
     sp++;
 }
+template <int STRIDE = kTraceBlock>
 NXD uint2 stack_pop(lds_u64* lds, const uint2* spill, int& sp)
 {
     sp--;
     if (sp < kLdsDepth) {
-        const unsigned long long v = lds[sp * kTraceBlock];
+        const unsigned long long v = lds[sp * STRIDE];
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     }
     if (sp < kLdsDepth + kSpillDepth) return spill[sp - kLdsDepth];
@@ -155,6 +160,42 @@ NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t inv
     tg = make_uint2(n1.y, hitMask & 0x00ffffffu);
 }
 
+// ChildTrace for the thin kernel's closest-hit search (nx_trace.hip thin_wave_search): the SAME slab arithmetic as child_trace
+// above, child by child in storage order, but what comes out is which children the ray enters (bit c of `entered`: child_trace's
+// `tmin <= tmax`) and every child's computed entry distance tminOut[c] — the very number that test compares — instead of the two
+// hit masks.  The search carries the largest entry distance along a triangle's path from the root: its "gate".
+NXD void child_trace_gate(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, float tmaxRay, uint32_t& entered, float (&tminOut)[8])
+{
+    const uint4 n0 = nd[0], n2 = nd[2], n3 = nd[3], n4 = nd[4];
+    const f3 p = mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const f3 tdir = mk3(__uint_as_float((e_imask & 0xffu) << 23) * idir.x, __uint_as_float((e_imask << 15) & 0x7f800000u) * idir.y,
+                        __uint_as_float((e_imask << 7) & 0x7f800000u) * idir.z);
+    const f3 torg = (p - org) * idir;
+    const bool nx = dir.x < 0.0f, ny = dir.y < 0.0f, nz = dir.z < 0.0f;
+    entered = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t qlox = i ? n2.y : n2.x, qloy = i ? n2.w : n2.z, qloz = i ? n3.y : n3.x;
+        const uint32_t qhix = i ? n3.w : n3.z, qhiy = i ? n4.y : n4.x, qhiz = i ? n4.w : n4.z;
+        const uint32_t xMin = nx ? qhix : qlox, xMax = nx ? qlox : qhix;
+        const uint32_t yMin = ny ? qhiy : qloy, yMax = ny ? qloy : qhiy;
+        const uint32_t zMin = nz ? qhiz : qloz, zMax = nz ? qloz : qhiz;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float tminx = fmaf(ubyte_f(xMin, j), tdir.x, torg.x);
+            const float tminy = fmaf(ubyte_f(yMin, j), tdir.y, torg.y);
+            const float tminz = fmaf(ubyte_f(zMin, j), tdir.z, torg.z);
+            const float tmaxx = fmaf(ubyte_f(xMax, j), tdir.x, torg.x);
+            const float tmaxy = fmaf(ubyte_f(yMax, j), tdir.y, torg.y);
+            const float tmaxz = fmaf(ubyte_f(zMax, j), tdir.z, torg.z);
+            const float tmin = __int_as_float(imax3(__float_as_int(tminx), __float_as_int(tminy), __float_as_int(fmaxf(tminz, 0.0f))));
+            const float tmax = __int_as_float(imin3(__float_as_int(tmaxx), __float_as_int(tmaxy), __float_as_int(fminf(tmaxz, tmaxRay))));
+            tminOut[4 * i + j] = tmin;
+            entered |= (tmin <= tmax) ? (1u << (4 * i + j)) : 0u;
+        }
+    }
+}
 
 // The traversal of nx_trace.hip's trace_kernel for ONE ray per lane, run until every lane of the wave is done (no queue, no
 // refill): the tail kernel traces its continuation and shadow rays with it.  The loop body is the same step — pop / retire,
@@ -162,7 +203,7 @@ NXD void child_trace(const uint4 (&nd)[5], f3 org, f3 dir, f3 idir, uint32_t inv
 // the one the persistent kernel would produce (tests/test_gpu_tail.py compares the two pipelines bit for bit).
 // `valid`: this lane has a ray.  Closest hit: hitT (1e30 = miss), hitU, hitV, hitTri, hitInst.  Any hit: returns whether the
 // ray is occluded within hitT.  Must be called by all 64 lanes.
-template <bool ANY_HIT>
+template <bool ANY_HIT, int STRIDE = kTraceBlock>
 NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, bool valid, f3 org, f3 dir, float& hitT, float& hitU, float& hitV,
                        uint32_t& hitTri, uint32_t& hitInst)
 {
@@ -204,7 +245,7 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
                     nodes = tlasNodes;
                     instSp = -1;
                 }
-                const uint2 e = stack_pop(stackLds, stackSpill, sp);
+                const uint2 e = stack_pop<STRIDE>(stackLds, stackSpill, sp);
                 if (e.y & 0xff000000u) ng = e;
                 else { tg = e; ng = make_uint2(0u, 0u); }
             }
@@ -216,7 +257,7 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
         if (wantNode) {
             const int nodeOffset = 31 - __clz((int)ng.y);
             ng.y &= ~(1u << nodeOffset);
-            if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+            if (ng.y & 0xff000000u) stack_push<STRIDE>(stackLds, stackSpill, sp, ng);
             const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
             const int rel = __popc(ng.y & ~(0xffffffffu << slot));
             recAddr = (unsigned long long)(nodes + (size_t)(ng.x + (uint32_t)rel) * (unsigned)kNodeStride);
@@ -224,8 +265,8 @@ NXD bool traverse_wave(const DeviceState* __restrict__ S, lds_u64* stackLds, boo
             const int off = 31 - __clz((int)tg.y);
             tg.y &= ~(1u << off);
             recAddr = (unsigned long long)&instTrav[tg.x + (uint32_t)off];
-            if (tg.y) stack_push(stackLds, stackSpill, sp, tg);
-            if (ng.y & 0xff000000u) stack_push(stackLds, stackSpill, sp, ng);
+            if (tg.y) stack_push<STRIDE>(stackLds, stackSpill, sp, tg);
+            if (ng.y & 0xff000000u) stack_push<STRIDE>(stackLds, stackSpill, sp, ng);
             instSp = sp;
         } else if (wantTri) {
             const int off = 31 - __clz((int)tg.y);

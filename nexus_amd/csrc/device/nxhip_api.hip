@@ -505,6 +505,8 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
                 if (n >= 1 && n <= 64) c->logicBlocksPerCU = n;
             }
             if (const char* e = std::getenv("NX_THIN_JOINT")) c->thinJoint = std::atoi(e) != 0;  // measurement only
+            if (const char* e = std::getenv("NX_THIN_LANES")) { const int n = std::atoi(e); if (n >= 1 && n <= 64) c->h.thinLanes = (uint32_t)n; }   // sweeps of the hand-over rule
+            if (const char* e = std::getenv("NX_THIN_ITERS")) { const int n = std::atoi(e); if (n >= 1 && n <= 4096) c->h.thinIters = (uint32_t)n; }
             if (const char* e = std::getenv("NX_NO_THIN")) c->thinWaves = std::atoi(e) == 0;  // measurement only: no cooperative finish of a dry wave's last rays
             if (const char* e = std::getenv("NX_SCAN_SEPARATE")) c->scanSeparate = std::atoi(e) != 0;  // measurement only: one material launch per type in the SCAN pipeline
             if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
@@ -1744,7 +1746,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
     // — each trace launch of the level gets its own, chained to it alone, so that the closest-hit rays' searches run beside whatever
     // the any-hit launch still has to do (it is the longer one of the early levels) and the other way round in the late ones
-    const int thinBlocks = 3 * c->numCUs;
+    const int thinBlocks = 3 * c->numCUs;  // (48 KiB of LDS: three workgroups per CU)
     auto thin_level = [&](int bounceArg) {
         if (!thinFlag) return;
         if (c->thinJoint) {  // (NX_THIN_JOINT, measurement only: one launch for both lists behind the whole level)
