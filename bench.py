@@ -534,6 +534,17 @@ def main():
     # one step = one frame; a pass renders up to S frames
     rep_s = measure(n_frames, n_warm, args.reps, S, "timed region")
     elapsed = statistics.median(rep_s)
+    if os.environ.get("NX_WAVE_TIMELINE_OUT"):
+        # measurement builds only (tools/build_variant.sh ... -DNX_WAVE_TIMELINE): every trace wave's start / queue-dry / end times of
+        # the last pass, [any-hit][bounce][wave][5] uint64, for tools/wave_timeline.py
+        import ctypes
+        import numpy as _np
+        _L = capi.lib()
+        if hasattr(_L, "nxhip_debug_read_wave_timeline"):
+            _buf = _np.zeros((2, 12, 8192, 5), _np.uint64)
+            _rc = _L.nxhip_debug_read_wave_timeline(_buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_ulonglong(_buf.nbytes))
+            stamp("wave timeline read: rc %d" % _rc)
+            _np.save(os.environ["NX_WAVE_TIMELINE_OUT"], _buf)
 
     # (--png shows the headline's image, not what later measurements add to the accumulation)
     headline_full = full_rgba.clone() if (dist_mode and args.png and rank == 0) else None

@@ -41,6 +41,9 @@ constexpr int kReserve = NX_RESERVE;  // most rays reserved per fetch atomic (me
 #ifndef NX_REFILL_BELOW
 #define NX_REFILL_BELOW 40
 #endif
+#ifndef NX_WG_RANGE
+#define NX_WG_RANGE 1
+#endif
 static_assert((kRaySurvives << 30) == 0x80000000u, "the roulette bit of rayO.w moves to bit 31 of the lane's ray index");
 constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer than this many of the 64 are still traversing
 
@@ -336,6 +339,11 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
     return r;
 }
 
+#ifdef NX_WAVE_TIMELINE
+constexpr int kTimelineBounces = 12, kTimelineWaves = 8192;
+__device__ unsigned long long g_waveTimeline[2][kTimelineBounces][kTimelineWaves][5];
+#endif
+
 template <bool ANY_HIT, bool STATS>
 // 5 waves per SIMD for both variants (96 VGPRs, no spills in the loop).  Before an instance entry also carried its BLAS
 // root (17 more live registers in the fetch), 6 waves at 80 VGPRs was the best point (5: -3 %, 7: -0.3 %, 8: -1.5 %); with it,
@@ -365,6 +373,15 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // and three IEEE divisions into every iteration in which any lane left an instance — most of them on instanced scenes.)
     __shared__ float ldsWorld[9 * kTraceBlock];
 
+#if NX_WG_RANGE
+    // The workgroup's block of rays (see the refill): {next ray, end} packed in one 64-bit word the four waves draw from with
+    // LDS atomics; sLock: a wave is fetching the next block; sDry: no shard holds rays any more; sShard: the shard the blocks come from
+    // (sBegin / sEnd: the eight shards' first ray and end, sReserve: the block size — kept here, not in every wave's registers: they
+    //  are needed once per block)
+    __shared__ unsigned long long sRange;
+    __shared__ int sLock, sDry, sShard, sReserve;
+    __shared__ int sBegin[kXcds], sEnd[kXcds];
+#endif
     NX_G Counters* C = S->counters;
     // the queue's eight regions (nx_device.h): region k = slots [k * cap, k * cap + regionRays[k]), fetch head k counts the
     // rays handed out of it
@@ -399,6 +416,13 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const int homeRays = shard_rays(homeShard);
     // this wave's rank among the waves that call this shard home
     const int rankInShard = (int)(blockIdx.x >> 3) * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
+#ifdef NX_WAVE_TIMELINE
+    // measurement variant: every wave's life in the launch (wall_clock64: 100 MHz, one clock for the chip), kept in a device array
+    // and read with nxhip_debug_read_wave_timeline (bench.py NX_WAVE_TIMELINE_OUT)
+    const unsigned long long wpStart = wall_clock64();
+    unsigned long long wpDry = 0ull;
+    int wpHanded = 0;
+#endif
     // A wave the queue does not need leaves without touching a fetch head.  The grid is sized for the largest queue; on a
     // small one most waves would otherwise each walk all 8 heads with returning atomics to find out that nothing is left,
     // which made every launch cost about 0.5 ms however few rays it carried.
@@ -408,13 +432,24 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // drain), then use more waves.  Against one wave per 64 rays throughout: the driver's 20-frame pass +4 % (its late
     // bounces carry 0.3-4 M rays), one-frame passes unchanged; 256 rays per wave throughout: one-frame passes -5 %.
     const int raysPerWave = min(256, max(kWave, (size >> 10) & ~(kWave - 1)));
+#if !NX_WG_RANGE
     if (rankInShard * raysPerWave >= homeRays) return;
+#endif
     // Reservation size: kReserve rays, but no more than half a wave's even share of the queue, so that on a small queue
     // every wave draws a few times and the launch does not end with a handful of waves still holding full blocks
     // (one frame per pass: +14 %; 64 frames per pass: within noise).
     const int gridWaves = (int)(gridDim.x * (kTraceBlock / kWave));
     const int wavesAtWork = min(gridWaves, size / raysPerWave + kXcds);
     const int reserve = min(kReserve, max(kWave, (size / (wavesAtWork * 2)) & ~(kWave - 1)));
+#if NX_WG_RANGE
+    if (threadIdx.x < kXcds) {
+        sBegin[threadIdx.x] = shard_begin((int)threadIdx.x);
+        sEnd[threadIdx.x] = shard_begin((int)threadIdx.x) + shard_rays((int)threadIdx.x);
+    }
+    if (threadIdx.x == 0) { sRange = 0ull; sLock = 0; sDry = 0; sShard = homeShard; sReserve = reserve; }
+    __syncthreads();  // (before any wave leaves: the exit below is per wave)
+    if (rankInShard * raysPerWave >= homeRays) return;
+#endif
     int shard = homeShard;
     bool exhausted = false;
     int rngCur = 0, rngEnd = 0;  // rays reserved by this wave and not handed to a lane yet
@@ -481,41 +516,121 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 if (needMask == 0ull) break;
                 if (rngCur >= rngEnd) {
                     if (exhausted) break;
-                    // one returning atomic reserves kReserve rays of `shard` (the head counts rays handed out)
                     const int leader = __ffsll((long long)needMask) - 1;
-                    const int shardBegin = shard_begin(shard);
-                    const int shardEnd = shardBegin + shard_rays(shard);
-                    int base = 0;
-                    if (lane == leader) base = atomicAdd(&heads[shard * kRegionStride], reserve);
-                    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-                    rngCur = shardBegin + base;
-                    rngEnd = min(shardEnd, rngCur + reserve);
-                    if (rngCur >= shardEnd) {
-                        // this shard is dry: one load of all 8 heads tells which shards still hold rays (a load is served
-                        // in parallel with other waves', returning atomics on a head are serialised); go to the fullest
-                        rngCur = rngEnd = 0;
-                        int left = 0;
-                        if (lane < kXcds) {
-                            const int taken = __hip_atomic_load(&heads[lane * kRegionStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            left = max(0, shard_rays(lane) - taken);
+#if NX_WG_RANGE
+                    // The rays a wave hands its idle lanes come out of the WORKGROUP's block: one LDS atomic takes as many as the wave
+                    // needs now.  A block is what one returning atomic on the shard's head reserves (below) — as before, but for the
+                    // four waves together, so that the last block of a launch is finished by four waves side by side instead of by
+                    // the one that happened to draw it while the others leave (wave by wave, a launch's last 200-450 us ran on 2 % of
+                    // the chip: tools/wave_timeline.py).  (readfirstlane: what comes out of LDS is the same in every lane, and the
+                    // compiler must know it — the range, `exhausted` and the loop's conditions stay scalar.)
+                    {
+                        const int want = (int)__popcll(needMask);
+                        unsigned long long old = 0ull;
+                        if (lane == leader) old = __hip_atomic_fetch_add(&sRange, (unsigned long long)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int cur = __builtin_amdgcn_readlane((int)(uint32_t)old, leader);
+                        const int end = __builtin_amdgcn_readlane((int)(uint32_t)(old >> 32), leader);
+                        if (cur < end) {
+                            rngCur = cur;
+                            rngEnd = min(end, cur + want);
                         }
-                        int best = 0, bestLeft = 0;
-#pragma unroll
-                        for (int k = 0; k < kXcds; k++) {
-                            const int l = __shfl(left, k);
-                            if (l > bestLeft) { bestLeft = l; best = k; }
-                        }
-                        best = __builtin_amdgcn_readfirstlane(best);
-                        bestLeft = __builtin_amdgcn_readfirstlane(bestLeft);
-                        if (bestLeft <= 0) {
+                    }
+                    if (rngCur >= rngEnd)
+#endif
+                    {
+#if NX_WG_RANGE
+                        // the workgroup's block is used up
+                        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0) {
                             exhausted = true;
-                            // how long "long" is for this launch: kThinFactor times what a ray of this wave took on average (a wave
-                            // iteration advances its busy lanes — about 40 of 64 — by one record each), at least thinIters
-                            // (thinIters 0 — a test hook — hands a wave's rays over after their first iteration, dry queue or not)
+#ifdef NX_WAVE_TIMELINE
+                            wpDry = wall_clock64();
+#endif
                             thinAfter = thinIters ? max(thinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u))) : 0u;
+                            break;
                         }
-                        else shard = best;
-                        continue;
+                        int lock = 1;
+                        if (lane == leader) lock = __hip_atomic_exchange(&sLock, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lock = __builtin_amdgcn_readlane(lock, leader);
+                        if (lock != 0) {
+                            // another wave of the workgroup is fetching the next block: go on with the lanes that have rays (back here
+                            // after the next iteration); a wave without any waits
+                            if (__ballot(active) != 0ull) break;
+                            __builtin_amdgcn_s_sleep(4);
+                            continue;
+                        }
+                        // this wave fetches (unless a block was published since it looked)
+                        const unsigned long long now = __hip_atomic_load(&sRange, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__builtin_amdgcn_readfirstlane((int)((uint32_t)now < (uint32_t)(now >> 32))) != 0) {
+                            if (lane == leader) __hip_atomic_store(&sLock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            continue;
+                        }
+                        shard = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sShard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        const int shardBegin = __builtin_amdgcn_readfirstlane(sBegin[shard]), shardEnd = __builtin_amdgcn_readfirstlane(sEnd[shard]);
+                        const int blockRays = __builtin_amdgcn_readfirstlane(sReserve);
+#else
+                        const int shardBegin = shard_begin(shard);
+                        const int shardEnd = shardBegin + shard_rays(shard);
+                        const int blockRays = reserve;
+#endif
+                        // one returning atomic reserves a block of rays of `shard` (the head counts rays handed out)
+                        int base = 0;
+                        if (lane == leader) base = atomicAdd(&heads[shard * kRegionStride], blockRays);
+                        base = __builtin_amdgcn_readlane(base, leader);
+                        rngCur = shardBegin + base;
+                        rngEnd = min(shardEnd, rngCur + blockRays);
+#if NX_WG_RANGE
+                        if (rngCur < shardEnd) {  // the workgroup's new block
+                            if (lane == leader) {
+                                __hip_atomic_store(&sRange, ((unsigned long long)(uint32_t)rngEnd << 32) | (unsigned long long)(uint32_t)rngCur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&sLock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            rngCur = rngEnd = 0;
+                            continue;
+                        }
+#endif
+                        if (rngCur >= shardEnd) {
+                            // this shard is dry: one load of all 8 heads tells which shards still hold rays (a load is served
+                            // in parallel with other waves', returning atomics on a head are serialised); go to the fullest
+                            rngCur = rngEnd = 0;
+                            int left = 0;
+                            if (lane < kXcds) {
+                                const int taken = __hip_atomic_load(&heads[lane * kRegionStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if NX_WG_RANGE
+                                left = max(0, sEnd[lane] - sBegin[lane] - taken);
+#else
+                                left = max(0, shard_rays(lane) - taken);
+#endif
+                            }
+                            int best = 0, bestLeft = 0;
+#pragma unroll
+                            for (int k = 0; k < kXcds; k++) {
+                                const int l = __shfl(left, k);
+                                if (l > bestLeft) { bestLeft = l; best = k; }
+                            }
+                            best = __builtin_amdgcn_readfirstlane(best);
+                            bestLeft = __builtin_amdgcn_readfirstlane(bestLeft);
+                            if (bestLeft <= 0) {
+                                exhausted = true;
+#ifdef NX_WAVE_TIMELINE
+                                wpDry = wall_clock64();
+#endif
+                                // how long "long" is for this launch: kThinFactor times what a ray of this wave took on average (a wave
+                                // iteration advances its busy lanes — about 40 of 64 — by one record each), at least thinIters
+                                // (thinIters 0 — a test hook — hands a wave's rays over after their first iteration, dry queue or not)
+                                thinAfter = thinIters ? max(thinIters, (uint32_t)((float)kThinFactor * 40.0f * (float)itersTotal / (float)max(taken, 1u))) : 0u;
+                            }
+                            else shard = best;
+#if NX_WG_RANGE
+                            // (the workgroup's state: no rays anywhere, or the shard its next block comes from; the other waves find out at
+                            //  their next look)
+                            if (lane == leader) {
+                                if (bestLeft <= 0) __hip_atomic_store(&sDry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else __hip_atomic_store(&sShard, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&sLock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+#endif
+                            continue;
+                        }
                     }
                 }
                 const int avail = rngEnd - rngCur;
@@ -744,6 +859,9 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 }
                 activeMask = __ballot(active);
                 thinAllowed = false;  // (lanes the list had no room for: this wave finishes them itself)
+#ifdef NX_WAVE_TIMELINE
+                wpHanded = n;
+#endif
             }
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
         itersTotal += spins;
@@ -751,6 +869,16 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 
 #ifdef NX_EXTRA_VALU
     if (dummy0 + dummy1 + dummy2 + dummy3 == 123.456f) S->traceStats[0].rays = 1;  // keeps the filler alive
+#endif
+#ifdef NX_WAVE_TIMELINE
+    if (!STATS && lane == 0 && bounce < kTimelineBounces) {
+        const int w = (int)blockIdx.x * (kTraceBlock / kWave) + (int)(threadIdx.x / kWave);
+        if (w < kTimelineWaves) {
+            unsigned long long* rec = g_waveTimeline[ANY_HIT ? 1 : 0][bounce][w];
+            rec[0] = wpStart; rec[1] = wpDry; rec[2] = wall_clock64(); rec[3] = ((unsigned long long)taken << 32) | (unsigned long long)itersTotal;
+            rec[4] = (unsigned long long)wpHanded;
+        }
+    }
 #endif
     if (STATS) {
         // wave-level reduction, one atomic per wave and counter
@@ -875,6 +1003,19 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
 }
 
 const void* thin_kernel_ptr() { return (const void*)thin_kernel; }
+
+#ifdef NX_WAVE_TIMELINE
+}  // namespace nxd
+// (measurement variant only) the timeline of the LAST launches of every level; clears it
+extern "C" int nxhip_debug_read_wave_timeline(void* out, unsigned long long bytes)
+{
+    if (bytes != sizeof(nxd::g_waveTimeline)) return (int)sizeof(nxd::g_waveTimeline) > 0 ? -1 : -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nxd::g_waveTimeline), bytes) != hipSuccess) return -4;
+    return 0;
+}
+namespace nxd {
+#endif
 
 const void* trace_kernel_ptr(bool anyHit, bool stats)
 {
