@@ -34,7 +34,7 @@ enum {
 };
 
 /* Bumped whenever an entry point changes its signature or meaning, or a struct of this header / nexus_pod.h its layout. */
-#define NXHIP_API_VERSION 5
+#define NXHIP_API_VERSION 6
 
 /* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
 const char *nxhip_last_error(void);
@@ -188,6 +188,9 @@ int nxhip_read_entry_states(nxhip_ctx *ctx, void *out, uint32_t capacityRuns, ui
  * through the cooperative search and compare the records with the oracle's.  nxhip_debug_thin_counts: the rays the last hook call
  * handed over (closest-hit, any-hit). */
 int nxhip_debug_set_thin(nxhip_ctx *ctx, uint32_t lanes, uint32_t iters, int inHooks);
+/* ... and how many items a thin wave's pool may hold (0 = the product's 960 of 1 024): a round whose children do not fit puts items back and
+ * goes on with fewer per round — a test lowers the limit so that ordinary scenes drive that path; results must not change. */
+int nxhip_debug_set_thin_pool(nxhip_ctx *ctx, uint32_t slots);
 int nxhip_debug_thin_counts(nxhip_ctx *ctx, int32_t counts[2]);
 
 /* ---- rendering ----------------------------------------------------------------------------------- */

@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
     "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
-    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_set_entry_points", "nxhip_read_entry_states", "nxhip_debug_set_thin", "nxhip_debug_thin_counts", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
+    "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_set_entry_points", "nxhip_read_entry_states", "nxhip_debug_set_thin", "nxhip_debug_set_thin_pool", "nxhip_debug_thin_counts", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
 ]
@@ -72,7 +72,7 @@ class KernelTimes(C.Structure):
 
 KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate", "thin")
 
-API_VERSION = 5  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
+API_VERSION = 6  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
 
 
 def abi_words():
@@ -681,6 +681,11 @@ class Context:
         """the thin kernel's hand-over rule, and whether the ray-batch hooks use it too (a test hook: include/nexus_hip.h)"""
         self.L.nxhip_debug_set_thin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         check(self.L.nxhip_debug_set_thin(self.h, lanes, iters, 1 if in_hooks else 0), "nxhip_debug_set_thin")
+
+    def debug_set_thin_pool(self, slots=0):
+        """how many items a thin wave's pool may hold before a round puts items back (0: the product's limit; a test hook)"""
+        self.L.nxhip_debug_set_thin_pool.argtypes = [C.c_void_p, C.c_uint32]
+        check(self.L.nxhip_debug_set_thin_pool(self.h, int(slots)), "nxhip_debug_set_thin_pool")
 
     def debug_thin_counts(self):
         """rays the last ray-batch hook call handed to the thin kernel: (closest-hit, any-hit)"""

@@ -131,10 +131,12 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
     f3 cO = o, cD = d, cI = idirW;
     uint32_t rounds = 0u;
     bool careful = false;
+    // (the product's limit, or the lower one a test sets to drive the put-back path: nxhip_debug_set_thin_pool)
+    const int poolLimit = S->thinPoolLimit ? min(kPoolLimit, max(kWave, (int)S->thinPoolLimit)) : kPoolLimit;
     while (n > 0) {
         if (++rounds > (1u << 16)) { r.complete = false; break; }  // (a tree that is not a tree: the ordinary loop's stall guard deals with it)
         // (after a round whose children did not all fit — below — only as many items as can expand whatever they hold: 24 each)
-        const int take = careful ? min(min(n, kWave), max(1, (kPoolLimit - n) / 24)) : min(n, kWave);
+        const int take = careful ? min(min(n, kWave), max(1, (poolLimit - n) / 24)) : min(n, kWave);
         const bool have = lane < take;
         const int at = n - 1 - lane;
         const unsigned long long item = have ? pool[at] : 0ull;
@@ -242,7 +244,7 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
         // A round whose children do not all fit: the lanes up to the last one that fits push theirs, the others put their OWN item
         // back (one slot each, on top of those: the 64 slots above kPoolLimit are kept for that) and the search goes on more
         // carefully.  Only when not even one item can be expanded is the ray given to the in-order replay.
-        const bool fits = n + incl <= kPoolLimit;  // (a prefix of the lanes: incl never decreases)
+        const bool fits = n + incl <= poolLimit;  // (a prefix of the lanes: incl never decreases)
         const bool putBack = mine > 0 && !fits;
         const unsigned long long backMask = __ballot(putBack);
         if (backMask != 0ull) {
@@ -860,7 +862,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     active = false;
                 }
                 activeMask = __ballot(active);
-                thinAllowed = false;  // (lanes the list had no room for: this wave finishes them itself)
+                // (once per wave; lanes the list had no room for: this wave finishes them itself.  The test hook's rule — thinIters 0 —
+                //  hands over after EVERY refill as long as the list has room, so that nearly all rays of a batch go through the search
+                //  however the waves share the queue)
+                if (thinIters != 0u || base + n > (int)S->thinCapacity) thinAllowed = false;
 #ifdef NX_WAVE_TIMELINE
                 wpHanded = n;
 #endif

@@ -2155,6 +2155,15 @@ int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHoo
     return NXHIP_OK;
 }
 
+int nxhip_debug_set_thin_pool(nxhip_ctx* c, uint32_t slots)
+{
+    NX_CHECK_CTX(c);
+    NX_SYNC_ALL(c);
+    c->h.thinPoolLimit = slots;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
 int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
 {
     NX_CHECK_CTX(c);

@@ -46,6 +46,26 @@ def test_closest_hit_through_the_thin_kernel_is_bit_exact(gpu_ctx_factory, make_
     assert SH.hit_records_equal(ctx.trace_batch(_rays_for(scene, 40000, seed=17)), got)
 
 
+@pytest.mark.parametrize("make_scene", [SH.soup_scene, SH.instanced_scene])
+def test_a_pool_that_runs_over_puts_items_back_and_finds_the_same_records(gpu_ctx_factory, make_scene):
+    """A round of the search whose children do not fit the wave's pool puts items back and goes on with fewer items per round; only a
+    single item that cannot expand gives the ray to the in-order replay.  The product's pool (1 024 items) is not filled by these
+    scenes, so the hook lowers the limit to 64 / 96 / 160 items: every wide node then takes that path, and the records stay the
+    oracle's bit for bit — closest hit and any hit."""
+    scene = make_scene()
+    ctx = _thin_ctx(gpu_ctx_factory, scene)
+    rays = _rays_for(scene, 30000, seed=23)
+    for slots in (64, 96, 160):
+        ctx.debug_set_thin_pool(slots)
+        _check_closest(ctx, scene, rays)
+    orc = scene.oracle()
+    closest = orc.trace_closest(rays)
+    tmax = np.where(closest["hitDistance"] < 1e29, closest["hitDistance"] * np.float32(1.001), 10.0).astype(np.float32)
+    ctx.debug_set_thin_pool(64)
+    assert np.array_equal(ctx.trace_shadow_batch(rays, tmax), orc.trace_any(rays, tmax))
+    ctx.debug_set_thin_pool(0)
+
+
 def test_any_hit_through_the_thin_kernel(gpu_ctx_factory):
     scene = SH.instanced_scene(seed=9, n_inst=10)
     ctx = _thin_ctx(gpu_ctx_factory, scene)
