@@ -435,7 +435,10 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     // each (up to 256, refilled as lanes free up: a wave with a backlog keeps its lanes busy through what would be its
     // drain), then use more waves.  Against one wave per 64 rays throughout: the driver's 20-frame pass +4 % (its late
     // bounces carry 0.3-4 M rays), one-frame passes unchanged; 256 rays per wave throughout: one-frame passes -5 %.
-    const int raysPerWave = min(256, max(kWave, (size >> 10) & ~(kWave - 1)));
+#ifndef NX_RPW_SHIFT
+#define NX_RPW_SHIFT 10
+#endif
+    const int raysPerWave = min(256, max(kWave, (size >> NX_RPW_SHIFT) & ~(kWave - 1)));
 #if !NX_WG_RANGE
     if (rankInShard * raysPerWave >= homeRays) return;
 #endif
