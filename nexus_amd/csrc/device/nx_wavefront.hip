@@ -1149,7 +1149,12 @@ __global__ void __launch_bounds__(kShadeBlock, NX_SHADE_WAVES) shade_scan_kernel
     // this workgroup's place among those that start on the same type, and how many of them there are
     const int myStart = rank % nTypes, myIndex = rank / nTypes;
     // four rays per thread while that still gives every starter a tile, else one (see shade_scan_type)
-    const int per = inRegion >= 4 * kShadeBlock * ((ranks + nTypes - 1) / nTypes) ? 4 : 1;
+    // (... while that gives every starter FOUR tiles: with fewer the launch is as long as its unluckiest workgroup — one frame per pass:
+    //  material step 0.50 -> 0.45 ms per frame; the driver's 20-frame pass =)
+#ifndef NX_SCAN_TILE_FACTOR
+#define NX_SCAN_TILE_FACTOR 4
+#endif
+    const int per = inRegion >= NX_SCAN_TILE_FACTOR * 4 * kShadeBlock * ((ranks + nTypes - 1) / nTypes) ? 4 : 1;
     const int tiles = (inRegion + per * kShadeBlock - 1) / (per * kShadeBlock);
     if (myIndex >= tiles) return;  // more workgroups than tiles (late bounces): the surplus leaves before any barrier or atomic
     // the types in graph order of the reference (Diffuse, Plastic, Dielectric, Conductor: PathTracer.cpp:116-120), rotated so that
