@@ -204,6 +204,7 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t materialTypeMask = 0xfu;
     // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
     bool classicPipeline = false;
+    bool thinInFlight = false;  // NX_THIN_IN_FLIGHT (NX_TUNING_KNOBS): the thin level also when several passes are in flight
     bool thinInHooks = false;  // nxhip_debug_set_thin: the ray-batch hooks hand over and launch the thin kernel too
     bool thinJoint = false;  // NX_THIN_JOINT=1 (measurement only): one thin launch per level instead of one per trace launch
     bool thinWaves = true;  // the trace launches of a pass finish the last long rays of a dry wave cooperatively (NX_NO_THIN=1 with NX_TUNING_KNOBS=1: off)

@@ -507,6 +507,7 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
             if (const char* e = std::getenv("NX_THIN_JOINT")) c->thinJoint = std::atoi(e) != 0;  // measurement only
             if (const char* e = std::getenv("NX_THIN_LANES")) { const int n = std::atoi(e); if (n >= 1 && n <= 64) c->h.thinLanes = (uint32_t)n; }   // sweeps of the hand-over rule
             if (const char* e = std::getenv("NX_THIN_ITERS")) { const int n = std::atoi(e); if (n >= 1 && n <= 4096) c->h.thinIters = (uint32_t)n; }
+            if (const char* e = std::getenv("NX_THIN_IN_FLIGHT")) c->thinInFlight = std::atoi(e) != 0;  // measurement only: the thin level with passes in flight too
             if (const char* e = std::getenv("NX_NO_THIN")) c->thinWaves = std::atoi(e) == 0;  // measurement only: no cooperative finish of a dry wave's last rays
             if (const char* e = std::getenv("NX_SCAN_SEPARATE")) c->scanSeparate = std::atoi(e) != 0;  // measurement only: one material launch per type in the SCAN pipeline
             if (const char* e = std::getenv("NX_PIPELINE_CLASSIC")) c->classicPipeline = std::atoi(e) != 0;  // measurement only: logic kernel + material queues under fast compaction too
@@ -1716,7 +1717,7 @@ int pass_flavor(const nxhip_ctx* c)
     // Small passes one at a time keep it as well: the median of single passes does not show it (a rank of 8's 2.5 frames' worth: 4.57 ->
     // 4.6-4.7 ms, an extra launch per level), but one pass in seven holds an outlier ray (6.2 ms instead of 4.6) and sequences of small
     // passes are what a viewer or a rank of a tile split renders: four frames per pass 1 223 -> 1 335 Msamples/s, one frame 602 -> 620.
-    if (c->thinWaves && !c->statsEnabled && c->passesInFlight <= 1u) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
+    if (c->thinWaves && !c->statsEnabled && (c->passesInFlight <= 1u || c->thinInFlight)) f |= kFlavorThin;  // (the caller's setting, not effective_slots(): a timing replay of a run with passes in flight keeps that run's kernels)
     return f;
 }
 
