@@ -115,6 +115,26 @@ def test_the_special_cases_follow_ieee_and_annex_f():
         assert np.all(np.isnan(O.fmath_batch(OPS["pow"], np.array([-2.0, -0.5]), np.array([2.0, 0.5]))))
 
 
+def test_the_float_functions_coefficients_are_what_the_fitting_script_derives():
+    """include/nexus_fmath.h says its binary32 polynomials are fitted (tools/fmath_coeffs.py: weighted minimax fits of each function's
+    series remainder), not transcribed from anywhere: every coefficient the script prints must stand in the header, digit for digit."""
+    import io
+    import os
+    import re
+    import runpy
+    from contextlib import redirect_stdout
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        runpy.run_path(os.path.join(root, "tools", "fmath_coeffs.py"), run_name="__main__")
+    printed = re.findall(r"-?\d\.\d+(?:e[+-]\d+)?f", buf.getvalue())
+    assert len(printed) >= 30
+    header = open(os.path.join(root, "include", "nexus_fmath.h")).read()
+    missing = [c for c in printed if c not in header]
+    assert not missing, "coefficients the script derives that the header does not hold: %r" % missing
+
+
 def test_tonemap_uses_the_shared_pow():
     """LinearToGamma (Utils/Utils.h:51-54) through nxf_pow: the 8-bit values of the oracle's tonemap equal a 50-digit evaluation
     wherever that is not within 1e-6 of a rounding boundary"""
