@@ -96,6 +96,10 @@ struct PassSlot {
     DevBuf scanStatus;        // ordered compaction: tile status words (allocated with the queues)
     DevBuf thinLists;         // 2 x kThinListEntries queue slots: the rays the trace launches of a level hand to the thin kernel (allocated with the queues)
     uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
+    // the slot's error word as the pass left it, copied into pinned host memory behind every pass on the slot's own stream: what
+    // nxhip_sync reads instead of a blocking 4-byte device read per slot (errorFresh: no launch since that could have set it)
+    uint32_t* hostError = nullptr;
+    bool errorFresh = false;
     size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
     // Instances of the pass graph, one per SHAPE it has been asked for (see serial_shade, trace_blocks, tail_bounce in
     // nxhip_api.hip: a small pass, a large pass and a pass among several in flight are different graphs).  A pass of another

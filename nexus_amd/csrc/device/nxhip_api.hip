@@ -538,6 +538,7 @@ void nxhip_destroy(nxhip_ctx* c)
         PassSlot* q = slot_at(c, k);
         if (q->done) (void)hipEventDestroy(q->done);
         if (q->accumulated) (void)hipEventDestroy(q->accumulated);
+        if (q->hostError) (void)hipHostFree(q->hostError);
         if (k > 0 && q->ownsStream && q->stream) (void)hipStreamDestroy(q->stream);
     }
     c->extra.clear();
@@ -559,12 +560,18 @@ static int check_device_errors(nxhip_ctx* c)
 {
     uint32_t any = 0u;
     for (uint32_t k = 0; k < slot_count(c); k++) {
-        uint32_t* word = &slot_at(c, k)->frame.as<FrameState>()->errorWord;
+        PassSlot* const q = slot_at(c, k);
+        if (!q->frame.p) continue;  // (a slot that never rendered)
+        uint32_t* word = &q->frame.as<FrameState>()->errorWord;
         uint32_t w = 0u;
-        NX_HIP(hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost));
+        // (the caller has synchronised: a pass's own copy of the word is there; anything launched since — the ray-batch hooks — is read here)
+        if (q->errorFresh && q->hostError) w = *q->hostError;
+        else NX_HIP(hipMemcpy(&w, word, 4, hipMemcpyDeviceToHost));
+        q->errorFresh = false;
         if (w) {
             const uint32_t zero = 0u;
             NX_HIP(hipMemcpy(word, &zero, 4, hipMemcpyHostToDevice));
+            if (q->hostError) *q->hostError = 0u;
         }
         any |= w;
     }
@@ -2057,6 +2064,11 @@ try {
             }
         }
     }
+    // the error word of this pass travels behind it (nxhip_sync then needs no read of its own: a blocking device read costs about 0.1 ms,
+    // once per frame for a viewer that synchronises every frame)
+    if (!q->hostError) NX_HIP(hipHostMalloc((void**)&q->hostError, sizeof(uint32_t), hipHostMallocDefault));
+    NX_HIP(hipMemcpyAsync(q->hostError, &q->frame.as<FrameState>()->errorWord, sizeof(uint32_t), hipMemcpyDeviceToHost, q->stream));
+    q->errorFresh = true;
     if (R > 1) NX_HIP(hipEventRecord(q->done, q->stream));
     q->frames = frames;
     q->frameLast = frameLast;
@@ -2494,6 +2506,7 @@ static int run_trace_chunk(nxhip_ctx* c, bool anyHit, uint32_t n)
         void* args[4] = {(void*)&S, (void*)&n, (void*)&any, (void*)&slot};
         NX_HIP(hipLaunchKernel(hook_sizes_kernel_ptr(), dim3(1), dim3(64), args, 0, c->stream));
     }
+    c->errorFresh = false;  // (this launch may set the error word after the last pass's copy of it)
     const bool thin = c->thinInHooks && !c->statsEnabled;
     Launch l = make_launch(trace_kernel_ptr(anyHit, c->statsEnabled), anyHit ? c->shadowBlocks : c->traceBlocks, kTraceBlockThreads,
                            anyHit ? NXHIP_K_SHADOW : NXHIP_K_TRACE, c->dState.as<DeviceState>(), kHookBounceSlot | (thin ? kTraceThinFlag : 0));
