@@ -179,7 +179,7 @@ int nxhip_set_tail_bounce(nxhip_ctx *ctx, uint32_t bounce);
  * reference starts every ray at the root (Cuda/BVH/BVH8Traversal.cuh:165-192).  Hit records are unchanged bit for bit; the node
  * visit counts of nxhip_read_trace_stats drop by the steps saved.  Takes effect for a pinhole camera (lens radius 0). */
 int nxhip_set_entry_points(nxhip_ctx *ctx, int on);
-/* The entry states of the last rendered pass, 96 bytes each (nx_device.h EntryState: six stack entries, node group, leaf group,
+/* The entry states of the last rendered pass, 80 bytes each (nx_device.h EntryState: six stack entries, node group, leaf group,
  * then int32 sp, instSp, leafSlot, steps) — a test hook: how many node steps the walk saved per run.  *count = number of runs. */
 int nxhip_read_entry_states(nxhip_ctx *ctx, void *out, uint32_t capacityRuns, uint32_t *count);
 /* Test hook for the thin kernel (nx_trace.hip): the hand-over rule — at most `lanes` busy lanes of a dry wave for at least `iters`

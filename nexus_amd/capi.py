@@ -695,12 +695,11 @@ class Context:
         return int(out[0]), int(out[1])
 
     def read_entry_states(self):
-        """(runs, 24) int32: the entry states of the last pass; column 19 = node steps saved, 16 = stack entries, 18 = instance record,
-        20-21 / 22-23 = instance record / triangle of the triangles the walk consumed (-1: none)"""
+        """(runs, 20) int32: the entry states of the last pass; column 19 = node steps saved, 16 = stack entries, 18 = instance record"""
         self.L.nxhip_read_entry_states.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         n = C.c_uint32(0)
         check(self.L.nxhip_read_entry_states(self.h, None, 0, C.byref(n)), "nxhip_read_entry_states")
-        out = np.zeros((n.value, 24), np.int32)
+        out = np.zeros((n.value, 20), np.int32)
         if n.value:
             check(self.L.nxhip_read_entry_states(self.h, _ptr(out), n.value, C.byref(n)), "nxhip_read_entry_states")
         return out

@@ -98,7 +98,6 @@ struct PassSlot {
     uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
     // the slot's error word as the pass left it, copied into pinned host memory behind every pass on the slot's own stream: what
     // nxhip_sync reads instead of a blocking 4-byte device read per slot (errorFresh: no launch since that could have set it)
-    uint32_t entrySeen = 0;   // nxhip_ctx::entryGeneration this slot's last pass computed the entry states for (nx_entry.hip): a pass recomputes them only after a change
     uint32_t* hostError = nullptr;
     bool errorFresh = false;
     size_t pathCapacity = 0;  // paths this slot's queue buffers hold right now; 0: released (nxhip_ctx::queueCapacity is the nominal size)
@@ -209,7 +208,6 @@ struct nxhip_ctx : nxd::PassSlot {
     uint32_t materialTypeMask = 0xfu;
     // NX_TUNING_KNOBS=1 NX_PIPELINE_CLASSIC=1 (measurement only): the logic kernel + material queues also under fast compaction
     bool classicPipeline = false;
-    uint32_t entryGeneration = 1;  // bumped by everything the entry states depend on: camera, pixel set, acceleration structures (any state upload, refits, rebuilds)
     bool thinInFlight = false;  // NX_THIN_IN_FLIGHT (NX_TUNING_KNOBS): the thin level also when several passes are in flight
     bool thinInHooks = false;  // nxhip_debug_set_thin: the ray-batch hooks hand over and launch the thin kernel too
     bool thinJoint = false;  // NX_THIN_JOINT=1 (measurement only): one thin launch per level instead of one per trace launch

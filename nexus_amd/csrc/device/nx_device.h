@@ -182,12 +182,8 @@ struct __attribute__((aligned(16))) EntryState {
     int32_t instSp;    // -1: in the TLAS
     int32_t leafSlot;  // instance record (TLAS leaf order) the state is inside of, -1: none
     int32_t steps;     // node steps taken (0: the state is the root's; the kernel then starts as usual)
-    // Triangles the walk CONSUMED because every ray of the run hits them (second half of round 5): the instance record and the
-    // triangle's place in that BLAS's intersection stream, in the order the loop would test them; 0xffffffff: none.  A ray computes
-    // its own Moeller-Trumbore record for them when it installs the state (nx_trace.hip), then starts at the state.
-    uint32_t hitLeaf[2], hitTri[2];
 };
-static_assert(sizeof(EntryState) == 96, "EntryState layout");
+static_assert(sizeof(EntryState) == 80, "EntryState layout");
 struct ShadowQueue {
     NX_G float4* rayO;
     NX_G float4* rayD;

@@ -24,10 +24,6 @@
 #include "nx_device.h"
 #include "nx_math.h"
 
-#ifndef NX_ENTRY_TRIANGLES
-#define NX_ENTRY_TRIANGLES 1
-#endif
-
 namespace nxd {
 
 namespace {
@@ -47,11 +43,8 @@ struct Bundle {
 
 enum { kMissAll = 0, kHitAll = 1, kUndecided = 2 };
 
-// one child box [lo, hi] against the bundle.  [hitLo, hitHi]: what the rays' hit distances lie between once the walk has consumed
-// a triangle every ray hits (1e300: no hit yet) — the kernel enters a child only while its entry distance is at or below the ray's
-// hit distance, so a box all rays would enter is "hit by all" only if every ray reaches it in front of hitLo, "missed by all" if
-// none reaches it in front of hitHi, undecided in between.  (b.dir are unit vectors: parameters are distances.)
-NXD int classify(const Bundle& b, const double lo[3], const double hi[3], const double hitLo, const double hitHi)
+// one child box [lo, hi] against the bundle
+NXD int classify(const Bundle& b, const double lo[3], const double hi[3])
 {
     double m[3];
     bool flat[3];
@@ -99,7 +92,6 @@ NXD int classify(const Bundle& b, const double lo[3], const double hi[3], const 
     // hit by all: every edge ray through the shrunk box (a flat axis stays the plane it is; an axis too thin to shrink: undecided)
     for (int a = 0; a < 3; a++)
         if (!flat[a] && hi[a] - lo[a] <= 4.0 * m[a]) return kUndecided;
-    double tnMin = 1.0e300, tnMax = 0.0;
     for (int k = 0; k < 4; k++) {
         double tn = 0.0, tf = 1.0e300;
         for (int a = 0; a < 3; a++) {
@@ -112,22 +104,12 @@ NXD int classify(const Bundle& b, const double lo[3], const double hi[3], const 
         // (a clear pass: the entry and exit distances apart by more than rounding, unless a flat axis makes them one plane's)
         if (!(tn <= tf) || tf <= 0.0) return kUndecided;
         if (!(flat[0] || flat[1] || flat[2]) && !(tn < tf)) return kUndecided;
-        tnMin = fmin(tnMin, tn);
-        tnMax = fmax(tnMax, tn);
-    }
-    if (hitHi < 1.0e299) {
-        // (the entry distance over the bundle lies between its values on the four edge rays up to second order in the bundle's
-        //  opening angle, 1e-5 for a run of 64 pixels: the margins are a hundred times that)
-        const double slack = 1.0e-3 * (tnMax + m[0] + m[1] + m[2]) + 1.0e-6;
-        if (tnMin - slack > hitHi) return kMissAll;   // every ray has its hit in front of this box
-        if (tnMax + slack < hitLo) return kHitAll;
-        return kUndecided;
     }
     return kHitAll;
 }
 
 // ChildTrace (nx_traverse.h child_trace) for the bundle: the hit mask every ray of it gets, or false when a child is undecided
-NXD bool bundle_child_trace(const Bundle& b, const NX_G uint4* node, const uint32_t invOct4, const double hitLo, const double hitHi, uint2& ng, uint2& tg)
+NXD bool bundle_child_trace(const Bundle& b, const NX_G uint4* node, const uint32_t invOct4, uint2& ng, uint2& tg)
 {
     const uint4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
     const double p[3] = {(double)__uint_as_float(n0.x), (double)__uint_as_float(n0.y), (double)__uint_as_float(n0.z)};
@@ -152,7 +134,7 @@ NXD bool bundle_child_trace(const Bundle& b, const NX_G uint4* node, const uint3
             const double hi[3] = {p[0] + scale[0] * (double)((qhix >> (8 * j)) & 0xffu), p[1] + scale[1] * (double)((qhiy >> (8 * j)) & 0xffu),
                                   p[2] + scale[2] * (double)((qhiz >> (8 * j)) & 0xffu)};
             if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return false;  // (an inverted slot: leave it to the kernel's own arithmetic)
-            const int c = classify(b, lo, hi, hitLo, hitHi);
+            const int c = classify(b, lo, hi);
 #ifdef NX_ENTRY_DEBUG
             if (blockIdx.x * blockDim.x + threadIdx.x == NX_ENTRY_DEBUG) printf("child %d.%d bits %u class %d box [%g %g %g] [%g %g %g]\n", i, j, childBits, c, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 #endif
@@ -165,52 +147,6 @@ NXD bool bundle_child_trace(const Bundle& b, const NX_G uint4* node, const uint3
     return true;
 }
 
-// One triangle of the intersection stream (p0 | id, e0, e1: nx_device.h) against the bundle: hit by every ray (the four edge rays hit
-// its plane at points whose barycentrics lie a margin inside: the pyramid's cut with the plane is their convex hull), missed by every
-// ray (all four violate the same linear constraint, or the plane lies behind), or undecided.  Hit by all: [tLo, tHi] bounds the
-// distance.
-NXD int classify_triangle(const Bundle& b, const NX_G float4* rec, double& tLo, double& tHi)
-{
-    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-    const D3 p0{(double)r0.x, (double)r0.y, (double)r0.z}, e0{(double)r1.x, (double)r1.y, (double)r1.z}, e1{(double)r2.x, (double)r2.y, (double)r2.z};
-    const D3 n = dcross(e0, e1);
-    const double nn = ddot(n, n);
-    if (!(nn > 0.0)) return kUndecided;
-    const double rootNn = sqrt(nn);
-    const double height = ddot(n, dsub(p0, b.org));
-    double u[4], v[4], t[4];
-    int front = 0, behind = 0;
-    for (int k = 0; k < 4; k++) {
-        const double denom = ddot(n, b.dir[k]);
-        if (!(fabs(denom) > 1.0e-4 * rootNn)) return kUndecided;  // grazing
-        t[k] = height / denom;
-        if (t[k] > 0.0) front++; else behind++;
-        const D3 q{b.org.x + t[k] * b.dir[k].x - p0.x, b.org.y + t[k] * b.dir[k].y - p0.y, b.org.z + t[k] * b.dir[k].z - p0.z};
-        u[k] = ddot(dcross(q, e1), n) / nn;
-        v[k] = ddot(dcross(e0, q), n) / nn;
-    }
-    if (behind == 4) return kMissAll;
-    if (front != 4) return kUndecided;
-    const double m = 2.0e-3;
-    int in = 0, uLow = 0, vLow = 0, wHigh = 0;
-    double lo = 1.0e300, hi = 0.0;
-    for (int k = 0; k < 4; k++) {
-        if (u[k] >= m && v[k] >= m && u[k] + v[k] <= 1.0 - m) in++;
-        if (u[k] <= -m) uLow++;
-        if (v[k] <= -m) vLow++;
-        if (u[k] + v[k] >= 1.0 + m) wHigh++;
-        lo = fmin(lo, t[k]);
-        hi = fmax(hi, t[k]);
-    }
-    if (uLow == 4 || vLow == 4 || wHigh == 4) return kMissAll;
-    if (in != 4) return kUndecided;
-    const double mag = fabs(b.org.x) + fabs(b.org.y) + fabs(b.org.z) + fabs(p0.x) + fabs(p0.y) + fabs(p0.z);
-    if (!(lo > 1.0e-3 * mag)) return kUndecided;  // (a hit this close to the origin: leave it to the kernel's own t > 0)
-    tLo = lo * (1.0 - 1.0e-3) - 1.0e-6 * mag;
-    tHi = hi * (1.0 + 1.0e-3) + 1.0e-6 * mag;
-    return kHitAll;
-}
-
 }  // namespace
 
 // the state of run `run`: the root's when a condition is not met
@@ -221,7 +157,6 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
     st.ng = make_uint2(0u, 0x80000000u);
     st.tg = make_uint2(0u, 0u);
     st.sp = 0; st.instSp = -1; st.leafSlot = -1; st.steps = 0;
-    st.hitLeaf[0] = st.hitLeaf[1] = 0xffffffffu; st.hitTri[0] = st.hitTri[1] = 0u;
     const EntryState root = st;
 
     const nx_camera cam = S->camera;
@@ -269,11 +204,6 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
         if (neg == 4) oct |= (a == 0 ? 4u : (a == 1 ? 2u : 1u));
     }
     const uint32_t invOct4 = (7u - oct) * 0x01010101u;
-    for (int k = 0; k < 4; k++) {  // unit edge rays from here on: parameters along them are distances, as the kernel's hit distances are
-        const double len = sqrt(ddot(b.dir[k], b.dir[k]));
-        b.dir[k] = D3{b.dir[k].x / len, b.dir[k].y / len, b.dir[k].z / len};
-    }
-    b.axis = D3{b.dir[0].x + b.dir[1].x + b.dir[2].x + b.dir[3].x, b.dir[0].y + b.dir[1].y + b.dir[2].y + b.dir[3].y, b.dir[0].z + b.dir[1].z + b.dir[2].z + b.dir[3].z};
     for (int k = 0; k < 4; k++) {
         b.plane[k] = dcross(b.dir[k], b.dir[(k + 1) & 3]);
         if (ddot(b.plane[k], b.axis) < 0.0) b.plane[k] = D3{-b.plane[k].x, -b.plane[k].y, -b.plane[k].z};
@@ -281,35 +211,26 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
 
     const bool identityScene = (S->sceneFlags & kSceneAllIdentity) != 0u;
     const NX_G uint4* nodes = S->tlasNodes;
-    const NX_G float4* isect = nullptr;
-    double hitLo = 1.0e300, hitHi = 1.0e300;  // the run's hit distances once a triangle has been consumed
-    int hits = 0;
-    // The traversal loop of nx_trace.hip, step by step, for the whole run at once: acquire (pop), then ONE of — a TLAS leaf (the first
-    // pending instance + its BLAS's root), a triangle of a pending BLAS leaf, a node.  Every step taken has the outcome every ray
-    // of the run gets; the walk stops in front of the first step it cannot decide.
     for (;;) {
-        if (st.steps >= 12 || st.sp >= kEntryMaxStack - 2) break;
-        if (st.tg.y == 0u && (st.ng.y & 0xff000000u) == 0u) {
-            // out of work: the next stack entry (none left: the rays are finished — nothing the walk needs to say)
-            if (st.sp == 0) break;
-            EntryState next = st;
-            if (next.sp == next.instSp) {  // leaving the (identity) instance
-                nodes = S->tlasNodes;
-                next.instSp = -1;
-                next.leafSlot = -1;
-            }
-            const uint2 e = next.stack[--next.sp];
-            next.stack[next.sp] = make_uint2(0u, 0u);
-            if (e.y & 0xff000000u) next.ng = e;
-            else { next.tg = e; next.ng = make_uint2(0u, 0u); }
-            st = next;
-            continue;
-        }
-        if (st.tg.y != 0u && st.instSp < 0) {
-            // TLAS leaves: the first pending instance and its BLAS's root in one step, as the kernel takes them — through identity
-            // instances only (the bundle is then the same in the BLAS's frame)
-            if (!identityScene) break;
-            EntryState in = st;
+        // (loop top of nx_trace.hip's traversal: a node group with unvisited children and no pending leaf work)
+        if (st.tg.y != 0u || (st.ng.y & 0xff000000u) == 0u) break;
+        if (st.steps >= 8 || st.sp >= kEntryMaxStack - 2) break;
+        EntryState next = st;
+        const int nodeOffset = 31 - __clz((int)next.ng.y);
+        next.ng.y &= ~(1u << nodeOffset);
+        if (next.ng.y & 0xff000000u) next.stack[next.sp++] = next.ng;
+        const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
+        const int rel = __popc(next.ng.y & ~(0xffffffffu << slot));
+        uint2 ng, tg;
+        if (!bundle_child_trace(b, nodes + (size_t)(next.ng.x + (uint32_t)rel) * (unsigned)kNodeStride, invOct4, ng, tg)) break;
+        next.ng = ng;
+        next.tg = tg;
+        next.steps++;
+        if (tg.y != 0u && next.instSp < 0) {
+            // TLAS leaves: the first instance and its BLAS's root in one step, as the kernel takes them — through identity instances
+            // only (the bundle is then the same in the BLAS's frame)
+            if (!identityScene || next.sp >= kEntryMaxStack - 2) { st = next; break; }
+            EntryState in = next;
             const int off = 31 - __clz((int)in.tg.y);
             in.tg.y &= ~(1u << off);
             const uint32_t leaf = in.tg.x + (uint32_t)off;
@@ -318,51 +239,14 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
             in.instSp = in.sp;
             in.leafSlot = (int32_t)leaf;
             const NX_G InstTrav* rec = &S->instTrav[leaf];
-            uint2 ng, tg;
-            if (!bundle_child_trace(b, (const NX_G uint4*)rec->root, invOct4, hitLo, hitHi, ng, tg)) break;
+            if (!bundle_child_trace(b, (const NX_G uint4*)rec->root, invOct4, ng, tg)) { st = next; break; }
             in.ng = ng;
             in.tg = tg;
             in.steps++;
             st = in;
             nodes = rec->nodes;
-            isect = rec->isect;
             continue;
         }
-        if (st.tg.y != 0u) {
-#if !NX_ENTRY_TRIANGLES
-            break;  // (measurement: the walk ends at the first triangles, as in the first half of round 5)
-#endif
-            // a triangle of the pending leaf, in the loop's order: consumed when every ray misses it, or when every ray hits it (each
-            // ray then computes its own record for it at install) — at most two of the latter
-            const int off = 31 - __clz((int)st.tg.y);
-            const uint32_t tri = st.tg.x + (uint32_t)off;
-            double tLo = 0.0, tHi = 0.0;
-            const int c = classify_triangle(b, isect + (size_t)tri * (unsigned)kTriStride, tLo, tHi);
-            if (c == kUndecided || (c == kHitAll && hits == 2)) break;
-            EntryState next = st;
-            next.tg.y &= ~(1u << off);
-            if (c == kHitAll) {
-                next.hitLeaf[hits] = (uint32_t)st.leafSlot;
-                next.hitTri[hits] = tri;
-                hits++;
-                hitLo = fmin(hitLo, tLo);  // (a ray's hit distance after the test: the smaller of what it had and this one)
-                hitHi = fmin(hitHi, tHi);
-            }
-            st = next;
-            continue;
-        }
-        // a node: the next child of the node group
-        EntryState next = st;
-        const int nodeOffset = 31 - __clz((int)next.ng.y);
-        next.ng.y &= ~(1u << nodeOffset);
-        if (next.ng.y & 0xff000000u) next.stack[next.sp++] = next.ng;
-        const int slot = (nodeOffset - 24) ^ (int)(invOct4 & 7u);
-        const int rel = __popc(next.ng.y & ~(0xffffffffu << slot));
-        uint2 ng, tg;
-        if (!bundle_child_trace(b, nodes + (size_t)(next.ng.x + (uint32_t)rel) * (unsigned)kNodeStride, invOct4, hitLo, hitHi, ng, tg)) break;
-        next.ng = ng;
-        next.tg = tg;
-        next.steps++;
         st = next;
     }
     return st;

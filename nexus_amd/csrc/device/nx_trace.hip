@@ -348,10 +348,7 @@ constexpr int kTimelineBounces = 12, kTimelineWaves = 8192;
 __device__ unsigned long long g_waveTimeline[2][kTimelineBounces][kTimelineWaves][5];
 #endif
 
-// ENTRY: the primary launch of a pass with entry points (nx_entry.hip) — the only launch that installs entry states at refill; the
-// other launches are compiled without that code (its loads and the consumed triangles' tests cost the refill's registers: 8 -> 15
-// spilled VGPRs when every closest-hit launch carried it).  The counting variant keeps it either way.
-template <bool ANY_HIT, bool STATS, bool ENTRY = false>
+template <bool ANY_HIT, bool STATS>
 // 5 waves per SIMD for both variants (96 VGPRs, no spills in the loop).  Before an instance entry also carried its BLAS
 // root (17 more live registers in the fetch), 6 waves at 80 VGPRs was the best point (5: -3 %, 7: -0.3 %, 8: -1.5 %); with it,
 // 6 waves spill 23 VGPRs inside the loop (-10 %), 5 and 4 measure +4.5 % and +1 % over the old kernel at 6.
@@ -366,7 +363,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const int bounce = bounceArg & 0xff;
     const bool scan = !ANY_HIT && (bounceArg & kTraceScanFlag) != 0;
     // ... | kTraceEntryFlag: the rays name the entry state of their run (rayO.w): installed at refill instead of the root's
-    const bool entryLaunch = !ANY_HIT && (ENTRY || STATS) && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
+    const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
     // ... | kTraceThinFlag: the last long rays of a dry wave may be handed to the thin kernel (below)
     bool thinAllowed = !STATS && kThinCode && (bounceArg & kTraceThinFlag) != 0;
     const int thinLanes = (int)S->thinLanes;
@@ -667,7 +664,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                     xformed = false;
                     nodes = tlasNodes;
                     if (STATS) nRays++;
-                    if (!ANY_HIT && (ENTRY || STATS) && entryLaunch) {
+                    if (!ANY_HIT && entryLaunch) {
                         // the state the first node steps of this ray's run provably lead to (nx_entry.hip), instead of the root's
                         const uint32_t en = __float_as_uint(o.w) >> kRayEntryShift;
                         if (en != 0u) {
@@ -689,33 +686,6 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                                     nodes = rec->nodes;
                                     isect = rec->isect;
                                     instIdx = rec->instIdx;
-                                }
-                                // the triangles the walk consumed because every ray of the run hits them: this ray's own record for each,
-                                // in the loop's order and with the loop's arithmetic (the triangle step below; identity instances: the
-                                // ray is the world ray)
-                                const uint4 consumed = *(const NX_G uint4*)&es->hitLeaf[0];  // hitLeaf[0], hitLeaf[1], hitTri[0], hitTri[1]
-#pragma unroll
-                                for (int k = 0; k < 2; k++) {
-                                    const uint32_t leaf = k ? consumed.y : consumed.x, triRec = k ? consumed.w : consumed.z;
-                                    if (leaf != 0xffffffffu) {
-                                        const NX_G InstTrav* rec = instTrav + leaf;
-                                        GF4 tr = rec->isect + (size_t)triRec * (unsigned)kTriStride;
-                                        const float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
-                                        const f3 p0 = mk3(t0.x, t0.y, t0.z), edge0 = mk3(t1.x, t1.y, t1.z), edge1 = mk3(t2.x, t2.y, t2.z);
-                                        const f3 rayCrossEdge1 = cross3(dir, edge1);
-                                        const float det = dot3(edge0, rayCrossEdge1);
-                                        const float invDet = 1.0f / det;
-                                        const f3 sv = org - p0;
-                                        const float u = invDet * dot3(sv, rayCrossEdge1);
-                                        const f3 sCrossEdge0 = cross3(sv, edge0);
-                                        const float v = invDet * dot3(dir, sCrossEdge0);
-                                        const float t = invDet * dot3(edge1, sCrossEdge0);
-                                        if (!(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0f && t < hitT)) {
-                                            hitT = t; hitU = u; hitV = v;
-                                            hitTri = __float_as_uint(t0.w);
-                                            hitInst = rec->instIdx;
-                                        }
-                                    }
                                 }
                             }
                         }
@@ -944,7 +914,6 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 }
 
 template __global__ void trace_kernel<false, false>(const DeviceState*, int);
-template __global__ void trace_kernel<false, false, true>(const DeviceState*, int);
 template __global__ void trace_kernel<false, true>(const DeviceState*, int);
 template __global__ void trace_kernel<true, false>(const DeviceState*, int);
 template __global__ void trace_kernel<true, true>(const DeviceState*, int);
@@ -1044,7 +1013,6 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
 }
 
 const void* thin_kernel_ptr() { return (const void*)thin_kernel; }
-const void* trace_entry_kernel_ptr() { return (const void*)trace_kernel<false, false, true>; }  // the primary launch with entry points
 
 #ifdef NX_WAVE_TIMELINE
 }  // namespace nxd

@@ -25,7 +25,6 @@ const void* count_scan_kernel_ptr();
 const void* inst_code_kernel_ptr();
 const void* entry_state_kernel_ptr();
 const void* thin_kernel_ptr();
-const void* trace_entry_kernel_ptr();
 const void* begin_frame_kernel_ptr();
 const void* hook_sizes_kernel_ptr();
 const void* generate_kernel_ptr();
@@ -240,7 +239,6 @@ static int upload_state(nxhip_ctx* c)
 {
     if (!c->stateDirty) return NXHIP_OK;
     NX_SYNC_ALL(c);  // no pass in flight may see half of an edit
-    c->entryGeneration++;  // (camera, pixel set, BVH pointers ...: the next pass of every slot walks the primary rays' entry states again)
     for (uint32_t k = 0; k < slot_count(c); k++) {
         PassSlot* s = slot_at(c, k);
         compose_view(c, s);
@@ -670,7 +668,6 @@ static int refresh_blas_table(nxhip_ctx* c)
 // The matrices come from the DEVICE's instance table: nxhip_set_instance_transforms computes the inverses there.
 static int refresh_shade_inst(nxhip_ctx* c)
 {
-    c->entryGeneration++;
     const size_t n = c->hostInstances.size();
     std::vector<nx_bvh_instance> inst(n);
     NX_SYNC_ALL(c);
@@ -1028,7 +1025,6 @@ int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t 
 int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node* node)
 {
     NX_CHECK_CTX(c);
-    c->entryGeneration++;
     if (!node || blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_debug_write_blas_node: no such BLAS");
     BlasHost& b = c->blas[(size_t)blasId];
     if (nodeIdx >= b.nodeCount) return fail_invalid("nxhip_debug_write_blas_node: no such node");
@@ -1139,7 +1135,6 @@ try {
 int nxhip_rebuild_tlas(nxhip_ctx* c, const nx_bvh_instance* instances, uint32_t instanceCount)
 try {
     NX_CHECK_CTX(c);
-    c->entryGeneration++;
     if (!instances || instanceCount == 0) return fail_invalid("nxhip_rebuild_tlas: empty input");
     if (kNodeStride != 5) return fail_invalid("nxhip_rebuild_tlas: built with padded node records");
     for (uint32_t i = 0; i < instanceCount; i++)
@@ -1192,7 +1187,6 @@ try {
     int rc = upload_state(c);
     if (rc != NXHIP_OK) return rc;
     if (slot_count(c) > 1) NX_SYNC_ALL(c);  // passes on the other slots' streams still traverse the old placement
-    c->entryGeneration++;  // (the boxes the primary rays' entry states were walked through move)
     if (c->refitIds.bytes < (size_t)count * 4) NX_ALLOC(c->refitIds, (size_t)count * 4);
     if (c->refitMatrices.bytes < (size_t)count * 64) NX_ALLOC(c->refitMatrices, (size_t)count * 64);
     // stream order does the rest: a frame already in flight finishes with the old placement, the next one sees the new
@@ -1707,7 +1701,7 @@ int tail_bounce(const nxhip_ctx* c)
 // kernel is in the graph only for a scene with an environment map or a background that is not exactly black — PathTracer.cu:
 // 152-164 adds throughput x background, and +0 changes nothing), and the logic kernel's variant (one item per thread under an
 // environment map).  Part of a graph instance's key, so a change of any of them picks or builds the matching instance.
-constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4, kFlavorEntry = 8, kFlavorThin = 16, kFlavorEntryCompute = 32;
+constexpr int kFlavorScan = 1, kFlavorMissKernel = 2, kFlavorEnvMap = 4, kFlavorEntry = 8, kFlavorThin = 16;
 int pass_flavor(const nxhip_ctx* c)
 {
     int f = 0;
@@ -1746,10 +1740,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     std::vector<std::vector<Launch>> levels;
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
     const bool entry = (pass_flavor(c) & kFlavorEntry) != 0;
-    // beside the generate kernel: the entry states of the primary rays' runs (nx_entry.hip), read by the launch below — a function of the
-    // camera, the pixel set and the acceleration structures, so only the first pass of a SLOT after a change of any of them walks them
-    // (every slot once: a slot's pass then never reads a table another slot's pass is still writing other bytes into)
-    if (entry && q->entrySeen != c->entryGeneration) {
+    if (entry) {  // beside the generate kernel: the entry states of the primary rays' runs (nx_entry.hip), read by the launch below
         Launch l = make_launch(entry_state_kernel_ptr(), (int)((c->entryRuns + 63u) / 64u), 64, NXHIP_K_GENERATE, S);
         l.ptr = c->entryTable.p;
         l.count = c->entryRuns;
@@ -1759,7 +1750,7 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
     // (the dry waves of a pass's trace launches may hand their last long rays to the thin kernel: nx_trace.hip)
     const int thinFlag = (pass_flavor(c) & kFlavorThin) ? kTraceThinFlag : 0;
-    levels.push_back({make_launch((entry && !stats) ? trace_entry_kernel_ptr() : trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
+    levels.push_back({make_launch(trace_kernel_ptr(false, stats), traceBlocks, kTraceBlockThreads, NXHIP_K_TRACE, S, (entry ? kTraceEntryFlag : 0) | thinFlag)});
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
     // — each trace launch of the level gets its own, chained to it alone, so that the closest-hit rays' searches run beside whatever
     // the any-hit launch still has to do (it is the longer one of the early levels) and the other way round in the late ones
@@ -1898,8 +1889,7 @@ constexpr size_t kMaxGraphInstances = 8;
 static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
 {
     const bool serial = serial_shade(c);
-    const int blocks = trace_blocks(c, c->traceBlocks), tail = tail_bounce(c);
-    const int flavor = pass_flavor(c) | (((pass_flavor(c) & kFlavorEntry) && q->entrySeen != c->entryGeneration) ? kFlavorEntryCompute : 0);
+    const int blocks = trace_blocks(c, c->traceBlocks), tail = tail_bounce(c), flavor = pass_flavor(c);
     for (auto& g : q->graphs)
         if (g.serialShade == serial && g.traceBlocks == blocks && g.tailBounce == tail && g.flavor == flavor) {
             *execOut = g.exec;
@@ -2079,7 +2069,6 @@ try {
     if (!q->hostError) NX_HIP(hipHostMalloc((void**)&q->hostError, sizeof(uint32_t), hipHostMallocDefault));
     NX_HIP(hipMemcpyAsync(q->hostError, &q->frame.as<FrameState>()->errorWord, sizeof(uint32_t), hipMemcpyDeviceToHost, q->stream));
     q->errorFresh = true;
-    if (pass_flavor(c) & kFlavorEntry) q->entrySeen = c->entryGeneration;  // (this pass computed the entry states, or they were current)
     if (R > 1) NX_HIP(hipEventRecord(q->done, q->stream));
     q->frames = frames;
     q->frameLast = frameLast;
