@@ -15,13 +15,28 @@ COMMON    := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Inexus_amd/csrc/d
 # command line ("Unknown command line argument"), so they are probed once — an empty translation unit compiled with them — and
 # left out when the probe fails (the build then still succeeds, the kernels spill a little more: see above).
 SCHEDFLAGS := -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -amdgpu-sched-strategy=max-memory-clause
+# The probe runs only when device code is going to be compiled (not for `make clean` / `make oracle`) and only when the caller has
+# not given DEVEXTRA itself (tools/ab_bench.sh does); whether the flags went in is compiled into the library (NX_SCHED_FLAGS ->
+# nxhip_build_info() bit 1, printed by bench.py as config.build), so a run built without them cannot be mistaken for one with them.
+NX_DEVICE_GOALS := $(filter-out clean oracle,$(or $(MAKECMDGOALS),all))
+SCHED_DEF :=
+ifeq ($(origin DEVEXTRA),undefined)
+ifneq ($(NX_DEVICE_GOALS),)
 SCHED_OK   := $(shell echo '__global__ void k(){}' | $(HIPCC) -x hip --offload-arch=$(ARCH) $(SCHEDFLAGS) -c -o /dev/null - >/dev/null 2>&1 && echo yes)
 ifneq ($(SCHED_OK),yes)
 $(warning hipcc does not accept "$(SCHEDFLAGS)": building the device code without them (material kernels spill 18-21 VGPRs instead of 12-14))
 SCHEDFLAGS :=
+else
+SCHED_DEF := -DNX_SCHED_FLAGS=1
 endif
-DEVEXTRA  ?= -fno-slp-vectorize $(SCHEDFLAGS)
-DEVFLAGS  := $(COMMON) $(DEVEXTRA) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1
+endif
+DEVEXTRA  := -fno-slp-vectorize $(SCHEDFLAGS)
+else
+SCHED_DEF := $(if $(findstring amdgpu-sched-strategy,$(DEVEXTRA)),-DNX_SCHED_FLAGS=1,)
+endif
+# `make release`: the library without the nxhip_debug_* test hooks (NX_NO_DEBUG_HOOKS; the tests need the default build)
+HOOKS_DEF ?=
+DEVFLAGS  := $(COMMON) $(DEVEXTRA) --offload-arch=$(ARCH) -DNX_BUILT_FOR_GFX950=1 $(SCHED_DEF) $(HOOKS_DEF)
 HOSTFLAGS := $(COMMON)
 
 DEV_SRCS  := $(wildcard nexus_amd/csrc/device/*.hip)
@@ -47,10 +62,14 @@ $(OUT): $(DEV_OBJS) $(HOST_OBJS)
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
+# The library a product links: the same code with the nxhip_debug_* test hooks refusing (nexus_amd/lib/release/; objects of its own)
+release:
+	$(MAKE) OUT=nexus_amd/lib/release/libnexus_amd.so OBJDIR=build/release/obj HOOKS_DEF=-DNX_NO_DEBUG_HOOKS=1 all
+
 clean:
 	rm -rf build $(OUT)
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean release
 
 # Host-side AddressSanitizer + UBSan build (device code is compiled as usual; GPU ASan is not available on this pool).
 # Used by tools/run_sanitized_cpu_tests.sh; output goes to build/asan/ and never replaces the product library.

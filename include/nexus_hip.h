@@ -358,6 +358,9 @@ int nxhip_read_graph_timeline(nxhip_ctx *ctx, int32_t *klass, float *startMs, fl
 
 /* Build-time facts for tests: 1 if the library was compiled with device code for gfx950. */
 int nxhip_has_gfx950_code(void);
+/* Build facts as bits: 1 = device code for gfx950, 2 = built with the Makefile's scheduler flags, 4 = nxhip_debug_* hooks compiled in
+ * (the default; a `make release` library keeps the symbols and refuses the calls). */
+int nxhip_build_info(void);
 
 /* ---- ABI stamp ---------------------------------------------------------------------------------------
  * A library that does not match its caller — a stale build picked up through NEXUS_AMD_LIB / LD_LIBRARY_PATH, a header of

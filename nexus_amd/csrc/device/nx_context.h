@@ -96,6 +96,12 @@ struct PassSlot {
     DevBuf scanStatus;        // ordered compaction: tile status words (allocated with the queues)
     DevBuf thinLists;         // 2 x kThinListEntries queue slots: the rays the trace launches of a level hand to the thin kernel (allocated with the queues)
     uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
+    // Entry states of the primary rays' runs (nx_entry.hip), [ceil(localCount / 64)], allocated when entry points are on.  One table per
+    // SLOT: the slot's pass graph writes it (entry_state_kernel, beside generate) and the slot's own primary closest-hit launch reads
+    // it, so passes in flight never write a table another pass is reading.  Kernels find it through the slot's DeviceState (entry,
+    // entryRuns), never through a pointer fixed into a graph node.
+    DevBuf entryTable;
+    uint32_t entryRuns = 0;
     // the slot's error word as the pass left it, copied into pinned host memory behind every pass on the slot's own stream: what
     // nxhip_sync reads instead of a blocking 4-byte device read per slot (errorFresh: no launch since that could have set it)
     uint32_t* hostError = nullptr;
@@ -212,8 +218,6 @@ struct nxhip_ctx : nxd::PassSlot {
     bool thinInHooks = false;  // nxhip_debug_set_thin: the ray-batch hooks hand over and launch the thin kernel too
     bool thinJoint = false;  // NX_THIN_JOINT=1 (measurement only): one thin launch per level instead of one per trace launch
     bool thinWaves = true;  // the trace launches of a pass finish the last long rays of a dry wave cooperatively (NX_NO_THIN=1 with NX_TUNING_KNOBS=1: off)
-    bool entryPoints = false;   // nxhip_set_entry_points
-    nxd::DevBuf entryTable;     // [ceil(localCount / 64)] EntryState, allocated when entry points are on
-    uint32_t entryRuns = 0;
+    bool entryPoints = false;   // nxhip_set_entry_points (the tables: PassSlot::entryTable, one per slot)
     bool scanSeparate = false;  // NX_SCAN_SEPARATE=1 (measurement only): one material launch per type instead of one for all
 };

@@ -333,7 +333,7 @@ struct DeviceState {
     uint32_t thinCapacity;           // entries per list
     uint32_t thinLanes, thinIters;   // hand-over rule: at most thinLanes busy lanes for at least thinIters iterations (4 / 64; a test hook sets 64 / 0: every ray of a dry wave)
     uint32_t thinPoolLimit;          // items a thin wave's pool may hold before a round puts items back (0: all of it; a test hook lowers it: nxhip_debug_set_thin_pool)
-    uint32_t thinPad_;
+    uint32_t entryRuns;              // states in `entry`
 };
 
 // What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
@@ -351,7 +351,7 @@ constexpr uint64_t layout_stamp()
     const uint64_t w[] = {
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
-        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), offsetof(DeviceState, thinClosest), offsetof(DeviceState, thinCapacity), offsetof(DeviceState, thinIters), offsetof(DeviceState, thinPoolLimit), offsetof(Counters, thinCount), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), offsetof(DeviceState, entryRuns), offsetof(DeviceState, thinClosest), offsetof(DeviceState, thinCapacity), offsetof(DeviceState, thinIters), offsetof(DeviceState, thinPoolLimit), offsetof(Counters, thinCount), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(RegionCounters, scanTile), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),

@@ -180,7 +180,26 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
         constexpr int kSpecial = 0x003 | 0x004 | 0x200 | 0x020 | 0x010 | 0x080;
         if (__builtin_amdgcn_classf(cam.position[0], kSpecial) || __builtin_amdgcn_classf(cam.position[1], kSpecial) || __builtin_amdgcn_classf(cam.position[2], kSpecial)) return root;
     }
-    const double eps = 0.01;  // of a pixel: the generate kernel's float x, y and direction are within 1e-4 of a pixel of the exact ones
+    // The bundle's margin, in pixels.  generate_kernel computes a direction as (llc + vpX * x + vpY * y) - position in binary32: each
+    // component carries a few roundings of its LARGEST operand — half an ulp each for the two products, the two sums and the
+    // difference, so at most 8 x 2^-24 of M = max(|llc| + |vpX| + |vpY|, |position|) per component with room to spare — and that, over the
+    // world-space size of a pixel on the view plane, is how far the kernel's ray can lie from the exact one through its sub-pixel position.
+    // A camera near the origin: ~1e-4 pixel, the fixed 0.01 covers it (and the float x, y themselves).  A camera far from the origin with
+    // a short focus distance (position ~1e3, a view plane of a few units at 4k): tenths of a pixel — the margin follows, and beyond a
+    // quarter of a pixel the run starts at the root like a run that meets no other condition.
+    double eps = 0.01;
+    {
+        double M = 0.0, px2 = 0.0, py2 = 0.0;
+        for (int a = 0; a < 3; a++) {
+            M = fmax(M, fmax(fabs((double)cam.lowerLeftCorner[a]) + fabs((double)cam.viewportX[a]) + fabs((double)cam.viewportY[a]), fabs((double)cam.position[a])));
+            px2 += (double)cam.viewportX[a] * (double)cam.viewportX[a];
+            py2 += (double)cam.viewportY[a] * (double)cam.viewportY[a];
+        }
+        const double pixel = fmin(sqrt(px2) / (double)resX, sqrt(py2) / (double)resY);  // world-space size of a pixel on the view plane
+        if (!(pixel > 0.0)) return root;
+        eps += 1.7320508 * 8.0 * 5.9604644775390625e-8 * M / pixel;
+        if (!(eps <= 0.25)) return root;
+    }
     const double xs[4] = {((double)imin - eps) / resX, ((double)imax + 1.0 + eps) / resX, ((double)imax + 1.0 + eps) / resX, ((double)imin - eps) / resX};
     const double ys[4] = {((double)jmin - eps) / resY, ((double)jmin - eps) / resY, ((double)jmax + 1.0 + eps) / resY, ((double)jmax + 1.0 + eps) / resY};
     b.axis = D3{0.0, 0.0, 0.0};
@@ -252,14 +271,13 @@ NXD EntryState walk_run(const DeviceState* __restrict__ S, const uint32_t run)
     return st;
 }
 
-// One thread per run.  The state is computed in registers and stored ONCE: with passes in flight the kernel runs in every pass's
-// graph and rewrites the table while another pass's closest-hit launch reads it — with the same bytes (camera, scene and pixel
-// map are the same for all passes in flight: a change of any of them waits for them), so a reader can never see a mixture.
-__global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __restrict__ S, EntryState* out, const uint32_t runs)
+// One thread per run.  The table is the SLOT's own (DeviceState::entry / entryRuns of the slot whose pass graph this launch is part
+// of): written here, read by the same pass's primary closest-hit launch one level later, by nobody else.
+__global__ void __launch_bounds__(64) entry_state_kernel(const DeviceState* __restrict__ S)
 {
     const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
-    if (run >= runs) return;
-    ((NX_G EntryState*)out)[run] = walk_run(S, run);
+    if (run >= S->entryRuns || S->entry == nullptr) return;
+    S->entry[run] = walk_run(S, run);
 }
 
 const void* entry_state_kernel_ptr() { return (const void*)entry_state_kernel; }

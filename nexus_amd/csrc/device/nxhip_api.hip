@@ -166,6 +166,14 @@ static int sync_all(nxhip_ctx* c)
         if (rcSync_ != NXHIP_OK) return rcSync_;        \
     } while (0)
 
+// The nxhip_debug_* entry points exist for the tests (one of them plants a cycle in an uploaded BVH).  A `make release` library
+// (NX_NO_DEBUG_HOOKS) keeps the symbols — the header and the ABI stamp are the same — and refuses the calls.
+#ifdef NX_NO_DEBUG_HOOKS
+#define NX_DEBUG_HOOK(name) return fail_invalid(name ": this library was built without the test hooks (make release)")
+#else
+#define NX_DEBUG_HOOK(name) do { } while (0)
+#endif
+
 static void invalidate_graph(nxhip_ctx* c)
 {
     // a replay may still be executing (render calls are asynchronous): destroying its exec, graph and timing events
@@ -229,6 +237,8 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     v.thinClosest = s->thinLists.as<uint32_t>();
     v.thinAny = s->thinLists.p ? s->thinLists.as<uint32_t>() + kThinListEntries : nullptr;
     v.thinCapacity = s->thinLists.p ? kThinListEntries : 0u;
+    v.entry = (c->entryPoints && s->entryTable.p) ? s->entryTable.as<EntryState>() : nullptr;
+    v.entryRuns = v.entry ? s->entryRuns : 0u;
     // queue regions: eight, or one spanning the buffer when slots are handed out in the reference's serial order
     const bool ordered = c->h.compactMode == NX_COMPACT_ORDERED;
     v.queueShards = ordered ? 1u : (uint32_t)kQueueShards;
@@ -395,6 +405,23 @@ int nxhip_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// bit 0: device code for gfx950; bit 1: built with the Makefile's scheduler flags (SCHEDFLAGS: about 10 % on the material kernels);
+// bit 2: the nxhip_debug_* test hooks are compiled in (the default build; `make release` leaves them as stubs that refuse)
+int nxhip_build_info(void)
+{
+    int f = 0;
+#ifdef NX_BUILT_FOR_GFX950
+    f |= 1;
+#endif
+#ifdef NX_SCHED_FLAGS
+    f |= 2;
+#endif
+#ifndef NX_NO_DEBUG_HOOKS
+    f |= 4;
+#endif
+    return f;
 }
 
 int nxhip_has_gfx950_code(void)
@@ -1025,6 +1052,7 @@ int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t 
 int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node* node)
 {
     NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_write_blas_node");
     if (!node || blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_debug_write_blas_node: no such BLAS");
     BlasHost& b = c->blas[(size_t)blasId];
     if (nodeIdx >= b.nodeCount) return fail_invalid("nxhip_debug_write_blas_node: no such node");
@@ -1045,6 +1073,7 @@ int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, 
 int nxhip_debug_set_scan_epoch(nxhip_ctx* c, uint32_t epoch)
 {
     NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_set_scan_epoch");
     NX_SYNC_ALL(c);
     for (uint32_t k = 0; k < slot_count(c); k++) slot_at(c, k)->scanEpoch = std::min(epoch, kScanEpochLimit - 1u);
     return NXHIP_OK;
@@ -1716,7 +1745,7 @@ int pass_flavor(const nxhip_ctx* c)
         black = black && bits == 0u;
     }
     if (c->hdrMap.texels.p || !black) f |= kFlavorMissKernel;
-    if (c->entryPoints && c->entryTable.p) f |= kFlavorEntry;
+    if (c->entryPoints) f |= kFlavorEntry;  // (the slot's table exists before its graph is asked for: ensure_entry_table)
     // The thin kernel (nx_trace.hip) pays when ONE pass runs at a time: the lanes a dry wave leaves idle are then idle SIMD time, and
     // a level ends with its slowest ray (driver command: mean of five repetitions 19.9 -> 19.0 ms, 512 frames in 64-frame passes one at a
     // time +2.9 %).  With several passes in flight the other passes' waves fill those lanes anyway and the hand-over is extra work
@@ -1741,11 +1770,8 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     levels.push_back({make_launch(generate_kernel_ptr(), wide, wideThreads, NXHIP_K_GENERATE, S)});
     const bool entry = (pass_flavor(c) & kFlavorEntry) != 0;
     if (entry) {  // beside the generate kernel: the entry states of the primary rays' runs (nx_entry.hip), read by the launch below
-        Launch l = make_launch(entry_state_kernel_ptr(), (int)((c->entryRuns + 63u) / 64u), 64, NXHIP_K_GENERATE, S);
-        l.ptr = c->entryTable.p;
-        l.count = c->entryRuns;
-        l.nargs = 30;
-        levels.back().push_back(l);
+        // (table and count come from the slot's DeviceState: a graph node holds no pointer that a re-allocation could leave dangling)
+        levels.back().push_back(make_launch(entry_state_kernel_ptr(), (int)((q->entryRuns + 63u) / 64u), 64, NXHIP_K_GENERATE, S));
     }
     const int traceBlocks = trace_blocks(c, c->traceBlocks), shadowBlocks = trace_blocks(c, c->shadowBlocks);
     // (the dry waves of a pass's trace launches may hand their last long rays to the thin kernel: nx_trace.hip)
@@ -1872,6 +1898,11 @@ int launch_now(nxhip_ctx* c, Launch& l)
         NX_HIP(hipEventRecord(t->start, c->stream));
     }
     NX_HIP(hipLaunchKernel(l.fn, l.grid, l.block, args, 0, c->stream));
+    // Any launch outside a pass graph that can set the slot's error word (traversal / ordered-scan stall guards) makes the pinned copy
+    // the last pass left behind stale: nxhip_sync then reads the word itself.  Here, once, for every such launch — the eager timing
+    // path, the ray-batch hooks, the thin kernel behind them and whatever comes later (accumulate cannot set it and is issued after
+    // every pass: it keeps the copy fresh).
+    if (l.klass != NXHIP_K_ACCUMULATE) c->errorFresh = false;
     if (t) {
         NX_HIP(hipEventRecord(t->stop, c->stream));
         c->times.launches[l.klass]++;  // elapsed times are resolved in nxhip_read_kernel_times
@@ -1968,6 +1999,21 @@ static int pass_graph(nxhip_ctx* c, PassSlot* q, hipGraphExec_t* execOut)
 // puts behind them, e.g. the multi-GPU gather), so that no pass ever queues behind the accumulate of its predecessor.
 static PassSlot* render_slot(nxhip_ctx* c, uint32_t R, uint32_t i) { return R <= 1 ? static_cast<PassSlot*>(c) : c->extra[i].get(); }
 
+// Entry points on: slot q has a table of one state per run of 64 local pixels.  The graph instances of a slot are keyed by shape,
+// not by table size, and entry_state_kernel's grid is the run count: a slot whose run count changes drops its graphs.
+static int ensure_entry_table(nxhip_ctx* c, PassSlot* q)
+{
+    const uint32_t runs = (c->localCount + 63u) / 64u;
+    if (q->entryRuns == runs && q->entryTable.p) return NXHIP_OK;
+    NX_SYNC_ALL(c);
+    if (q->entryRuns != runs) invalidate_graph(c);
+    NX_ALLOC(q->entryTable, (size_t)std::max(1u, runs) * sizeof(EntryState));
+    NX_HIP(hipMemset(q->entryTable.p, 0, (size_t)std::max(1u, runs) * sizeof(EntryState)));  // (steps 0: "start at the root")
+    q->entryRuns = runs;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
 static int ensure_slot_events(PassSlot* q)
 {
     if (!q->done) NX_HIP(hipEventCreateWithFlags(&q->done, hipEventDisableTiming));
@@ -1987,25 +2033,18 @@ try {
         rc = refresh_shade_inst(c);
         if (rc != NXHIP_OK) return rc;
     }
-    if (c->entryPoints) {  // the entry-state table follows the pixel set (one state per run of 64 local pixels)
-        const uint32_t runs = (c->localCount + 63u) / 64u;
-        if (c->entryRuns != runs || !c->entryTable.p) {
-            NX_SYNC_ALL(c);
-            NX_ALLOC(c->entryTable, (size_t)std::max(1u, runs) * sizeof(EntryState));
-            NX_HIP(hipMemset(c->entryTable.p, 0, (size_t)std::max(1u, runs) * sizeof(EntryState)));  // (steps 0: "start at the root")
-            c->entryRuns = runs;
-            c->h.entry = c->entryTable.as<EntryState>();
-            c->stateDirty = true;
-        }
-    }
-    rc = upload_state(c);
-    if (rc != NXHIP_OK) return rc;
     // the slot this pass renders in: round robin over the passes in flight (one slot: everything on the context's stream,
     // exactly the single-pass behaviour)
     const uint32_t R = std::max(1u, effective_slots(c));
     if (c->nextSlot >= R) c->nextSlot = 0;
     PassSlot* q = render_slot(c, R, c->nextSlot);
     c->nextSlot = (c->nextSlot + 1) % R;
+    if (c->entryPoints) {  // the slot's entry-state table follows the pixel set (one state per run of 64 local pixels)
+        rc = ensure_entry_table(c, q);
+        if (rc != NXHIP_OK) return rc;
+    }
+    rc = upload_state(c);
+    if (rc != NXHIP_OK) return rc;
     if (!slot_queues_ready(c, q)) {
         rc = ensure_slot_queues(c, q);
         if (rc != NXHIP_OK) return rc;
@@ -2147,18 +2186,21 @@ int nxhip_set_entry_points(nxhip_ctx* c, int on)
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     c->entryPoints = on != 0;
-    if (!c->entryPoints) {
-        c->entryTable.release();
-        c->entryRuns = 0;
-        c->h.entry = nullptr;
-    }
-    c->stateDirty = true;  // (nxhip_render_frame allocates the table for the current pixel set and publishes it)
+    if (!c->entryPoints)
+        for (uint32_t k = 0; k < slot_count(c); k++) {
+            slot_at(c, k)->entryTable.release();
+            slot_at(c, k)->entryRuns = 0;
+        }
+    // (nxhip_render_frame allocates the rendering slot's table for the current pixel set; compose_view publishes it in the slot's
+    //  DeviceState — the pass graphs read it from there, so no graph instance can hold a freed table: ADVICE r5)
+    c->stateDirty = true;
     return NXHIP_OK;
 }
 
 int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHooks)
 {
     NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_set_thin");
     if (lanes == 0 || lanes > 64u) return fail_invalid("nxhip_debug_set_thin: lanes must be in [1, 64]");
     NX_SYNC_ALL(c);
     c->h.thinLanes = lanes;
@@ -2171,6 +2213,7 @@ int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHoo
 int nxhip_debug_set_thin_pool(nxhip_ctx* c, uint32_t slots)
 {
     NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_set_thin_pool");
     NX_SYNC_ALL(c);
     c->h.thinPoolLimit = slots;
     c->stateDirty = true;
@@ -2180,6 +2223,7 @@ int nxhip_debug_set_thin_pool(nxhip_ctx* c, uint32_t slots)
 int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
 {
     NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_thin_counts");
     if (!counts) return fail_invalid("nxhip_debug_thin_counts: null destination");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
@@ -2194,8 +2238,11 @@ int nxhip_read_entry_states(nxhip_ctx* c, void* out, uint32_t capacityRuns, uint
     if (!count) return fail_invalid("nxhip_read_entry_states: null count");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
-    *count = c->entryTable.p ? c->entryRuns : 0u;
-    if (out && c->entryTable.p) NX_HIP(hipMemcpy(out, c->entryTable.p, (size_t)std::min(capacityRuns, c->entryRuns) * sizeof(EntryState), hipMemcpyDeviceToHost));
+    // the table of the slot that rendered last (every slot's table holds the same states: camera, pixel set and scene are the context's)
+    const PassSlot* q = c->lastRendered ? c->lastRendered : static_cast<const PassSlot*>(c);
+    const bool have = c->entryPoints && q->entryTable.p;
+    *count = have ? q->entryRuns : 0u;
+    if (out && have) NX_HIP(hipMemcpy(out, q->entryTable.p, (size_t)std::min(capacityRuns, q->entryRuns) * sizeof(EntryState), hipMemcpyDeviceToHost));
     return NXHIP_OK;
 }
 

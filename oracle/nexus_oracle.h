@@ -161,6 +161,9 @@ float orc_rand(uint32_t *state);
  * Cuda/BSDF/ (all .cuh files).  conductor Eval exists only as an extension. */
 int orc_bsdf_sample(const nx_material *m, const float wi[3], uint32_t *rng, float wo[3], float throughput[3], float *pdf);
 int orc_bsdf_eval(const nx_material *m, const float wi[3], const float wo[3], float throughput[3], float *pdf);
+/* ... over arrays of the C-ABI hooks' records (include/nexus_pod.h nx_bsdf_query / nx_bsdf_result) */
+void orc_bsdf_sample_batch(const nx_material *m, const nx_bsdf_query *q, uint32_t n, nx_bsdf_result *r);
+void orc_bsdf_eval_batch(const nx_material *m, const nx_bsdf_query *q, uint32_t n, nx_bsdf_result *r);
 
 /* Software stand-in for tex2D<float4> on an sRGB, wrap, bilinear, normalised-coordinate texture. */
 void orc_tex2d(const nx_texture_desc *t, float u, float v, float out[4]);

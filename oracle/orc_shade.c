@@ -375,6 +375,28 @@ int orc_bsdf_eval(const nx_material *m, const float wi[3], const float wo[3], fl
     return ok;
 }
 
+/* The same two calls over arrays of the C-ABI hooks' query / result records (nexus_pod.h): what nxhip_bsdf_sample_batch /
+ * nxhip_bsdf_eval_batch do on the device, so that the statistical pins of tests/test_bsdf_pins.py can run a few hundred thousand
+ * queries on either side. */
+void orc_bsdf_sample_batch(const nx_material *m, const nx_bsdf_query *q, uint32_t n, nx_bsdf_result *r)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t s = q[i].rng;
+        r[i].pdf = 0.0f;
+        r[i].ok = (uint32_t)orc_bsdf_sample(m, q[i].wi, &s, r[i].wo, r[i].throughput, &r[i].pdf);
+        r[i].rngOut = s;
+    }
+}
+void orc_bsdf_eval_batch(const nx_material *m, const nx_bsdf_query *q, uint32_t n, nx_bsdf_result *r)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        r[i].pdf = 0.0f;
+        r[i].ok = (uint32_t)orc_bsdf_eval(m, q[i].wi, q[i].wo, r[i].throughput, &r[i].pdf);
+        r[i].wo[0] = q[i].wo[0]; r[i].wo[1] = q[i].wo[1]; r[i].wo[2] = q[i].wo[2];
+        r[i].rngOut = q[i].rng;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Software tex2D<float4>: normalised coordinates, wrap addressing, bilinear filter with 8-bit        */
 /* fractional weights, sRGB decode of RGB before filtering (texture descriptor: Assets/Texture.cpp:  */

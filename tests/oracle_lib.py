@@ -105,6 +105,8 @@ def lib():
         L.orc_rand.restype = C.c_float
         L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_bsdf_sample_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_bsdf_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_tex2d.argtypes = [C.POINTER(_TexDesc), C.c_float, C.c_float, C.c_void_p]
         L.orc_fmath_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_wavefront_create.argtypes = [C.POINTER(_Scene), C.c_uint32, C.c_void_p, C.c_int, C.c_int]
@@ -132,6 +134,23 @@ def fmath_batch(op, a, b=None):
     bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
     out = np.zeros(len(a), dtype=np.float64)
     lib().orc_fmath_batch(int(op), _ptr(a), None if bb is None else _ptr(bb), len(a), _ptr(out))
+    return out
+
+
+def bsdf_sample_batch(material, queries):
+    """orc_bsdf_sample over an array of pod.BSDF_QUERY_DT -> pod.BSDF_RESULT_DT (the oracle twin of capi.Context.bsdf_sample_batch)"""
+    m = np.array([material], dtype=pod.MAT_DT)
+    q = np.ascontiguousarray(queries, dtype=pod.BSDF_QUERY_DT)
+    out = np.zeros(len(q), dtype=pod.BSDF_RESULT_DT)
+    lib().orc_bsdf_sample_batch(_ptr(m), _ptr(q), len(q), _ptr(out))
+    return out
+
+
+def bsdf_eval_batch(material, queries):
+    m = np.array([material], dtype=pod.MAT_DT)
+    q = np.ascontiguousarray(queries, dtype=pod.BSDF_QUERY_DT)
+    out = np.zeros(len(q), dtype=pod.BSDF_RESULT_DT)
+    lib().orc_bsdf_eval_batch(_ptr(m), _ptr(q), len(q), _ptr(out))
     return out
 
 

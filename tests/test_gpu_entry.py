@@ -128,10 +128,80 @@ def test_a_camera_inside_the_geometry_and_axis_parallel_views(gpu_ctx_factory):
         assert np.array_equal(got_acc.view(np.uint32), base_acc.view(np.uint32))
 
 
-def test_passes_in_flight_share_the_entry_table(gpu_ctx_factory):
-    """Several passes in flight: every pass's graph rewrites the one entry table while the others' closest-hit launches read it.  The
-    kernel stores each state once, from registers (same bytes every time); a version that first stored the root's state and then the
-    walked one let a concurrent reader see a mixture (round 5: bench.py with 6 passes in flight rendered another image)."""
+def test_a_camera_far_from_the_origin_widens_the_bundle_or_starts_at_the_root(gpu_ctx_factory):
+    """generate_kernel's directions are (llc + vpX x + vpY y) - position in binary32; far from the origin with a short focus
+    distance their rounding is a good part of a pixel.  The bundle's margin follows the operands: frames stay bit-equal, and a camera
+    whose rounding exceeds a quarter of a pixel gets root states only."""
+    W, H = 256, 144
+    c = np.array((1000.0, 0.5, -800.0))
+    torus = scenegen.displaced_torus(128, 64, seed=3, major=1.0, minor=0.45, amp=0.05, center=tuple(c))
+    floor = scenegen.quad(tuple(c + (-6, -0.5, -6)), tuple(c + (-6, -0.5, 6)), tuple(c + (6, -0.5, 6)), tuple(c + (6, -0.5, -6)))
+    light = scenegen.quad(tuple(c + (-1.2, 3.5, -1.2)), tuple(c + (1.2, 3.5, -1.2)), tuple(c + (1.2, 3.5, 1.2)), tuple(c + (-1.2, 3.5, 1.2)))
+    mats = np.array([pod.make_material(pod.MAT_DIFFUSE, albedo=(0.6, 0.5, 0.4)), pod.make_material(pod.MAT_DIFFUSE, albedo=(0.7, 0.7, 0.7)),
+                     pod.make_material(pod.MAT_DIFFUSE, albedo=(0.8, 0.8, 0.8), emissive=(1.0, 1.0, 1.0), intensity=20.0)], dtype=pod.MAT_DT)
+    eye = c + (3.0, 1.5, 3.0)
+    fwd = (c - eye) / np.linalg.norm(c - eye)
+    for focus, expect_walk in ((5.0, True), (0.05, False)):
+        cam = capi.camera_init(tuple(eye), fwd, 60.0, W, H, focus, 0.0)
+        scene = SH.BuiltScene([torus, floor, light], [(i, i, workloads.IDENTITY) for i in range(3)], materials=mats, camera=cam,
+                              settings=workloads.make_settings(use_mis=True, path_length=3, background=(0.2, 0.3, 0.4), background_intensity=1.0))
+        scene.lights = SH.mesh_lights(scene.instances, scene.materials)
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+        ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
+        base, base_acc, _ = _frames(ctx, 3)
+        ctx.set_entry_points(True)
+        got, got_acc, _ = _frames(ctx, 3)
+        states = ctx.read_entry_states()
+        walked = float((states[:, 19] >= 1).mean())
+        print("focus %g: %.2f of the runs start below the root" % (focus, walked))
+        assert (walked > 0.2) if expect_walk else (walked == 0.0)
+        for k in range(3):
+            assert np.array_equal(got[k].view(np.uint32), base[k].view(np.uint32)), focus
+        assert np.array_equal(got_acc.view(np.uint32), base_acc.view(np.uint32))
+
+
+def test_on_off_on_keeps_the_states_and_the_frames(gpu_ctx_factory):
+    """on -> render -> off -> render -> on -> render.  The pass graph of the first "on" must not be replayed with the
+    table that "off" freed: the entry kernel takes table and count from the slot's DeviceState, so the third render walks the states
+    into the new table (steps > 0) and every frame equals the frame without entry points."""
+    W, H = 256, 144
+    scene = _torus_scene(W, H)
+    pm = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)
+    for in_flight in (1, 3):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+        ctx.set_pixel_map(pm)
+        ctx.set_passes_in_flight(in_flight)
+
+        def one(n=3):
+            ctx.reset_frame_number()
+            for _ in range(n):
+                ctx.render_frame()
+                ctx.accumulate()
+            return ctx.read_radiance().view(np.uint32).copy()
+
+        base = one()
+        ctx.set_entry_points(True)
+        first = one()
+        s1 = ctx.read_entry_states()
+        ctx.set_entry_points(False)
+        assert len(ctx.read_entry_states()) == 0
+        off = one()
+        ctx.set_entry_points(True)
+        again = one()
+        s2 = ctx.read_entry_states()
+        assert (s1[:, 19] >= 1).mean() > 0.4 and np.array_equal(s1, s2), "the states are walked again after off / on"
+        for got in (first, off, again):
+            assert np.array_equal(got, base), in_flight
+
+
+def test_passes_in_flight_have_their_own_entry_tables(gpu_ctx_factory):
+    """Several passes in flight: every slot's pass graph writes the slot's OWN entry table, which only that pass's primary launch
+    reads (round 5 shared one table between the slots, rewritten by every pass with identical bytes — a race that was only safe
+    while every writer stored the same bytes; an earlier two-store version rendered another image with 6 passes in flight)."""
     W, H = 320, 200
     scene = _torus_scene(W, H, nu=256, nv=128)
     pm = multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W)
