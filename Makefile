@@ -87,3 +87,9 @@ example: $(OUT)
 	$(HIPCC) -O2 -std=c++17 -Iinclude examples/nexus_render.cpp -o build/nexus_render -Lnexus_amd/lib -lnexus_amd -Wl,-rpath,'$$ORIGIN/../nexus_amd/lib'
 
 .PHONY: example
+
+# configs[1] through the kept C++ API (examples/nexus_bench.cpp): beside the library, so that it travels to the GPU box with it
+bench_example: $(OUT)
+	$(HIPCC) -O2 -std=c++17 -Iinclude examples/nexus_bench.cpp -o nexus_amd/lib/nexus_bench -Lnexus_amd/lib -lnexus_amd -Wl,-rpath,'$$ORIGIN'
+
+.PHONY: bench_example

@@ -47,6 +47,9 @@ public:
     // Primary rays start from the traversal state the first node steps of their run of 64 paths provably share instead of the TLAS
     // root (nxhip_set_entry_points: hit records unchanged, pinhole cameras only).  Off by default.
     void SetEntryPoints(bool on);
+    // The order of the frame's paths: NXHIP_ORDER_ROWS (the reference's, default) or NXHIP_ORDER_TILES (8 x 8 pixel tiles: the rays a
+    // wave fetches together are a compact block of the image; kept across OnResize).  nxhip_set_pixel_order.
+    void SetPixelOrder(int order);
     // Multi-GPU extension (no counterpart in the reference): one PathTracer per GPU, each renders and
     // accumulates the interleaved row tiles of its rank; Render() then ends with ONE RCCL gather of the accumulated tiles to
     // rank 0, whose GetPixelBuffer() returns the full frame.  `id128`: the 128 bytes rank 0 obtained from

@@ -34,7 +34,7 @@ enum {
 };
 
 /* Bumped whenever an entry point changes its signature or meaning, or a struct of this header / nexus_pod.h its layout. */
-#define NXHIP_API_VERSION 6
+#define NXHIP_API_VERSION 7
 
 /* Thread-local message of the last failing call (replaces CheckCudaErrors -> exit(99), Utils/Utils.cpp:3-12). */
 const char *nxhip_last_error(void);
@@ -142,6 +142,15 @@ int nxhip_set_modes(nxhip_ctx *ctx, int rngMode, int compactMode, int conductorM
 /* Multi-GPU tile split: this context renders `localCount` pixels; pixelMap[i] = global pixel index of local
  * pixel i (NULL: identity over width*height).  Re-allocates the queues for localCount paths. */
 int nxhip_set_pixel_map(nxhip_ctx *ctx, const uint32_t *pixelMap, uint32_t localCount);
+/* The order of the context's paths over the FULL frame (no tile split): NXHIP_ORDER_ROWS = image rows, the reference's (thread k of
+ * GenerateKernel is pixel k: PathTracer.cu:85-100) and the default; NXHIP_ORDER_TILES = 8 x 8 pixel tiles, row-major inside a
+ * tile, tiles left to right in bands of eight rows — the 64 primary rays a wave fetches together are then a compact block of the
+ * image instead of a 64 x 1 strip (coherent node fetches, and what entry points need: nxhip_set_entry_points).  With the
+ * pixel-keyed RNG the image does not depend on it.  Equivalent to nxhip_set_pixel_map with the map nxhip_tile_pixel_map(width,
+ * height, 1, 0, 1, order, ...) returns; unlike a caller's map the ORDER is kept across nxhip_resize.  A later nxhip_set_pixel_map /
+ * nxhip_mgpu_init replaces it. */
+enum { NXHIP_ORDER_ROWS = 0, NXHIP_ORDER_TILES = 1 };
+int nxhip_set_pixel_order(nxhip_ctx *ctx, int order);
 
 /* Batch `frames` consecutive frames into one pass of the wavefront (default 1 = the reference's one frame per
  * Render()).  Every queue then holds localCount * frames paths, so each kernel launch carries `frames` times the work:

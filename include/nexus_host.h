@@ -95,6 +95,8 @@ int nxs_scene_set_hdr_map(nxs_scene *s, const uint8_t *rgba8, uint32_t w, uint32
 int nxs_scene_add_mesh(nxs_scene *s, const nx_triangle *tris, uint32_t triCount, int32_t materialId, int32_t *meshId);
 int nxs_scene_create_instance(nxs_scene *s, uint32_t meshId, int32_t materialId, const float pos[3], const float rotDeg[3],
                               const float scale[3], int32_t *instanceId);
+/* MeshInstance::AssignMaterial + Scene::InvalidateMeshInstance (the viewer's material picker): applied by the next nxs_scene_update. */
+int nxs_scene_assign_material(nxs_scene *s, uint32_t instanceId, int32_t materialId);
 /* MeshInstance::SetTransform + Scene::InvalidateMeshInstance: move an existing instance; applied by the next nxs_scene_update. */
 int nxs_scene_set_instance_transform(nxs_scene *s, uint32_t instanceId, const float pos[3], const float rotDeg[3], const float scale[3]);
 /* Extension (off by default): refit the TLAS in nxs_scene_update when only existing instances changed, instead of the
@@ -119,6 +121,9 @@ int nxs_pathtracer_set_modes(nxs_pathtracer *p, int rngMode, int compactMode, in
  * Render() calls in flight */
 int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer *p, uint32_t frames);
 int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer *p, uint32_t passes);
+/* PathTracer::SetPixelOrder / SetEntryPoints (extensions): NXHIP_ORDER_* of the frame's paths; primary rays from their run's entry state */
+int nxs_pathtracer_set_pixel_order(nxs_pathtracer *p, int order);
+int nxs_pathtracer_set_entry_points(nxs_pathtracer *p, int on);
 /* PathTracer::SetDeviceBlasBuild (extension, off by default): meshes added to `s` from now on get their BVH8 from the device
  * builder (nxhip_build_blas) instead of the host's; switch it off, or destroy the scene, before `p` goes away. */
 int nxs_pathtracer_set_device_blas_build(nxs_pathtracer *p, nxs_scene *s, int enable);

@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_build_info", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
+    "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_build_info", "nxhip_set_pixel_order", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_set_entry_points", "nxhip_read_entry_states", "nxhip_debug_set_thin", "nxhip_debug_set_thin_pool", "nxhip_debug_thin_counts", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
@@ -38,10 +38,10 @@ HOST_SYMBOLS = [
     "nxs_renderer_save_screenshot", "nxs_renderer_save_exr", "nxs_renderer_frame_number", "nxs_renderer_megasamples_per_second", "nxs_renderer_device_context",
     "nxs_renderer_set_modes",
     "nxh_load_scene_file", "nxh_loaded_scene_free", "nxh_loaded_mesh_count", "nxh_loaded_mesh_triangle_count", "nxh_loaded_mesh_triangles",
-    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_set_tlas_refit", "nxs_scene_set_device_tlas", "nxs_pathtracer_set_device_blas_build",
+    "nxh_loaded_material_count", "nxh_loaded_materials", "nxh_loaded_instance_count", "nxh_loaded_instances", "nxs_scene_load_file", "nxs_scene_set_instance_transform", "nxs_scene_assign_material", "nxs_scene_set_tlas_refit", "nxs_scene_set_device_tlas", "nxs_pathtracer_set_device_blas_build",
     "nxs_last_error", "nxs_scene_create", "nxs_scene_destroy", "nxs_scene_add_material", "nxs_scene_add_texture", "nxs_scene_set_hdr_map",
     "nxs_scene_add_mesh", "nxs_scene_create_instance", "nxs_scene_set_camera", "nxs_scene_set_render_settings", "nxs_scene_update",
-    "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes", "nxs_pathtracer_set_frames_per_pass", "nxs_pathtracer_set_passes_in_flight",
+    "nxs_scene_light_count", "nxs_scene_instance_count", "nxs_pathtracer_create", "nxs_pathtracer_destroy", "nxs_pathtracer_set_modes", "nxs_pathtracer_set_frames_per_pass", "nxs_pathtracer_set_passes_in_flight", "nxs_pathtracer_set_pixel_order", "nxs_pathtracer_set_entry_points",
     "nxs_pathtracer_update_device_scene", "nxs_pathtracer_render", "nxs_pathtracer_reset_frame_number", "nxs_pathtracer_frame_number",
     "nxs_pathtracer_read_pixels", "nxs_pathtracer_device_context",
 ]
@@ -72,7 +72,7 @@ class KernelTimes(C.Structure):
 
 KERNEL_CLASSES = ("generate", "trace", "shadow", "logic", "shade", "accumulate", "thin")
 
-API_VERSION = 6  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
+API_VERSION = 7  # NXHIP_API_VERSION of the include/nexus_hip.h these bindings were written against
 
 
 def abi_words():
@@ -527,6 +527,12 @@ class Context:
             check(self.L.nxhip_set_pixel_map(self.h, _ptr(pm), len(pm)), "nxhip_set_pixel_map")
             self.local_count = len(pm)
 
+    def set_pixel_order(self, order):
+        """nxhip_set_pixel_order: ORDER_ROWS (0, the reference's) or ORDER_TILES (1: 8 x 8 pixel tiles) over the full frame"""
+        self.L.nxhip_set_pixel_order.argtypes = [C.c_void_p, C.c_int]
+        check(self.L.nxhip_set_pixel_order(self.h, int(order)), "nxhip_set_pixel_order")
+        self.local_count = self.width * self.height
+
     def build_blas(self, tris):
         """BLAS built on the device (binned SAH + SAH-DP collapse by default, see set_device_builder); returns the BLAS id"""
         t = np.ascontiguousarray(tris, dtype=pod.TRI_DT)
@@ -925,6 +931,10 @@ class Scene:
         p, r, sc = (np.asarray(x, np.float32) for x in (position, rotation_deg, scale))
         _scheck(self.L.nxs_scene_set_instance_transform(self.h, instance_id, _ptr(p), _ptr(r), _ptr(sc)), "nxs_scene_set_instance_transform")
 
+    def assign_material(self, instance_id, material_id):
+        self.L.nxs_scene_assign_material.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
+        _scheck(self.L.nxs_scene_assign_material(self.h, instance_id, material_id), "nxs_scene_assign_material")
+
     def set_tlas_refit(self, enable=True):
         _scheck(self.L.nxs_scene_set_tlas_refit(self.h, 1 if enable else 0), "nxs_scene_set_tlas_refit")
 
@@ -1073,6 +1083,14 @@ class PathTracer:
 
     def set_passes_in_flight(self, passes):
         _scheck(self.L.nxs_pathtracer_set_passes_in_flight(self.h, passes), "nxs_pathtracer_set_passes_in_flight")
+
+    def set_pixel_order(self, order):
+        self.L.nxs_pathtracer_set_pixel_order.argtypes = [C.c_void_p, C.c_int]
+        _scheck(self.L.nxs_pathtracer_set_pixel_order(self.h, int(order)), "nxs_pathtracer_set_pixel_order")
+
+    def set_entry_points(self, on=True):
+        self.L.nxs_pathtracer_set_entry_points.argtypes = [C.c_void_p, C.c_int]
+        _scheck(self.L.nxs_pathtracer_set_entry_points(self.h, 1 if on else 0), "nxs_pathtracer_set_entry_points")
 
     def set_device_blas_build(self, scene, enable=True):
         """PathTracer::SetDeviceBlasBuild: meshes added to `scene` from now on are built into BVH8s on the GPU"""

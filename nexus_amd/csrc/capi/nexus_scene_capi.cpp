@@ -103,6 +103,15 @@ int nxs_scene_create_instance(nxs_scene* s, uint32_t meshId, int32_t materialId,
     });
 }
 
+int nxs_scene_assign_material(nxs_scene* s, uint32_t instanceId, int32_t materialId)
+{
+    return guarded([&] {
+        if (instanceId >= s->scene.GetMeshInstances().size()) throw std::runtime_error("nxs_scene_assign_material: no such instance");
+        s->scene.GetMeshInstances()[instanceId].AssignMaterial(materialId);
+        s->scene.InvalidateMeshInstance(instanceId);
+    });
+}
+
 int nxh_load_scene_file(const char* file, nxh_loaded_scene** out)
 {
     return guarded([&] {
@@ -261,6 +270,8 @@ int nxs_pathtracer_set_modes(nxs_pathtracer* p, int rngMode, int compactMode, in
 }
 int nxs_pathtracer_set_frames_per_pass(nxs_pathtracer* p, uint32_t frames) { return guarded([&] { p->pt.SetFramesPerPass(frames); }); }
 int nxs_pathtracer_set_passes_in_flight(nxs_pathtracer* p, uint32_t passes) { return guarded([&] { p->pt.SetPassesInFlight(passes); }); }
+int nxs_pathtracer_set_pixel_order(nxs_pathtracer* p, int order) { return guarded([&] { p->pt.SetPixelOrder(order); }); }
+int nxs_pathtracer_set_entry_points(nxs_pathtracer* p, int on) { return guarded([&] { p->pt.SetEntryPoints(on != 0); }); }
 int nxs_pathtracer_set_device_blas_build(nxs_pathtracer* p, nxs_scene* s, int enable)
 {
     return guarded([&] { p->pt.SetDeviceBlasBuild(s->scene, enable != 0); });

@@ -218,6 +218,7 @@ struct nxhip_ctx : nxd::PassSlot {
     bool thinInHooks = false;  // nxhip_debug_set_thin: the ray-batch hooks hand over and launch the thin kernel too
     bool thinJoint = false;  // NX_THIN_JOINT=1 (measurement only): one thin launch per level instead of one per trace launch
     bool thinWaves = true;  // the trace launches of a pass finish the last long rays of a dry wave cooperatively (NX_NO_THIN=1 with NX_TUNING_KNOBS=1: off)
+    int pixelOrder = 0;         // nxhip_set_pixel_order: NXHIP_ORDER_* of the full frame, re-applied by nxhip_resize (a caller's own map is not)
     bool entryPoints = false;   // nxhip_set_entry_points (the tables: PassSlot::entryTable, one per slot)
     bool scanSeparate = false;  // NX_SCAN_SEPARATE=1 (measurement only): one material launch per type instead of one for all
 };

@@ -190,7 +190,7 @@ static_assert(sizeof(Eval) == 8, "one 8-byte word per entry");
 // its kernel tests a leaf's triangles in an inner loop.  In THIS trace kernel a triangle record costs a whole loop iteration, exactly like
 // a node (nx_trace.hip: one record per iteration), so the device builder's collapse prices it higher: 0.75, the winner of the sweep
 // 0.3 / 0.5 / 0.75 / 1.0 / 1.5 on configs[1], [3], [4] (profiles/r06_prim_cost_sweep.txt: driver command +2.7 %, configs[3] +1.2 %,
-// configs[4] -0.8 %; 1.0 and above lose 3.6 % on configs[4]).  The host builder and the oracle keep the reference's 0.3: their trees are
+// configs[4] -0.8 %; 1.0 and above lose 3.6 % on configs[4]).  The host builder (and the tests' CPU restatement) keep the reference's 0.3: their trees are
 // compared byte for byte with the reference's algorithm; the parity tests of device-built trees read the tree back, so they hold.
 constexpr float kCostPrimDevice = 0.75f, kCostNode = 1.0f;
 static float blas_prim_cost()

@@ -854,6 +854,14 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             if (!STATS && kThinCode && thinAllowed && ((exhausted && rngCur >= rngEnd) || thinIters == 0u) && activeMask != 0ull && __popcll(activeMask) <= thinLanes && spins >= thinAfter) {
                 // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
                 // a wave on each of them; this wave is done
+#ifdef NX_THIN_DROP
+                // BOUND EXPERIMENT (wrong results): the rays a hand-over rule would give away simply end here — closest hit with what they
+                // have found so far, any hit as occluded — so that the launch's time is what ANY hand-over, however fast, could reach
+                // at most (tools/ab_prebuilt.sh drop+NX_THIN_LANES=..+NX_THIN_ITERS=..)
+                if (active) { active = false; resultPending = !ANY_HIT; }
+                activeMask = 0ull;
+                thinAllowed = false;
+#else
                 NX_G int* const count = &C->thinCount[ANY_HIT ? 1 : 0][bounce];
                 int base = 0;
                 const int leader = __ffsll((long long)activeMask) - 1, n = (int)__popcll(activeMask);
@@ -872,6 +880,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
 #ifdef NX_WAVE_TIMELINE
                 wpHanded = n;
 #endif
+#endif  // NX_THIN_DROP
             }
         } while (activeMask != 0ull && ((exhausted && rngCur >= rngEnd) || __popcll(activeMask) >= kRefillBelow));
         itersTotal += spins;

@@ -787,7 +787,13 @@ NXD void shade_path(const DeviceState* S, const int bounce, const uint32_t frame
     uint32_t rng = seed_for(S, seedSlot, pixelIdx, (uint32_t)bounce, 1u, frame);
 
     const NX_G ShadeInst* inst = &S->shadeInst[instanceIdx];
+#ifdef NX_SHADE_SEQ_TRI
+    // BOUND EXPERIMENT (wrong results): every item reads the shading triangle of its QUEUE SLOT instead of its hit's —
+    // consecutive items, consecutive 96-byte records — so that what is left of the material launch is everything but the random gather
+    const NX_G nx_triangle* tri = shade_tri(inst->tris, seedSlot % max(inst->triCount, 1u));
+#else
     const NX_G nx_triangle* tri = shade_tri(inst->tris, triIdx);
+#endif
     const nx_material material = inst->material;
     MatParams mp = load_params(material);
     const NX_G float* T = inst->transform;

@@ -644,7 +644,11 @@ int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
     c->pixelMap.release();
     c->h.pixelMap = nullptr;
     c->stateDirty = true;
-    return set_frame_number_device(c, 0);
+    const int rcFrame = set_frame_number_device(c, 0);
+    if (rcFrame != NXHIP_OK) return rcFrame;
+    // (the ORDER of the full frame survives a resize; a caller's own pixel map does not: it was made for the old size)
+    if (c->pixelOrder != NXHIP_ORDER_ROWS) return nxhip_set_pixel_order(c, c->pixelOrder);
+    return NXHIP_OK;
 }
 
 // ---- scene upload -----------------------------------------------------------------------------------
@@ -1543,6 +1547,7 @@ int nxhip_set_pixel_map(nxhip_ctx* c, const uint32_t* pixelMap, uint32_t localCo
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     const uint32_t full = c->width * c->height;
+    c->pixelOrder = NXHIP_ORDER_ROWS;  // (a caller's own map, or none: nxhip_set_pixel_order sets it again behind its own call)
     // the queues are re-allocated first (all or nothing): a failure leaves the previous pixel set, map and queues in place
     if (!pixelMap) {
         const int rc = alloc_paths(c, full);
@@ -1564,6 +1569,27 @@ int nxhip_set_pixel_map(nxhip_ctx* c, const uint32_t* pixelMap, uint32_t localCo
     c->h.pixelMap = c->pixelMap.as<uint32_t>();
     c->stateDirty = true;
     return set_frame_number_device(c, 0);
+}
+
+int nxhip_set_pixel_order(nxhip_ctx* c, int order)
+try {
+    NX_CHECK_CTX(c);
+    if (order != NXHIP_ORDER_ROWS && order != NXHIP_ORDER_TILES) return fail_invalid("nxhip_set_pixel_order: order must be NXHIP_ORDER_ROWS or NXHIP_ORDER_TILES");
+    if (order == NXHIP_ORDER_ROWS) {
+        const int rc = nxhip_set_pixel_map(c, nullptr, 0);
+        if (rc == NXHIP_OK) c->pixelOrder = order;
+        return rc;
+    }
+    std::vector<uint32_t> map((size_t)c->width * c->height);
+    uint32_t n = 0;
+    int rc = nxhip_tile_pixel_map(c->width, c->height, 1, 0, 1, 1, map.data(), &n);
+    if (rc != NXHIP_OK) return rc;
+    rc = nxhip_set_pixel_map(c, map.data(), n);
+    if (rc == NXHIP_OK) c->pixelOrder = order;
+    return rc;
+} catch (const std::exception& e) {
+    set_error(std::string("nxhip_set_pixel_order: ") + e.what());
+    return NXHIP_ERR_INVALID;
 }
 
 // ---- rendering --------------------------------------------------------------------------------------

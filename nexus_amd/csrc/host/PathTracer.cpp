@@ -209,6 +209,11 @@ void PathTracer::SetFramesPerPass(uint32_t frames)
 void PathTracer::SetPassesInFlight(uint32_t passes) { Check(nxhip_set_passes_in_flight(m_Ctx, passes), "nxhip_set_passes_in_flight"); }
 void PathTracer::SetTailBounce(uint32_t bounce) { Check(nxhip_set_tail_bounce(m_Ctx, bounce), "nxhip_set_tail_bounce"); }
 void PathTracer::SetEntryPoints(bool on) { Check(nxhip_set_entry_points(m_Ctx, on ? 1 : 0), "nxhip_set_entry_points"); }
+void PathTracer::SetPixelOrder(int order)
+{
+    Check(nxhip_set_pixel_order(m_Ctx, order), "nxhip_set_pixel_order");
+    m_FrameNumber = 0;  // (a new pixel set starts the accumulation over, as OnResize does)
+}
 
 void PathTracer::Render(const Scene&)
 {

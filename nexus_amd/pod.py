@@ -100,6 +100,7 @@ LIGHT_POINT, LIGHT_AREA, LIGHT_MESH = 0, 1, 2
 RNG_REFERENCE_SLOT, RNG_PIXEL_KEYED = 0, 1
 COMPACT_FAST, COMPACT_ORDERED = 0, 1
 CONDUCTOR_REFERENCE, CONDUCTOR_EXTENDED = 0, 1
+ORDER_ROWS, ORDER_TILES = 0, 1  # nxhip_set_pixel_order
 PATH_MAX_LENGTH = 100
 # include/nexus_fmath.h NXF_OP_*: the shared transcendental functions, by number (double: 0-6; float, carried in doubles: 7-12)
 NXF_OPS = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "pow": 4, "atan2": 5, "asin": 6, "sinf": 7, "cosf": 8, "expf": 9, "logf": 10, "atan2f": 11, "asinf": 12}

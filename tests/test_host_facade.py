@@ -61,6 +61,72 @@ def test_facade_frame_equals_direct_capi_frame(gpu_ctx_factory):
 
 
 @pytest.mark.gpu
+def test_the_benched_configuration_through_the_facade_equals_the_ctypes_path(gpu_ctx_factory, tmp_path):
+    """bench.py's headline settings — configs[1]'s scene read from a Wavefront .obj by OBJLoader, BLASes and TLAS
+    built on the device, pixel-keyed random numbers, extended conductor, 8 x 8 pixel tiles (nxhip_set_pixel_order: the order comes from
+    the LIBRARY now, not from Python), entry points, several frames per Render() call — rendered through nexus::Scene / PathTracer
+    give the RGBA8 image the ctypes path gives for workloads.config2 built in memory.  (examples/nexus_bench.cpp is this call
+    sequence in C++; bench.py --through-facade times it.)"""
+    from nexus_amd import multigpu, workloads
+
+    W, H, nu, nv, frames = 256, 144, 96, 48, 4
+    want_scene = workloads.config2(W, H, nu, nv, 5, cls=SH.BuiltScene)
+    loaders.write_obj(str(tmp_path / "mesh.obj"), want_scene.meshes[0])
+
+    sc = capi.Scene(W, H)
+    pt = capi.PathTracer(W, H)
+    pt.set_device_blas_build(sc, True)
+    sc.set_device_tlas(True)
+    sc.load_file(str(tmp_path) + "/", "mesh.obj")  # mesh 0, its default material, instance 0
+    mats = want_scene.materials
+    ids = [sc.add_material(m) for m in mats]
+    floor_id = sc.add_mesh(want_scene.meshes[1], ids[1])
+    light_id = sc.add_mesh(want_scene.meshes[2], ids[2])
+    sc.create_instance(floor_id, ids[1])
+    sc.create_instance(light_id, ids[2])
+    sc.assign_material(0, ids[0])
+    eye = np.array((0.0, 3.3, 4.9))
+    fwd = np.array((0.0, 0.35, 0.0)) - eye  # (workloads._look: normalised in binary64, rounded by the binding)
+    sc.set_camera(tuple(eye), tuple(fwd / np.linalg.norm(fwd)), 52.0, 5.0, 0.0)
+    sc.set_render_settings(want_scene.settings)
+    sc.update()
+    assert sc.instance_count() == 3 and sc.light_count() == 1
+    pt.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    pt.set_pixel_order(pod.ORDER_TILES)
+    pt.set_entry_points(True)
+    pt.set_frames_per_pass(frames)
+    pt.update_device_scene(sc)
+    for _ in range(3):
+        pt.render(sc)
+    assert pt.frame_number() == 3 * frames
+    got = pt.read_pixels()
+    pt.set_device_blas_build(sc, False)
+    pt.close()
+
+    ctx = gpu_ctx_factory(W, H)
+    want_scene.upload(ctx, device_bvh=True, device_tlas=True)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))  # (the Python twin of the library's order)
+    ctx.set_entry_points(True)
+    ctx.set_frames_per_pass(frames)
+    ctx.reset_frame_number()
+    for _ in range(3):
+        ctx.render_frame()
+        ctx.accumulate()
+    want = ctx.read_rgba8()
+    assert np.array_equal(got, want), "%d of %d pixels differ" % (int((got != want).sum()), got.size)
+    # ... and nxhip_set_pixel_order gives the very map the Python helper computes
+    ctx.set_pixel_order(pod.ORDER_TILES)
+    ctx.set_frames_per_pass(frames)
+    ctx.reset_frame_number()
+    for _ in range(3):
+        ctx.render_frame()
+        ctx.accumulate()
+    assert np.array_equal(ctx.read_rgba8(), want)
+    assert np.array_equal(capi.tile_pixel_map(W, H, 1, 0, 1, tiled=True), multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
+
+
+@pytest.mark.gpu
 def test_facade_small_pass_measures_do_not_change_the_image():
     """PathTracer::SetFramesPerPass / SetPassesInFlight (and the tail kernel that small keyed passes use by default): six
     frames as six Render() calls, as three calls of two frames, and with three calls in flight — the same pixels."""
