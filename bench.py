@@ -100,7 +100,7 @@ def build_workload(args):
         name = ("configs[1]: seeded displaced torus %d triangles (BVH8 %d nodes) + floor + quad light, %dx%d, pathLength %d, conductor(extended)+diffuse, MIS/NEE on"
                 % (sc.triangles, sc.bvh8_nodes, args.width, args.height, args.path_length))
     elif args.config == 4:
-        sc = workloads.config4(args.width, args.height, args.path_length)
+        sc = workloads.config4(args.width, args.height, args.path_length, split_levels=int(os.environ.get("NX_PROBE_SPLIT_LEVELS", "0")))  # (probe: workloads.split_by_octants)
         sc.env_sampling = True  # configs[3] asks for "HDR envmap NEE/MIS": the extension of nxhip_set_env_sampling
         name = ("configs[3]: %d instances of a %d-triangle BLAS (BVH8 %d nodes) on a jittered lattice, random rotations / scales, DIELECTRIC roughness 0.2 ior 1.45, "
                 "2048x1024 procedural environment with NEE / MIS importance sampling (extension), %dx%d, pathLength %d"
@@ -478,7 +478,7 @@ def main():
             return t_local
     else:
         if args.pixel_order == "tiles":
-            ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W))
+            ctx.set_pixel_order(pod.ORDER_TILES)  # (the library's own 8 x 8 tile order: what a C++ caller gets from PathTracer::SetPixelOrder)
         ctx.set_frames_per_pass(S)
         if R > 1:
             ctx.set_passes_in_flight(R)
@@ -589,7 +589,7 @@ def main():
         # back to the full frame for the roofline section below
         S, R = S_full, R_full
         sync()
-        ctx.set_pixel_map(multigpu.tiled_order(np.arange(W * H, dtype=np.uint32), W) if args.pixel_order == "tiles" else None)
+        ctx.set_pixel_order(pod.ORDER_TILES if args.pixel_order == "tiles" else pod.ORDER_ROWS)
         ctx.set_frames_per_pass(S)
         ctx.set_passes_in_flight(max(R, 1))
 

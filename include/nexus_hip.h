@@ -30,7 +30,8 @@ enum {
     NXHIP_ERR_HIP = 2,     /* a HIP runtime call failed */
     NXHIP_ERR_NO_DEVICE = 3,
     NXHIP_ERR_TRAVERSAL = 4, /* a trace kernel gave up on rays that made no progress (malformed BVH): reported by nxhip_sync and the read-backs */
-    NXHIP_ERR_ABI = 5        /* caller and library (or the library's own translation units) disagree about a struct layout / the API version */
+    NXHIP_ERR_ABI = 5,       /* caller and library (or the library's own translation units) disagree about a struct layout / the API version */
+    NXHIP_ERR_TIMEOUT = 6    /* nxhip_sync_timeout gave up waiting: the context is DEAD from then on (every later call returns this) */
 };
 
 /* Bumped whenever an entry point changes its signature or meaning, or a struct of this header / nexus_pod.h its layout. */
@@ -50,6 +51,12 @@ void nxhip_destroy(nxhip_ctx *ctx);
 /* PathTracer::OnResize — PathTracer.cpp:290-303 (frees and re-allocates queues, resets the frame number) */
 int nxhip_resize(nxhip_ctx *ctx, uint32_t width, uint32_t height);
 int nxhip_sync(nxhip_ctx *ctx);
+/* nxhip_sync with a wall-clock limit (milliseconds).  The reference waits for the device without one and a kernel that never ends hangs
+ * the viewer (CheckCudaErrors only sees launches that RETURN: Utils/Utils.cpp:3-12, Renderer/PathTracer.cpp:280-284).  Polls the
+ * context's streams; work done in time: as nxhip_sync.  Otherwise NXHIP_ERR_TIMEOUT and the context is marked DEAD: nothing can be
+ * said about the device's state, every later call on it returns NXHIP_ERR_TIMEOUT without touching the device (nxhip_destroy frees
+ * the host side only); the caller reports and exits, or starts a fresh process — there is no in-process recovery from a hung GPU. */
+int nxhip_sync_timeout(nxhip_ctx *ctx, uint32_t timeoutMs);
 
 /* ---- scene upload -------------------------------------------------------------------------------- */
 
@@ -313,6 +320,10 @@ int nxhip_debug_write_blas_node(nxhip_ctx *ctx, int32_t blasId, uint32_t nodeIdx
  * viewer at a thousand one-frame passes per second gets there in 17 minutes — where the words are cleared in stream order and
  * the count starts over.  The test sets it just below the limit and renders across the wrap. */
 int nxhip_debug_set_scan_epoch(nxhip_ctx *ctx, uint32_t epoch);
+/* Test hook: the trace kernels hand the same rays out again and again (a ray that re-queues itself — what an in-kernel restart did in
+ * round 5 until the host's watchdog ended the process).  The per-launch progress check must end every such launch with
+ * NXHIP_ERR_TRAVERSAL from nxhip_sync within milliseconds. */
+int nxhip_debug_set_requeue(nxhip_ctx *ctx, int on);
 
 /* Kernel-level test hooks for the shading functions (same role as nxhip_trace_batch for the traversal): run the device
  * BSDF sample / eval (the headers of Cuda/BSDF/ as restated in nx_bsdf.h) and the software texture fetch on host arrays.

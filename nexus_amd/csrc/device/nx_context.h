@@ -94,6 +94,7 @@ struct PassSlot {
     DevBuf mqHit[4], mqDirInst[4], mqTp[4];
     DevBuf counters, frame, dState;
     DevBuf scanStatus;        // ordered compaction: tile status words (allocated with the queues)
+    DevBuf thinStates;        // 2 x kThinListEntries ThinState: the traversal state of every listed ray
     DevBuf thinLists;         // 2 x kThinListEntries queue slots: the rays the trace launches of a level hand to the thin kernel (allocated with the queues)
     uint32_t scanEpoch = 0;   // passes begun in this slot since the status words were last cleared
     // Entry states of the primary rays' runs (nx_entry.hip), [ceil(localCount / 64)], allocated when entry points are on.  One table per
@@ -218,6 +219,7 @@ struct nxhip_ctx : nxd::PassSlot {
     bool thinInHooks = false;  // nxhip_debug_set_thin: the ray-batch hooks hand over and launch the thin kernel too
     bool thinJoint = false;  // NX_THIN_JOINT=1 (measurement only): one thin launch per level instead of one per trace launch
     bool thinWaves = true;  // the trace launches of a pass finish the last long rays of a dry wave cooperatively (NX_NO_THIN=1 with NX_TUNING_KNOBS=1: off)
+    bool dead = false;          // nxhip_sync_timeout gave up: no further device work is issued or waited for
     int pixelOrder = 0;         // nxhip_set_pixel_order: NXHIP_ORDER_* of the full frame, re-applied by nxhip_resize (a caller's own map is not)
     bool entryPoints = false;   // nxhip_set_entry_points (the tables: PassSlot::entryTable, one per slot)
     bool scanSeparate = false;  // NX_SCAN_SEPARATE=1 (measurement only): one material launch per type instead of one for all

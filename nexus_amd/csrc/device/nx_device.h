@@ -167,6 +167,21 @@ constexpr int kTraceThinFlag = 0x400;
 // level its own thin launch, so that the closest-hit rays' searches run beside whatever the any-hit launch still has to do)
 constexpr int kThinClosestOnly = 0x800, kThinAnyOnly = 0x1000;
 
+// The traversal state of a ray a dry trace wave hands to thin_kernel (nx_trace.hip, round 6): everything the loop keeps per lane at its
+// loop top, so that the wave-wide search CONTINUES the ray instead of starting it again at the TLAS root — the stack's groups and the
+// two current ones become the search's first work items, the hit found so far its bound.  (The ray itself is read from its queue slot;
+// inside a transformed instance the search derives the ray in that frame from the instance record, as it does for any item.)
+struct alignas(16) ThinState {
+    uint2 ng, tg;            // the current node group / primitive group (loop top)
+    float hitT, hitU, hitV;  // closest hit so far (1e30: none); any hit: hitT = the ray's tmax, the rest unused
+    uint32_t hitTri, hitInst;
+    int32_t sp, instSp;      // stack entries; entries [0, instSp) belong to the TLAS frame (instSp < 0: the ray is in the TLAS frame)
+    uint32_t leaf;           // instSp >= 0: the instance record (TLAS leaf) the ray is inside
+    uint32_t pad_[4];
+    uint2 stack[32];         // kLdsDepth + kSpillDepth entries, bottom first
+};
+static_assert(sizeof(ThinState) == 320 && offsetof(ThinState, stack) == 64, "64-byte header + 32 stack entries");
+
 // Entry state of a run of 64 consecutive primary paths (nx_entry.hip).  The 64 rays of an 8 x 8 pixel tile visit the same nodes
 // with the same hit masks for their first ~4 of ~10 node steps (tools/entry_point_probe.py) — the same arithmetic done 64 times
 // for one answer.  entry_state_kernel walks those steps ONCE per run with a conservative test of the run's whole ray bundle
@@ -248,6 +263,9 @@ struct FrameState {
     uint32_t pad_[3];
 };
 constexpr uint32_t kErrTraversalStalled = 1u;
+// a trace wave was handed more rays than its launch's queue holds: rays come back into the queue they were taken from (round 5's in-kernel
+// restart did that and ran to the host's watchdog: gpurun_out/r5_10 — the per-refill iteration count cannot see a wave that keeps retiring and re-taking)
+constexpr uint32_t kErrRaysRetaken = 4u;
 constexpr uint32_t kErrScanStalled = 2u;  // a workgroup of the ordered compaction gave up waiting for a predecessor tile (never seen; the guard turns a hang into a status)
 // Ordered compaction, status word of a tile and queue: {tag = launch serial << 2 | state, value}.  The launch serial (pass epoch,
 // bounce, kernel kind) makes words of earlier launches read as "not there yet", so the array is never cleared between launches.
@@ -326,6 +344,8 @@ struct DeviceState {
     NX_G FrameState* frame;
     NX_G TraceStatsDev* traceStats;  // [0] closest, [1] shadow
     NX_G unsigned long long* scanStatus;  // [tiles of the largest queue][kScanWords]: ordered compaction (nx_wavefront.hip OrderedScan)
+    const NX_G uint32_t* leafOfInstance;  // [instanceCount]: the TLAS leaf (= index of the InstTrav record) of every instance
+    NX_G ThinState* thinStates;      // [2][thinCapacity] (closest hit, any hit): the traversal state that goes with entry k of the lists below
     NX_G EntryState* entry;          // [ceil(localCount / 64)]: entry states of the primary rays' runs, nullptr: off (nxhip_set_entry_points)
     // the last long rays of dry trace waves, handed to thin_kernel (nx_trace.hip): queue slots (closest hit: | roulette bit 31)
     NX_G uint32_t* thinClosest;
@@ -334,6 +354,7 @@ struct DeviceState {
     uint32_t thinLanes, thinIters;   // hand-over rule: at most thinLanes busy lanes for at least thinIters iterations (4 / 64; a test hook sets 64 / 0: every ray of a dry wave)
     uint32_t thinPoolLimit;          // items a thin wave's pool may hold before a round puts items back (0: all of it; a test hook lowers it: nxhip_debug_set_thin_pool)
     uint32_t entryRuns;              // states in `entry`
+    uint32_t debugRequeue;           // test hook (nxhip_debug_set_requeue): the trace kernels hand the same rays out again and again — a ray that re-queues itself (see kErrRaysRetaken)
 };
 
 // What a translation unit of the library believes about the device-resident structures and the compile-time knobs that shape
@@ -351,7 +372,7 @@ constexpr uint64_t layout_stamp()
     const uint64_t w[] = {
         sizeof(DeviceState), offsetof(DeviceState, camera), offsetof(DeviceState, envSampling), offsetof(DeviceState, localCount), offsetof(DeviceState, pixelMap),
         offsetof(DeviceState, radiance), offsetof(DeviceState, trace), offsetof(DeviceState, shadow), offsetof(DeviceState, material), offsetof(DeviceState, counters),
-        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), offsetof(DeviceState, entryRuns), offsetof(DeviceState, thinClosest), offsetof(DeviceState, thinCapacity), offsetof(DeviceState, thinIters), offsetof(DeviceState, thinPoolLimit), offsetof(Counters, thinCount), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
+        offsetof(DeviceState, frame), offsetof(DeviceState, traceStats), offsetof(DeviceState, scanStatus), offsetof(DeviceState, entry), offsetof(DeviceState, entryRuns), offsetof(DeviceState, debugRequeue), offsetof(DeviceState, thinStates), offsetof(DeviceState, leafOfInstance), sizeof(ThinState), offsetof(ThinState, stack), offsetof(DeviceState, thinClosest), offsetof(DeviceState, thinCapacity), offsetof(DeviceState, thinIters), offsetof(DeviceState, thinPoolLimit), offsetof(Counters, thinCount), sizeof(EntryState), offsetof(EntryState, sp), offsetof(Counters, scanTicket), offsetof(FrameState, scanEpoch),
         (uint64_t)kScanKinds, (uint64_t)kScanWords, (uint64_t)kScanEpochLimit, (uint64_t)kShadeBlockOrderedThreads,
         sizeof(Counters), sizeof(RegionCounters), offsetof(RegionCounters, traceShadowSize), offsetof(RegionCounters, materialSize), offsetof(RegionCounters, traceHead),
         offsetof(RegionCounters, shadowHead), offsetof(RegionCounters, scanTile), offsetof(Counters, orderedBase), offsetof(Counters, tailHead),

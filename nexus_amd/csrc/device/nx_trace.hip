@@ -100,6 +100,7 @@ struct ThinResult {
     float second;     // closest hit: the second smallest distance seen (3e38: none)
     float window;     // ... and how far above t a second one makes the result depend on the visiting order
     float gate;       // closest hit: the largest computed entry distance of the boxes on the found triangle's path from the root (see thin_wave_search)
+    bool replaced;    // closest hit, continued ray: a triangle closer than the hit the ray arrived with was found
     bool complete;    // the whole tree was searched
     uint32_t rounds;  // rounds of the search
     int poolMax;      // most items the pool held
@@ -108,8 +109,11 @@ struct ThinResult {
 // Searches ray (o, d) with the whole wave.  `bound`: closest hit — the ray's current hit distance (triangles at t <= bound count);
 // any hit — its tmax (a triangle at 0 < t < bound occludes).  `pool`: kPoolSlots LDS entries of the wave's own.
 // Everything in the result is wave-uniform.
+// `seed` (round 6): the state the ray was handed over with — the search then continues it: its first work items are the groups of the
+// ray's stack and its two current groups instead of the TLAS root, its bound and (closest hit) its best triangle so far the ray's own.
 template <bool ANY_HIT>
-NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* const pool, lds_f32* const poolGate, const f3 o, const f3 d, const float bound, const bool sceneIdentity)
+NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* const pool, lds_f32* const poolGate, const f3 o, const f3 d, const float bound, const bool sceneIdentity,
+                                const NX_G ThinState* const seed = nullptr)
 {
     GU4 tlasNodes = S->tlasNodes;
     const NX_G InstTrav* instTrav = S->instTrav;
@@ -121,9 +125,63 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
     r.t = bound; r.u = 0.0f; r.v = 0.0f; r.tri = 0xffffffffu; r.inst = 0xffffffffu; r.count = 0; r.second = 3.0e38f; r.complete = true;
     const float magnitude = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.window = ANY_HIT ? 0.0f : 1.0e-3f * (fminf(bound, 1.0e30f) + magnitude);
-    r.rounds = 0u; r.poolMax = 1; r.gate = 0.0f;
+    r.rounds = 0u; r.poolMax = 1; r.gate = 0.0f; r.replaced = false;
     int n = 1;  // items in the pool (uniform)
-    if (lane == 0) { pool[0] = (unsigned long long)kItemNode << 62; if (!ANY_HIT) poolGate[0] = 0.0f; }  // the TLAS root
+    if (seed == nullptr) {
+        if (lane == 0) { pool[0] = (unsigned long long)kItemNode << 62; if (!ANY_HIT) poolGate[0] = 0.0f; }  // the TLAS root
+    } else {
+        // The ray's remaining work, as the loop would have taken it up: stack entry k (lane k), the current node group (lane sp) and the
+        // current primitive group (lane sp + 1).  A node group's hit bits (24-31, octant-permuted) name inner children by slot; a
+        // primitive group's bits (0-23) name primitives from its base: instances in the TLAS frame, triangles in an instance's.
+        // Entries below instSp were pushed before the ray entered its instance: TLAS frame.  Every seed's gate is 0: the boxes above it
+        // were entered by the ray itself — the loop never tests them again either (a popped group is visited unconditionally).
+        const uint4 cur = *(const NX_G uint4*)&seed->ng;
+        const uint4 hh = *(const NX_G uint4*)&seed->hitInst;  // hitInst, sp, instSp, leaf
+        const int sp = min(max((int)hh.y, 0), kLdsDepth + kSpillDepth), instSp = (int)hh.z;
+        const uint32_t inFrame = instSp >= 0 ? hh.w + 1u : 0u;
+        uint2 e = make_uint2(0u, 0u);
+        bool nodeGroup = false;
+        uint32_t frame = inFrame;
+        if (lane < sp) {
+            e = seed->stack[lane];
+            nodeGroup = (e.y & 0xff000000u) != 0u;
+            if (instSp < 0 || lane < instSp) frame = 0u;
+        } else if (lane == sp) { e = make_uint2(cur.x, cur.y); nodeGroup = true; }
+        else if (lane == sp + 1) e = make_uint2(cur.z, cur.w);
+        uint32_t bits = nodeGroup ? (e.y >> 24) : (e.y & 0x00ffffffu);
+        const int mine = __popc(bits);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        n = __builtin_amdgcn_readlane(incl, kWave - 1);  // at most 34 groups x 24 < kPoolLimit
+        int w = incl - mine;
+        const uint32_t imask = e.y & 0xffu;
+        while (bits) {
+            const int b = 31 - __clz((int)bits);
+            bits &= ~(1u << b);
+            unsigned long long item;
+            if (nodeGroup) {
+                const int slot = b ^ (int)(invOct4 & 7u);
+                const uint32_t rel = (uint32_t)__popc(imask & ~(0xffffffffu << slot));
+                item = ((unsigned long long)((kItemNode << 30) | frame) << 32) | (unsigned long long)(e.x + rel);
+            } else {
+                const uint32_t tag = frame == 0u ? (kItemInst << 30) : ((kItemTri << 30) | frame);
+                item = ((unsigned long long)tag << 32) | (unsigned long long)(e.x + (uint32_t)b);
+            }
+            pool[w] = item;
+            if (!ANY_HIT) poolGate[w] = 0.0f;
+            w++;
+        }
+        r.poolMax = n;
+        if (!ANY_HIT) {
+            const uint4 hit = *(const NX_G uint4*)&seed->hitT;
+            r.t = __uint_as_float(hit.x);  // (the caller passes it as `bound` too)
+            if (hit.w != 0xffffffffu) { r.count = 1; r.u = __uint_as_float(hit.y); r.v = __uint_as_float(hit.z); r.tri = hit.w; r.inst = hh.x; }
+        }
+    }
     // the frame the wave derived last (see below; uniform): 0 = none yet
     uint32_t cFrame = 0u, cInst = 0u;
     GU4 cNodes = tlasNodes;
@@ -324,6 +382,7 @@ NXD ThinResult thin_wave_search(const DeviceState* __restrict__ S, lds_u64* cons
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m2 = fminf(m2, __shfl_xor(m2, off));
             if (r.count == 0 || m < r.t) {
+                r.replaced = true;
                 r.second = r.count ? fminf(r.t, m2) : m2;
                 r.t = m;
                 r.u = __shfl(cu, winner);
@@ -366,11 +425,15 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
     const bool entryLaunch = !ANY_HIT && (bounceArg & kTraceEntryFlag) != 0 && S->entry != nullptr;
     // ... | kTraceThinFlag: the last long rays of a dry wave may be handed to the thin kernel (below)
     bool thinAllowed = !STATS && kThinCode && (bounceArg & kTraceThinFlag) != 0;
-    const int thinLanes = (int)S->thinLanes;
+    const int thinLanes = (int)(S->thinLanes & 0xffu);
+    // (test hook, nxhip_debug_set_thin inHooks bit 1: hand over after thinIters iterations of EVERY stretch between two refill points, dry
+    //  queue or not — rays then arrive at the thin kernel with the state of exactly that many steps)
+    const bool thinAnyTime = (S->thinLanes >> 31) != 0u;
     const uint32_t thinIters = S->thinIters;
     uint32_t itersTotal = 0u, taken = 0u, thinAfter = thinIters;  // (wave-uniform: loop iterations and rays of this wave so far)
     const NX_G EntryState* const entryTable = S->entry;
     const int raySet = (bounceArg & kTraceScanFlag) ? (bounce & 1) : 0;
+    const bool requeue = S->debugRequeue != 0u;  // (nxhip_debug_set_requeue; scalar)
     __shared__ unsigned long long ldsStack[kLdsDepth * kTraceBlock];
     // the world-space ray (origin, direction, 1 / direction) of a lane that is inside a transformed instance: parked here on
     // entry and taken back on exit.  (Re-reading the ray from its queue on exit put a second, dependent memory round trip
@@ -691,8 +754,23 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                         }
                     }
                 }
-                rngCur += min(__popcll(needMask), avail);
+                // (the test hook — a wave-uniform scalar — leaves the range where it is: the same rays go out again at the next refill)
+                rngCur += requeue ? 0 : min(__popcll(needMask), avail);
                 taken += (uint32_t)min(__popcll(needMask), avail);
+#ifndef NX_NO_STALL_GUARD
+                // Progress per LAUNCH: a wave cannot be handed more rays than the queue holds.  One that is holds rays that come back into
+                // the queue — every one of them retires, so the iteration guard below, which counts between two refill points, never
+                // fires.  Same ending: the rays in hand are abandoned, the wave takes no more, the host gets NXHIP_ERR_TRAVERSAL.
+                if (taken > (uint32_t)size) {
+                    if (lane == 0) atomicOr(&S->frame->errorWord, kErrRaysRetaken);
+                    active = false;  // (the rays in hand end without a record of this visit: the launch's results are void, the status says so)
+                    resultPending = false;
+                    need = false;
+                    exhausted = true;
+                    rngCur = rngEnd = 0;
+                    break;
+                }
+#endif
             }
         }
         unsigned long long activeMask = __ballot(active);
@@ -851,7 +929,7 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 rngCur = rngEnd = 0;
             }
 #endif
-            if (!STATS && kThinCode && thinAllowed && ((exhausted && rngCur >= rngEnd) || thinIters == 0u) && activeMask != 0ull && __popcll(activeMask) <= thinLanes && spins >= thinAfter) {
+            if (!STATS && kThinCode && thinAllowed && ((exhausted && rngCur >= rngEnd) || thinIters == 0u || thinAnyTime) && activeMask != 0ull && __popcll(activeMask) <= thinLanes && spins >= thinAfter) {
                 // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
                 // a wave on each of them; this wave is done
 #ifdef NX_THIN_DROP
@@ -870,13 +948,28 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
                 const int place = base + (int)__popcll(activeMask & laneLt);
                 if (active && place < (int)S->thinCapacity) {  // (every entry below min(count, capacity) is written)
                     (ANY_HIT ? S->thinAny : S->thinClosest)[place] = rayIdx;
+                    // ... with the lane's loop-top state: the thin kernel continues the ray from here (ThinState, nx_device.h)
+                    NX_G ThinState* st = S->thinStates + (size_t)(ANY_HIT ? (int)S->thinCapacity : 0) + (size_t)place;
+                    *(NX_G uint4*)&st->ng = make_uint4(ng.x, ng.y, tg.x, tg.y);
+                    *(NX_G uint4*)&st->hitT = make_uint4(__float_as_uint(hitT), __float_as_uint(hitU), __float_as_uint(hitV), hitTri);
+                    // (the ray's instance record, by the instance it is inside of: its index rides in instIdx below the material code)
+                    const uint32_t leaf = instSp >= 0 ? S->leafOfInstance[instIdx & kHitInstMask] : 0u;
+                    *(NX_G uint4*)&st->hitInst = make_uint4(hitInst, (uint32_t)sp, (uint32_t)instSp, leaf);
+                    for (int k = 0; k < min(sp, kLdsDepth + kSpillDepth); k++) {  // (entries beyond the 32nd were dropped by stack_push, as in the reference)
+                        uint2 e;
+                        if (k < kLdsDepth) {
+                            const unsigned long long v = stackLds[k * kTraceBlock];
+                            e = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                        } else e = stackSpill[k - kLdsDepth];
+                        st->stack[k] = e;
+                    }
                     active = false;
                 }
                 activeMask = __ballot(active);
                 // (once per wave; lanes the list had no room for: this wave finishes them itself.  The test hook's rule — thinIters 0 —
                 //  hands over after EVERY refill as long as the list has room, so that nearly all rays of a batch go through the search
                 //  however the waves share the queue)
-                if (thinIters != 0u || base + n > (int)S->thinCapacity) thinAllowed = false;
+                if ((thinIters != 0u && !thinAnyTime) || base + n > (int)S->thinCapacity) thinAllowed = false;
 #ifdef NX_WAVE_TIMELINE
                 wpHanded = n;
 #endif
@@ -955,7 +1048,10 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
             const uint32_t slot = word & 0x7fffffffu;
             const float4 o = S->trace.rays[raySet].rayO[slot], d = S->trace.rays[raySet].rayD[slot];
             const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
-            ThinResult r = thin_wave_search<false>(S, pool, poolGate, org, dir, 1e30f, sceneIdentity);
+            // (round 6) the ray arrives with its traversal state: the search continues it — the stack's groups are its first items, the
+            // hit found so far its bound — instead of starting again at the root with no bound at all
+            const NX_G ThinState* st = S->thinStates + e;
+            ThinResult r = thin_wave_search<false>(S, pool, poolGate, org, dir, st->hitT, sceneIdentity, st);
             // Is the closest triangle found (computed distance t, the smallest of all the ray's triangles) what the reference's order
             // returns?  It is, if that order TESTS it: nothing tested can replace it (acceptance is `t < hit distance`, strictly,
             // on computed numbers — equal distances: the first met wins, so a second triangle at exactly t is left to the replay
@@ -971,7 +1067,15 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
             // a microsecond each: the 100-230 us of every thin launch.)  The window still bounds the SEARCH (boxes up to t + window are
             // opened), so that those second triangles are seen: it is thousands of roundings wide, a gate exceeds t by one or two.
             const float gate = r.gate == r.gate ? r.gate : 3.0e38f;  // (a NaN entry distance never passes child_trace's test; belt and braces)
-            const bool ambiguous = r.count != 0 && (r.second == r.t || (gate > r.t && r.second <= gate));
+            // A continued ray: what the loop would go on to do from the handed-over state is test SOME of the remaining triangles in its
+            // order, each against the hit distance of the moment, which starts at the carried hit's.  (i) No remaining triangle in
+            // front of the carried hit (`replaced` false): nothing can be accepted (`t < hit distance`, strictly: a triangle AT the
+            // carried distance loses to the one met first) — the carried hit is the result, no second distance matters.  (ii) A
+            // remaining triangle at the smallest distance t in front of it: the argument above, with the carried distance among the
+            // "distances of triangles accepted earlier" — it is: `second` starts from it when the first closer triangle is found
+            // (thin_wave_search), so a gate above t with the carried hit at or below the gate sends the ray to the replay.  The seeds'
+            // own gate is 0: the loop visits a popped group without testing its box again.
+            const bool ambiguous = r.count != 0 && r.replaced && (r.second == r.t || (gate > r.t && r.second <= gate));
 #ifdef NX_THIN_PRINTF
             if (lane == 0 && (e == 0 || r.rounds >= 24u || !r.complete || ambiguous)) printf("thin closest bounce %d list %d ray %d rounds %u pool %d complete %d ambiguous %d t %g gate %g second %g\n", bounce, nClosest, e, r.rounds, r.poolMax, (int)r.complete, (int)ambiguous, r.t, r.gate, r.second);
 #endif
@@ -999,7 +1103,7 @@ __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __
             const uint32_t slot = S->thinAny[e - nClosest];
             const float4 o = S->shadow.rayO[slot], d = S->shadow.rayD[slot];
             const f3 org = mk3(o.x, o.y, o.z), dir = mk3(d.x, d.y, d.z);
-            const ThinResult r = thin_wave_search<true>(S, pool, poolGate, org, dir, o.w, sceneIdentity);
+            const ThinResult r = thin_wave_search<true>(S, pool, poolGate, org, dir, o.w, sceneIdentity, S->thinStates + (size_t)cap + (size_t)(e - nClosest));
             bool occluded = r.count != 0;
 #ifdef NX_THIN_PRINTF
             if (lane == 0 && (e == nClosest || r.rounds >= 24u || !r.complete)) printf("thin any bounce %d list %d ray %d rounds %u pool %d complete %d occluded %d\n", bounce, nAny, e - nClosest, r.rounds, r.poolMax, (int)r.complete, (int)occluded);

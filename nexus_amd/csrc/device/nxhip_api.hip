@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -94,6 +95,10 @@ using namespace nxd;
         if (!(ctx)) {                          \
             set_error("null context");         \
             return NXHIP_ERR_INVALID;          \
+        }                                      \
+        if ((ctx)->dead) {                     \
+            set_error("the context is dead: nxhip_sync_timeout gave up waiting for the device (see include/nexus_hip.h)"); \
+            return NXHIP_ERR_TIMEOUT;          \
         }                                      \
     } while (0)
 
@@ -201,7 +206,7 @@ static size_t queue_region_cap(size_t n) { return ((n + kQueueShards * 64 - 1) /
 static size_t queue_buffer_slots(size_t n) { return queue_region_cap(n) * kQueueShards; }
 // entries per list of rays handed to the thin kernel (nx_trace.hip): a launch hands over at most DeviceState::thinLanes (4) rays per wave, 20 480 for a
 // full grid; a list that runs over only makes the waves it has no room for finish their rays themselves
-constexpr uint32_t kThinListEntries = 1u << 16;
+constexpr uint32_t kThinListEntries = 1u << 15;  // (x 2 lists x (4 B + a 320-byte ThinState) = 21 MB per slot)
 static size_t scan_status_tiles(size_t n) { return n / (size_t)std::min(kLogicBlockThreads, kShadeBlockThreads) + 2; }
 
 // Which pipeline a pass runs (nx_wavefront.hip): SCAN — the logic step's decision rides in the hit records and the material kernels
@@ -236,7 +241,8 @@ static void compose_view(nxhip_ctx* c, PassSlot* s)
     v.scanStatus = s->scanStatus.as<unsigned long long>();
     v.thinClosest = s->thinLists.as<uint32_t>();
     v.thinAny = s->thinLists.p ? s->thinLists.as<uint32_t>() + kThinListEntries : nullptr;
-    v.thinCapacity = s->thinLists.p ? kThinListEntries : 0u;
+    v.thinCapacity = (s->thinLists.p && s->thinStates.p) ? kThinListEntries : 0u;
+    v.thinStates = s->thinStates.as<ThinState>();
     v.entry = (c->entryPoints && s->entryTable.p) ? s->entryTable.as<EntryState>() : nullptr;
     v.entryRuns = v.entry ? s->entryRuns : 0u;
     // queue regions: eight, or one spanning the buffer when slots are handed out in the reference's serial order
@@ -287,12 +293,15 @@ static int alloc_slot_queues(nxhip_ctx* c, PassSlot* q, size_t n)
     NX_HIP(hipMemset(freshStatus.p, 0, statusBytes));
     DevBuf freshThin;  // (contents: whatever the trace launches of a level write before the thin kernel of that level reads)
     if (!freshThin.alloc((size_t)2 * kThinListEntries * sizeof(uint32_t))) return NXHIP_ERR_HIP;
+    DevBuf freshThinStates;  // (entry k of a list and state k belong together: the wave that writes one writes the other)
+    if (!freshThinStates.alloc((size_t)2 * kThinListEntries * sizeof(ThinState))) return NXHIP_ERR_HIP;
     NX_HIP(hipMemset(fresh[0].p, 0, n * 16));  // radiance
     NX_HIP(hipMemset(fresh[1].p, 0, n * 16));  // the paths' previous vertices: a read of an entry nobody has written yet is at least deterministic
     NX_SYNC_ALL(c);                            // nothing in flight may still use the old buffers
     for (int i = 0; i < kCount; i++) *slots[i] = std::move(fresh[i]);
     q->scanStatus = std::move(freshStatus);
     q->thinLists = std::move(freshThin);
+    q->thinStates = std::move(freshThinStates);
     q->scanEpoch = 0;
     q->pathCapacity = n;
     q->queuesScan = scan;
@@ -318,6 +327,7 @@ static void release_slot_queues(nxhip_ctx* c, PassSlot* q)
     for (DevBuf* b : bufs) b->release();
     q->scanStatus.release();
     q->thinLists.release();
+    q->thinStates.release();
     q->pathCapacity = 0;
     if (q == static_cast<PassSlot*>(c)) {
         DeviceState& h = c->h;
@@ -558,6 +568,16 @@ void nxhip_destroy(nxhip_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->dead) {
+        // nxhip_sync_timeout gave up on this context.  If the device has finished after all, everything below is safe; if it still has
+        // not, waiting for it (stream synchronisation, hipFree) would hang the caller: the context's device memory stays where it is
+        // until the process ends — which is what the caller of a timed-out context is about to do.
+        bool busy = false;
+        for (uint32_t k = 0; k < slot_count(c); k++)
+            if (slot_at(c, k)->stream && hipStreamQuery(slot_at(c, k)->stream) != hipSuccess) busy = true;
+        if (busy) return;
+        c->dead = false;
+    }
     (void)sync_all(c);
     (void)nxhip_mgpu_shutdown(c);
     invalidate_graph(c);
@@ -606,6 +626,10 @@ static int check_device_errors(nxhip_ctx* c)
         set_error("a workgroup of the ordered compaction gave up waiting for the tile before it (internal error)");
         return NXHIP_ERR_HIP;
     }
+    if (any & kErrRaysRetaken) {
+        set_error("a trace wave was handed more rays than its launch's queue holds: rays re-enter the queue they were taken from (internal error)");
+        return NXHIP_ERR_TRAVERSAL;
+    }
     if (any & kErrTraversalStalled) {
         set_error("a trace kernel abandoned rays that made no progress for millions of iterations: the uploaded or device-built BVH is not a tree");
         return NXHIP_ERR_TRAVERSAL;
@@ -619,6 +643,30 @@ int nxhip_sync(nxhip_ctx* c)
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
     return check_device_errors(c);
+}
+
+int nxhip_sync_timeout(nxhip_ctx* c, uint32_t timeoutMs)
+{
+    NX_CHECK_CTX(c);
+    NX_HIP(hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool busy = false;
+        for (uint32_t k = 0; k < slot_count(c); k++) {
+            PassSlot* s = slot_at(c, k);
+            if (!s->stream) continue;
+            const hipError_t e = hipStreamQuery(s->stream);
+            if (e == hipErrorNotReady) busy = true;
+            else if (e != hipSuccess) NX_HIP(e);
+        }
+        if (!busy) return check_device_errors(c);
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= (double)timeoutMs) {
+            c->dead = true;
+            set_error("nxhip_sync_timeout: the device did not finish within " + std::to_string(timeoutMs) + " ms; the context is dead (exit, or continue in a fresh process)");
+            return NXHIP_ERR_TIMEOUT;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 int nxhip_resize(nxhip_ctx* c, uint32_t width, uint32_t height)
@@ -1156,6 +1204,7 @@ try {
         NX_HIP(hipMemcpy(c->refitOrder.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         NX_HIP(hipMemcpy(c->refitLevelStart.p, levelStart.data(), levelStart.size() * 4, hipMemcpyHostToDevice));
         NX_HIP(hipMemcpy(c->leafOfInstance.p, leafOf.data(), leafOf.size() * 4, hipMemcpyHostToDevice));
+        c->h.leafOfInstance = c->leafOfInstance.as<uint32_t>();  // (also what a handed-over ray names its instance record by: ThinState::leaf)
         c->refitLevels = maxDepth + 1;
         c->tlasNodeCount = nodeCount;
     }
@@ -2229,9 +2278,19 @@ int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHoo
     NX_DEBUG_HOOK("nxhip_debug_set_thin");
     if (lanes == 0 || lanes > 64u) return fail_invalid("nxhip_debug_set_thin: lanes must be in [1, 64]");
     NX_SYNC_ALL(c);
-    c->h.thinLanes = lanes;
+    c->h.thinLanes = lanes | ((inHooks & 2) ? 0x80000000u : 0u);  // (bit 31: hand over at any time, see nx_trace.hip)
     c->h.thinIters = iters;
-    c->thinInHooks = inHooks != 0;
+    c->thinInHooks = (inHooks & 1) != 0;
+    c->stateDirty = true;
+    return NXHIP_OK;
+}
+
+int nxhip_debug_set_requeue(nxhip_ctx* c, int on)
+{
+    NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_set_requeue");
+    NX_SYNC_ALL(c);
+    c->h.debugRequeue = on ? 1u : 0u;
     c->stateDirty = true;
     return NXHIP_OK;
 }

@@ -208,7 +208,23 @@ def procedural_sky(width=2048, height=1024):
     return out
 
 
-def config4(width=1920, height=1080, path_length=8, n_side=10, nu=250, nv=200, cls=Workload):
+def split_by_octants(mesh, levels):
+    """PROBE (instance opening): the mesh cut into 8^levels parts by the octant of each triangle's centroid in the
+    bounding box of its part — what a TLAS whose leaves enter an instance's BLAS below its root would see, built from existing pieces
+    (every part a BLAS of its own, every placement repeated per part)."""
+    parts = [mesh]
+    for _ in range(levels):
+        nxt = []
+        for m in parts:
+            c = (m["pos0"].astype(np.float64) + m["pos1"] + m["pos2"]) / 3.0
+            mid = 0.5 * (c.min(0) + c.max(0))
+            key = (c[:, 0] > mid[0]) * 4 + (c[:, 1] > mid[1]) * 2 + (c[:, 2] > mid[2]) * 1
+            nxt += [m[key == k] for k in range(8) if np.any(key == k)]
+        parts = nxt
+    return parts
+
+
+def config4(width=1920, height=1080, path_length=8, n_side=10, nu=250, nv=200, cls=Workload, split_levels=0):
     """configs[3]: one 2*nu*nv-triangle BLAS (seed 2) instanced n_side^3 times on a jittered lattice with random rotations
     and scales (seed 3), DIELECTRIC roughness 0.2 ior 1.45, procedural 2048x1024 equirectangular environment.  The
     reference adds the environment on a miss only (PathTracer.cu:152-164); no environment NEE."""
@@ -222,7 +238,11 @@ def config4(width=1920, height=1080, path_length=8, n_side=10, nu=250, nv=200, c
                 placements.append((0, 0, capi.mat4_from_trs(pos, rng.uniform(0, 360, 3), rng.uniform(0.6, 1.3, 3))))
     mats = np.array([pod.make_material(pod.MAT_DIELECTRIC, albedo=(0.95, 0.97, 1.0), roughness=0.2, ior=1.45)], dtype=pod.MAT_DT)
     ext = n_side * 1.6
-    return cls([mesh], placements, materials=mats, camera=_look((ext * 0.9, ext * 0.55, ext * 1.25), (0, 0, 0), 45.0, width, height),
+    meshes = [mesh]
+    if split_levels:
+        meshes = split_by_octants(mesh, split_levels)
+        placements = [(k, 0, xf) for (_, _, xf) in placements for k in range(len(meshes))]
+    return cls(meshes, placements, materials=mats, camera=_look((ext * 0.9, ext * 0.55, ext * 1.25), (0, 0, 0), 45.0, width, height),
                settings=make_settings(use_mis=True, path_length=path_length, background=(1, 1, 1), background_intensity=1.0),
                hdr_map=procedural_sky(), build_threads=0)
 

@@ -229,6 +229,73 @@ def test_a_bvh_that_is_not_a_tree_ends_in_an_error_status_not_in_a_hang(gpu_ctx_
     ctx.sync()
 
 
+def test_rays_that_requeue_themselves_end_in_a_status_within_seconds(gpu_ctx_factory):
+    """VERDICT r5 item 7, from the failure in hand (gpurun_out/r5_10: an in-kernel restart whose rays came back into the queue ran to the
+    host's 150 s watchdog): every such ray RETIRES, so the iteration count between two refill points never reaches its limit.  The
+    per-launch check — a wave cannot be handed more rays than the queue holds — ends the launch; nxhip_sync reports
+    NXHIP_ERR_TRAVERSAL once; frames and ray batches work again afterwards."""
+    import time
+
+    import numpy as np
+    from nexus_amd import pod, scenegen
+    from tests import scene_helpers as SH
+
+    scene = SH.cornell_scene(128, 128, path_length=4)
+    ctx = gpu_ctx_factory(128, 128)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_REFERENCE)
+    rays = scenegen.interior_rays(20000, seed=2, extent=0.9)
+    rays["origin"][:, 1] += 1.0
+    want = scene.oracle().trace_closest(rays)
+    ctx.set_frames_per_pass(4)
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    ctx.accumulate()
+    good = ctx.read_accumulation()
+    ctx.debug_set_requeue(True)
+    t0 = time.time()
+    ctx.trace_batch(rays)  # (results void)
+    with pytest.raises(capi.NexusError, match="re-enter the queue"):
+        ctx.sync()
+    ctx.reset_frame_number()
+    ctx.render_frame()     # a whole pass of such launches
+    with pytest.raises(capi.NexusError, match="status 4"):
+        ctx.sync_timeout(20000)
+    assert time.time() - t0 < 5.0, "seconds, not the host's watchdog"
+    ctx.sync()  # reported once
+    ctx.debug_set_requeue(False)
+    assert SH.hit_records_equal(ctx.trace_batch(rays), want)
+    ctx.reset_frame_number()
+    ctx.render_frame()
+    ctx.accumulate()
+    ctx.sync()
+    assert np.array_equal(ctx.read_accumulation().view(np.uint32), good.view(np.uint32))
+
+
+def test_sync_with_a_wall_clock_limit_marks_the_context_dead():
+    """nxhip_sync_timeout: work that finishes in time -> as nxhip_sync; a limit that expires -> NXHIP_ERR_TIMEOUT (status 6), every later
+    call on the context answers with the same status without touching the device, closing it is safe.  (The expiry is provoked with
+    a limit of 0 ms on a pass that takes tens of milliseconds — a real hang is not something to stage on a shared GPU.)"""
+    from nexus_amd import pod, workloads
+    from tests import scene_helpers as SH
+
+    W, H = 512, 512
+    scene = workloads.config2(W, H, 128, 64, 8, cls=SH.BuiltScene)
+    ctx = capi.Context(W, H)
+    scene.upload(ctx)
+    ctx.set_modes(pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED)
+    ctx.set_frames_per_pass(64)
+    ctx.render_frame()
+    ctx.sync_timeout(30000)  # in time
+    ctx.render_frame()
+    with pytest.raises(capi.NexusError, match="status 6"):
+        ctx.sync_timeout(0)
+    for call in (ctx.render_frame, ctx.sync, ctx.accumulate, lambda: ctx.sync_timeout(1000)):
+        with pytest.raises(capi.NexusError, match="status 6"):
+            call()
+    ctx.close()  # (the pass has long finished by now: a normal teardown; a context whose device never answers keeps its memory)
+
+
 def test_released_queues_come_back_with_the_next_render(gpu_ctx_factory):
     """nxhip_release_queues (PathTracer::FreeDeviceBuffers): the image, the scene and the frame count survive, rendering and
     the ray-batch hook allocate again on demand; the same holds for the slots of passes in flight."""
