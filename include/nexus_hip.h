@@ -199,9 +199,11 @@ int nxhip_set_entry_points(nxhip_ctx *ctx, int on);
  * then int32 sp, instSp, leafSlot, steps) — a test hook: how many node steps the walk saved per run.  *count = number of runs. */
 int nxhip_read_entry_states(nxhip_ctx *ctx, void *out, uint32_t capacityRuns, uint32_t *count);
 /* Test hook for the thin kernel (nx_trace.hip): the hand-over rule — at most `lanes` busy lanes of a dry wave for at least `iters`
- * iterations (product: 4 / 64; 64 / 0 makes every wave hand over the first rays it takes, after one iteration) — and whether the ray-batch
+ * iterations (product: 16 / 16; 64 / 0 makes every wave hand over the first rays it takes, after one iteration) — and whether the ray-batch
  * hooks (nxhip_trace_batch, nxhip_trace_shadow_batch) use the hand-over + thin launch too, so that a test can put arbitrary rays
- * through the cooperative search and compare the records with the oracle's.  nxhip_debug_thin_counts: the rays the last hook call
+ * through the cooperative search and compare the records with the oracle's (inHooks bit 0).  inHooks bit 1: hand over after `iters`
+ * iterations of EVERY stretch between two refill points, dry queue or not — the rays then reach the thin kernel with the traversal
+ * state of exactly that many steps (round 6: the hand-over carries the state).  nxhip_debug_thin_counts: the rays the last hook call
  * handed over (closest-hit, any-hit). */
 int nxhip_debug_set_thin(nxhip_ctx *ctx, uint32_t lanes, uint32_t iters, int inHooks);
 /* ... and how many items a thin wave's pool may hold (0 = the product's 960 of 1 024): a round whose children do not fit puts items back and

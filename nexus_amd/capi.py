@@ -693,10 +693,11 @@ class Context:
         self.L.nxhip_sync_timeout.argtypes = [C.c_void_p, C.c_uint32]
         check(self.L.nxhip_sync_timeout(self.h, int(timeout_ms)), "nxhip_sync_timeout")
 
-    def debug_set_thin(self, lanes=4, iters=64, in_hooks=False):
-        """the thin kernel's hand-over rule, and whether the ray-batch hooks use it too (a test hook: include/nexus_hip.h)"""
+    def debug_set_thin(self, lanes=16, iters=16, in_hooks=False, any_time=False):
+        """the thin kernel's hand-over rule, and whether the ray-batch hooks use it too (a test hook: include/nexus_hip.h);
+        any_time: hand over after `iters` iterations of every stretch between two refill points, dry queue or not"""
         self.L.nxhip_debug_set_thin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
-        check(self.L.nxhip_debug_set_thin(self.h, lanes, iters, 1 if in_hooks else 0), "nxhip_debug_set_thin")
+        check(self.L.nxhip_debug_set_thin(self.h, lanes, iters, (1 if in_hooks else 0) | (2 if any_time else 0)), "nxhip_debug_set_thin")
 
     def debug_set_thin_pool(self, slots=0):
         """how many items a thin wave's pool may hold before a round puts items back (0: the product's limit; a test hook)"""

@@ -351,7 +351,7 @@ struct DeviceState {
     NX_G uint32_t* thinClosest;
     NX_G uint32_t* thinAny;
     uint32_t thinCapacity;           // entries per list
-    uint32_t thinLanes, thinIters;   // hand-over rule: at most thinLanes busy lanes for at least thinIters iterations (4 / 64; a test hook sets 64 / 0: every ray of a dry wave)
+    uint32_t thinLanes, thinIters;   // hand-over rule: at most thinLanes busy lanes for at least thinIters iterations (16 / 16; a test hook sets 64 / 0: every ray of a dry wave)
     uint32_t thinPoolLimit;          // items a thin wave's pool may hold before a round puts items back (0: all of it; a test hook lowers it: nxhip_debug_set_thin_pool)
     uint32_t entryRuns;              // states in `entry`
     uint32_t debugRequeue;           // test hook (nxhip_debug_set_requeue): the trace kernels hand the same rays out again and again — a ray that re-queues itself (see kErrRaysRetaken)

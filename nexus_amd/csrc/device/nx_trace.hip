@@ -58,11 +58,17 @@ constexpr int kRefillBelow = NX_REFILL_BELOW;  // refill idle lanes when fewer t
 // repetition of the driver's command 18.4 ms instead of 19.1 ... 21.3).  Splitting a ray INSIDE the loop was tried in round 3 and
 // cost the loop 11 % by its live values; the search below as a part of this kernel cost it 15 % out of line and 160 % inlined
 // (round 5: its registers around the refill point, not its execution).  So the trace kernels only HAND OVER: when the queue is
-// dry, at most 4 lanes of a wave are still busy and they have been for 64 iterations or four average rays, the wave appends those rays
-// to a list and ends.  thin_kernel — one launch per level, behind the closest-hit and any-hit launches — puts a whole wave on each
-// listed ray: all 64 lanes search the ray's tree TOGETHER, in any order: a pool of work items (node, instance entry, triangle) in
-// LDS; every round each lane takes one item, tests it against the ray with the loop's own functions and puts the children the ray
-// enters back; the smallest triangle distance found so far prunes, as the ray's own hit distance would.
+// dry, at most 16 lanes of a wave are still busy and they have been for 16 iterations and four average rays, the wave appends those
+// rays — WITH their traversal state (round 6: ThinState: stack, current groups, hit so far, instance) — to a list and ends.
+// thin_kernel — one launch per level, behind the closest-hit and any-hit launches — puts a whole wave on each listed ray: all 64
+// lanes search what is LEFT of the ray's tree together, in any order: a pool of work items (node, instance entry, triangle) in LDS,
+// seeded with the groups of the ray's stack; every round each lane takes one item, tests it against the ray with the loop's own
+// functions and puts the children the ray enters back; the smallest triangle distance found so far — from the start: the hit the
+// ray arrived with — prunes, as the ray's own hit distance would.  (Rounds 5: the search started again at the TLAS root with no
+// bound.  Measured, round 6: carrying the state is worth 0 ... +0.3 % on the driver's command at the same rule — the thin launches
+// are a few per cent of a pass either way — and what an eager rule could win, +4.2 % if handed-over rays cost nothing
+// (profiles/r06_handover.txt, the `drop` rows), the search's cost per ray takes back: rays a wave still holds when its queue is dry
+// are many and short, the search pays for the long ones only.)
 //   * Any-hit ray: occluded is occluded whatever the order.
 //   * Closest-hit ray: the reference's result (BVH8Traversal.cuh:148-322) is what ITS visiting order finds, and that depends on
 //     the order in exactly one situation: two triangles whose distances differ by less than the rounding of the slab test (the

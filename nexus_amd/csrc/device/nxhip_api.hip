@@ -497,8 +497,10 @@ int nxhip_create(int device, uint32_t width, uint32_t height, void* stream, nxhi
         h.settings.backgroundIntensity = 0.0f;
         h.camera.resolution[0] = width;
         h.camera.resolution[1] = height;
-        h.thinLanes = 4u;
-        h.thinIters = 64u;
+        // (round 6: 16 / 16 — at most 16 busy lanes for 16 iterations, and still "four average rays" long: nx_trace.hip kThinFactor.  With the
+        //  traversal state carried over: driver command +0.8 % over 4 / 64, a rank of 8's share 3.80 -> 3.70 ms; profiles/r06_handover.txt)
+        h.thinLanes = 16u;
+        h.thinIters = 16u;
         h.rngMode = NX_RNG_REFERENCE_SLOT;
         h.compactMode = NX_COMPACT_FAST;
         h.conductorMode = NX_CONDUCTOR_REFERENCE;

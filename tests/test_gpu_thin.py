@@ -41,9 +41,42 @@ def test_closest_hit_through_the_thin_kernel_is_bit_exact(gpu_ctx_factory, make_
     ctx = _thin_ctx(gpu_ctx_factory, scene)
     got = _check_closest(ctx, scene, _rays_for(scene, 40000, seed=17))
     assert (got["hitDistance"] < 1e29).mean() > 0.05
-    # ... and with the product's rule (4 lanes, 64 iterations) the same records again
-    ctx.debug_set_thin(lanes=4, iters=64, in_hooks=True)
+    # ... and with the product's rule (16 lanes, 16 iterations) the same records again
+    ctx.debug_set_thin(lanes=16, iters=16, in_hooks=True)
     assert SH.hit_records_equal(ctx.trace_batch(_rays_for(scene, 40000, seed=17)), got)
+
+
+@pytest.mark.parametrize("make_scene", [SH.soup_scene, SH.instanced_scene, mixed_identity_scene])
+def test_rays_handed_over_in_the_middle_of_their_traversal_are_continued_bit_exactly(gpu_ctx_factory, make_scene):
+    """Round 6: a handed-over ray brings its traversal state (stack, current groups, the hit found so far, the instance it is inside)
+    and the search CONTINUES it.  The hook hands every ray over after exactly k loop iterations, k = 1 ... 40: rays at the root, rays
+    in the TLAS, rays inside rotated instances with a hit in hand, rays one step from their end — closest hit and any hit — all must
+    end with the oracle's records."""
+    scene = make_scene()
+    ctx = gpu_ctx_factory(256, 256)
+    scene.upload(ctx)
+    rays = _rays_for(scene, 30000, seed=31)
+    orc = scene.oracle()
+    want = orc.trace_closest(rays)
+    rng = np.random.RandomState(3)
+    tmax = np.where(want["hitDistance"] < 1e29, want["hitDistance"] * rng.choice([0.999, 1.001], len(rays)), 10.0).astype(np.float32)
+    want_any = orc.trace_any(rays, tmax)
+    for k in (1, 2, 3, 5, 8, 13, 25, 40):
+        ctx.debug_set_thin(lanes=64, iters=k, in_hooks=True, any_time=True)
+        got = ctx.trace_batch(rays)
+        handed = ctx.debug_thin_counts()[0]
+        assert SH.hit_records_equal(got, want), "closest hit, handed over after %d iterations" % k
+        got_any = ctx.trace_shadow_batch(rays, tmax)
+        handed_any = ctx.debug_thin_counts()[1]
+        assert np.array_equal(got_any, want_any), "any hit, handed over after %d iterations" % k
+        print("after %2d iterations: %5d closest-hit and %5d any-hit rays continued by the thin kernel" % (k, handed, handed_any))
+        assert handed > (2000 if k <= 8 else 10) or make_scene is not SH.soup_scene
+    # ... and a pool kept small: seeds and their children are put back and taken again
+    ctx.debug_set_thin_pool(96)
+    ctx.debug_set_thin(lanes=64, iters=6, in_hooks=True, any_time=True)
+    assert SH.hit_records_equal(ctx.trace_batch(rays), want)
+    assert np.array_equal(ctx.trace_shadow_batch(rays, tmax), want_any)
+    ctx.debug_set_thin_pool(0)
 
 
 @pytest.mark.parametrize("make_scene", [SH.soup_scene, SH.instanced_scene])
