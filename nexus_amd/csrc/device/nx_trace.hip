@@ -938,13 +938,19 @@ __global__ void __launch_bounds__(kTraceBlock) trace_kernel(const DeviceState* _
             if (!STATS && kThinCode && thinAllowed && ((exhausted && rngCur >= rngEnd) || thinIters == 0u || thinAnyTime) && activeMask != 0ull && __popcll(activeMask) <= thinLanes && spins >= thinAfter) {
                 // the wave is dry and down to its last few long rays: they go to the thin kernel (below), which puts all 64 lanes of
                 // a wave on each of them; this wave is done
+#if defined(NX_THIN_DROP) && defined(NX_THIN_DROP_KIND)
+                if (ANY_HIT != (NX_THIN_DROP_KIND == 1)) { thinAllowed = false; }  // (bound per ray kind: the other kind's waves finish their rays themselves)
+                else
+#endif
 #ifdef NX_THIN_DROP
                 // BOUND EXPERIMENT (wrong results): the rays a hand-over rule would give away simply end here — closest hit with what they
                 // have found so far, any hit as occluded — so that the launch's time is what ANY hand-over, however fast, could reach
                 // at most (tools/ab_prebuilt.sh drop+NX_THIN_LANES=..+NX_THIN_ITERS=..)
-                if (active) { active = false; resultPending = !ANY_HIT; }
-                activeMask = 0ull;
-                thinAllowed = false;
+                {
+                    if (active) { active = false; resultPending = !ANY_HIT; }
+                    activeMask = 0ull;
+                    thinAllowed = false;
+                }
 #else
                 NX_G int* const count = &C->thinCount[ANY_HIT ? 1 : 0][bounce];
                 int base = 0;
@@ -1028,6 +1034,9 @@ template __global__ void trace_kernel<true, true>(const DeviceState*, int);
 
 // The listed rays of one level (closest-hit first, then any-hit; kThinClosestOnly / kThinAnyOnly: one list), one wave per ray,
 // grid-stride.  `bounceArg` as the trace launches got it: the ray set and the meaning of the closest-hit record follow kTraceScanFlag.
+#ifdef NX_THIN_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(NX_THIN_WAVES_PER_EU, NX_THIN_WAVES_PER_EU)))  // (measurement knob: DESIGN.md section 7)
+#endif
 __global__ void __launch_bounds__(kTraceBlock) thin_kernel(const DeviceState* __restrict__ S, const int bounceArg)
 {
     __shared__ unsigned long long sPool[(kTraceBlock / kWave) * kPoolSlots];

@@ -7,7 +7,10 @@
 
 namespace nxd {
 
-constexpr int kTraceBlock = 256;  // 4 waves
+#ifndef NX_TRACE_BLOCK
+#define NX_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = NX_TRACE_BLOCK;  // 4 waves (NX_TRACE_BLOCK: measurement knob, 64 / 128: DESIGN.md section 7)
 #ifndef NX_LDS_DEPTH
 #define NX_LDS_DEPTH 8
 #endif

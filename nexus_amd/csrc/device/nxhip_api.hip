@@ -74,7 +74,10 @@ bool DevBuf::alloc(size_t n)
     return true;
 }
 
-constexpr int kTraceBlockThreads = 256;
+#ifndef NX_TRACE_BLOCK
+#define NX_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlockThreads = NX_TRACE_BLOCK;
 constexpr int kWideBlockThreads = 256;
 #ifndef NX_SHADE_BLOCK
 #define NX_SHADE_BLOCK 256
@@ -1857,7 +1860,9 @@ std::vector<std::vector<Launch>> frame_levels(nxhip_ctx* c, PassSlot* q)
     // behind the trace launch(es) of a level: the rays their dry waves handed over, a wave each (thin_kernel)
     // — each trace launch of the level gets its own, chained to it alone, so that the closest-hit rays' searches run beside whatever
     // the any-hit launch still has to do (it is the longer one of the early levels) and the other way round in the late ones
-    const int thinBlocks = 3 * c->numCUs;  // (48 KiB of LDS: three workgroups per CU)
+    int thinBlocks = 3 * c->numCUs;  // (48 KiB of LDS: three workgroups per CU)
+    if (const char* on = std::getenv("NX_TUNING_KNOBS"); on && std::atoi(on) == 1)
+        if (const char* e = std::getenv("NX_THIN_BLOCKS_PER_CU")) { const int n = std::atoi(e); if (n >= 1 && n <= 16) thinBlocks = n * c->numCUs; }  // sweeps only
     auto thin_level = [&](int bounceArg) {
         if (!thinFlag) return;
         if (c->thinJoint) {  // (NX_THIN_JOINT, measurement only: one launch for both lists behind the whole level)
