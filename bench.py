@@ -640,7 +640,8 @@ def main():
             "mean_rep_ms": round(statistics.mean(rep_s) * 1e3, 3), "value_from_the_mean": round(W * H * n_frames / statistics.mean(rep_s) / 1e6, 3),
             "pass_sizes": schedule(n_frames), "frames_rendered_by_the_timed_loop": frames_rendered[0],
             "host_scene_build_s": round(t_build, 2), "tlas_builder": "device (nxhip_rebuild_tlas)" if (args.device_bvh and not args.host_tlas) else "host: agglomerative clustering + SAH-DP collapse (the reference's algorithm)",
-            "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
+            "build": (lambda f: {"gfx950": bool(f & 1), "scheduler_flags": bool(f & 2), "debug_hooks": bool(f & 4)})(int(capi.lib().nxhip_build_info())),
+            "blas_builder": "device: top-down binned SAH (16 bins) + SAH-DP collapse, a primitive priced at 0.75 of a node (nxhip_build_blas)" if args.device_bvh else "host: binned SAH (8 bins) + SAH-DP collapse (the reference's algorithm, --host-bvh)",
         },
     }
 
