@@ -149,9 +149,21 @@ def simulate(seqs, policy, cost, refill_below=40, thresh=16, bias=1.0, rays_per_
             elif policy == "postpone":
                 run_node = nN > 0
                 run_tri = nT > 0 and (nT >= thresh or nN == 0)
+            elif policy == "postpone_inst":
+                # round 6: instance entries wait until `thresh` lanes want one, or nothing else is left to do (node / triangle lanes go on)
+                run_node, run_tri = nN > 0, nT > 0
+                run_inst = nI > 0 and (nI >= thresh or (nN - nI == 0 and nT == 0))
             instr = cost["over"]
             lanes = cost["over"] * n_active
-            if run_node:
+            if policy == "postpone_inst":
+                nNode = nN - (0 if run_inst else nI)  # lanes in the node block: pure nodes, and the BLAS root test of the entries that run
+                if nNode > 0:
+                    instr += cost["node"]
+                    lanes += cost["node"] * nNode
+                if run_inst:
+                    instr += cost["inst"]
+                    lanes += cost["inst"] * nI
+            elif run_node:
                 instr += cost["node"]
                 lanes += cost["node"] * nN
                 if nI:
@@ -165,7 +177,11 @@ def simulate(seqs, policy, cost, refill_below=40, thresh=16, bias=1.0, rays_per_
             iters += 1
             for l in range(64):
                 k = kinds[l]
-                if (run_node and (k == 1 or k == 3)) or (run_tri and k == 2):
+                if policy == "postpone_inst":
+                    go = (k == 1) or (k == 2) or (k == 3 and run_inst)
+                else:
+                    go = (run_node and (k == 1 or k == 3)) or (run_tri and k == 2)
+                if go:
                     pos[l] += 1
                     if pos[l] >= len(seq[l]):
                         active[l] = False
@@ -180,9 +196,10 @@ def main():
     ap.add_argument("--inst", type=float, default=45.0)
     ap.add_argument("--over", type=float, default=48.0)
     ap.add_argument("--refill", type=float, default=90.0)
+    ap.add_argument("--scene", type=int, default=2, help="2 = configs[1], 4 = configs[3] (transformed instances: --inst 150)")
     args = ap.parse_args()
     cost = {"node": args.node, "tri": args.tri, "inst": args.inst, "over": args.over, "refill": args.refill}
-    scene = CS.config2(1920, 1080)
+    scene = CS.config4(1920, 1080) if args.scene == 4 else CS.config2(1920, 1080)
     orc = scene.oracle()
     prim = camera_rays(scene.camera, args.tiles, seed=1)
     pseq, phits = log_sequences(orc, prim)
@@ -196,6 +213,8 @@ def main():
             rows.append(("vote, bias %.1f" % b, dict(policy="vote", bias=b)))
         for t in (4, 8, 16, 24, 32):
             rows.append(("postpone triangles below %d lanes" % t, dict(policy="postpone", thresh=t)))
+        for t in (2, 4, 6, 8, 12, 16):
+            rows.append(("postpone instance entries below %d lanes" % t, dict(policy="postpone_inst", thresh=t)))
         base = None
         for label, kw in rows:
             ipr, lanes, it = simulate(seqs, cost=cost, **kw)
