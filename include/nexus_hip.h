@@ -210,6 +210,8 @@ int nxhip_debug_set_thin(nxhip_ctx *ctx, uint32_t lanes, uint32_t iters, int inH
  * goes on with fewer per round — a test lowers the limit so that ordinary scenes drive that path; results must not change. */
 int nxhip_debug_set_thin_pool(nxhip_ctx *ctx, uint32_t slots);
 int nxhip_debug_thin_counts(nxhip_ctx *ctx, int32_t counts[2]);
+/* ... and of level `bounce` (0 = the primary rays) of the pass rendered last: what its trace launches handed over (closest-hit, any-hit). */
+int nxhip_debug_thin_counts_of_pass(nxhip_ctx *ctx, uint32_t bounce, int32_t counts[2]);
 
 /* ---- rendering ----------------------------------------------------------------------------------- */
 

@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nxhip_read_rgba8", "nxhip_write_accumulation", "nxhip_bind_radiance", "nxhip_read_full_accumulation", "nxhip_read_full_rgba8", "nxhip_radiance_device_ptr", "nxhip_accumulation_device_ptr", "nxhip_accumulate_external", "nxhip_compose_tiles",
     "nxhip_read_queue_sizes", "nxhip_set_pixel_query", "nxhip_get_selected_instance", "nxhip_trace_batch",
     "nxhip_trace_shadow_batch", "nxhip_bsdf_sample_batch", "nxhip_bsdf_eval_batch", "nxhip_tex2d_batch", "nxhip_enable_trace_stats", "nxhip_read_trace_stats", "nxhip_enable_kernel_timing",
-    "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_build_info", "nxhip_set_pixel_order", "nxhip_sync_timeout", "nxhip_debug_set_requeue", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
+    "nxhip_read_kernel_times", "nxhip_read_graph_timeline", "nxhip_has_gfx950_code", "nxhip_build_info", "nxhip_set_pixel_order", "nxhip_sync_timeout", "nxhip_debug_set_requeue", "nxhip_debug_thin_counts_of_pass", "nxhip_debug_write_blas_node", "nxhip_rebuild_tlas", "nxhip_read_tlas_index", "nxhip_release_queues", "nxhip_set_device_builder",
     "nxhip_set_instance_transforms", "nxhip_read_tlas", "nxhip_set_passes_in_flight", "nxhip_set_tail_bounce", "nxhip_set_entry_points", "nxhip_read_entry_states", "nxhip_debug_set_thin", "nxhip_debug_set_thin_pool", "nxhip_debug_thin_counts", "nxhip_build_blas", "nxhip_read_blas", "nxhip_set_env_sampling",
     "nxhip_tile_pixel_map", "nxhip_mgpu_unique_id", "nxhip_mgpu_init", "nxhip_mgpu_attach", "nxhip_mgpu_gather", "nxhip_mgpu_read_rgba8",
     "nxhip_mgpu_read_accumulation", "nxhip_mgpu_shutdown", "nxhip_fmath_batch", "nxhip_abi_stamp", "nxhip_check_library", "nxhip_build_blas_batch", "nxhip_read_blas_batch", "nxhip_debug_set_scan_epoch",
@@ -682,6 +682,13 @@ class Context:
         """primary rays start from the state their run's first node steps provably share (include/nexus_hip.h)"""
         self.L.nxhip_set_entry_points.argtypes = [C.c_void_p, C.c_int]
         check(self.L.nxhip_set_entry_points(self.h, 1 if on else 0), "nxhip_set_entry_points")
+
+    def debug_thin_counts_of_pass(self, bounce):
+        """rays the trace launches of level `bounce` of the last pass handed to the thin kernel: (closest-hit, any-hit)"""
+        c = (C.c_int32 * 2)()
+        self.L.nxhip_debug_thin_counts_of_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        check(self.L.nxhip_debug_thin_counts_of_pass(self.h, bounce, c), "nxhip_debug_thin_counts_of_pass")
+        return int(c[0]), int(c[1])
 
     def debug_set_requeue(self, on=True):
         """test hook: the trace kernels hand the same rays out again and again (include/nexus_hip.h)"""

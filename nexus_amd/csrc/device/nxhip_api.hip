@@ -2324,6 +2324,19 @@ int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
     return NXHIP_OK;
 }
 
+int nxhip_debug_thin_counts_of_pass(nxhip_ctx* c, uint32_t bounce, int32_t counts[2])
+{
+    NX_CHECK_CTX(c);
+    NX_DEBUG_HOOK("nxhip_debug_thin_counts_of_pass");
+    if (!counts || bounce >= (uint32_t)kMaxBounceSlots) return fail_invalid("nxhip_debug_thin_counts_of_pass: null destination or bounce out of range");
+    NX_HIP(hipSetDevice(c->device));
+    NX_SYNC_ALL(c);
+    const PassSlot* q = c->lastRendered ? c->lastRendered : static_cast<const PassSlot*>(c);
+    for (int k = 0; k < 2; k++)
+        NX_HIP(hipMemcpy(&counts[k], &q->counters.as<Counters>()->thinCount[k][bounce], 4, hipMemcpyDeviceToHost));
+    return NXHIP_OK;
+}
+
 int nxhip_read_entry_states(nxhip_ctx* c, void* out, uint32_t capacityRuns, uint32_t* count)
 {
     NX_CHECK_CTX(c);

@@ -184,3 +184,43 @@ def test_axis_aligned_rays_through_the_thin_kernel(gpu_ctx_factory):
     rays["direction"] = dirs[rng.randint(0, len(dirs), len(rays))]
     rays["origin"] = rng.uniform(-1.2, 1.2, (len(rays), 3)).astype(np.float32) - 3.0 * rays["direction"]
     _check_closest(ctx, scene, rays, min_handed=0.005)  # (most of these rays miss the scene's root box and end at once)
+
+
+def test_whole_frames_with_every_ray_handed_over_mid_traversal(gpu_ctx_factory):
+    """The pass graph's own launches (not the ray-batch hooks): with the any-time hook every ray of every level — primary rays that
+    started from an ENTRY STATE, continuation rays, shadow rays — is handed over after k iterations and continued by the thin kernel
+    of its level, as long as the level's lists have room.  Frames, accumulation and queue sizes must equal the run without any
+    hand-over, in the SCAN pipeline (fast compaction) and in the classic one (ordered compaction, reference random numbers)."""
+    from nexus_amd import multigpu, workloads
+
+    W, H = 256, 144
+    scene = workloads.config2(W, H, 160, 80, 5, cls=SH.BuiltScene)
+    for modes, entry in (((pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED), True),
+                         ((pod.RNG_PIXEL_KEYED, pod.COMPACT_FAST, pod.CONDUCTOR_EXTENDED), False),
+                         ((pod.RNG_REFERENCE_SLOT, pod.COMPACT_ORDERED, pod.CONDUCTOR_REFERENCE), False)):
+        ctx = gpu_ctx_factory(W, H)
+        scene.upload(ctx)
+        ctx.set_modes(*modes)
+        ctx.set_pixel_order(pod.ORDER_TILES)
+        ctx.set_entry_points(entry)
+        ctx.set_tail_bounce(0)
+        ctx.set_frames_per_pass(2)
+
+        def run():
+            ctx.reset_frame_number()
+            for _ in range(2):
+                ctx.render_frame()
+                ctx.accumulate()
+            return ctx.read_radiance().view(np.uint32).copy(), ctx.read_accumulation().view(np.uint32).copy(), ctx.read_queue_sizes()
+
+        ctx.debug_set_thin(lanes=64, iters=1 << 20, in_hooks=False)  # (no wave ever qualifies: no hand-over at all)
+        want = run()
+        for k in (1, 4, 11):
+            ctx.debug_set_thin(lanes=64, iters=k, in_hooks=False, any_time=True)
+            got = run()
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (modes, entry, k)
+            assert SH.queue_sizes_identical(got[2], want[2]), (modes, entry, k)
+            handed = [ctx.debug_thin_counts_of_pass(b) for b in range(0, 4)]
+            print("%s entry %s k %d: handed over per level (closest, any) %s" % (modes, entry, k, handed))
+            assert handed[0][0] > 10000 and handed[1][0] > 1000 and handed[1][1] > 100, "the levels' rays did go through the thin kernel (up to the lists' 32 768 entries each)"
+        ctx.sync()
