@@ -1108,8 +1108,8 @@ int nxhip_read_blas(nxhip_ctx* c, int32_t blasId, nx_bvh8_node* nodes, uint32_t 
 
 int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, const nx_bvh8_node* node)
 {
+    NX_DEBUG_HOOK("nxhip_debug_write_blas_node");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_write_blas_node");
     if (!node || blasId < 0 || (size_t)blasId >= c->blas.size()) return fail_invalid("nxhip_debug_write_blas_node: no such BLAS");
     BlasHost& b = c->blas[(size_t)blasId];
     if (nodeIdx >= b.nodeCount) return fail_invalid("nxhip_debug_write_blas_node: no such node");
@@ -1129,8 +1129,8 @@ int nxhip_debug_write_blas_node(nxhip_ctx* c, int32_t blasId, uint32_t nodeIdx, 
 
 int nxhip_debug_set_scan_epoch(nxhip_ctx* c, uint32_t epoch)
 {
+    NX_DEBUG_HOOK("nxhip_debug_set_scan_epoch");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_set_scan_epoch");
     NX_SYNC_ALL(c);
     for (uint32_t k = 0; k < slot_count(c); k++) slot_at(c, k)->scanEpoch = std::min(epoch, kScanEpochLimit - 1u);
     return NXHIP_OK;
@@ -2281,8 +2281,8 @@ int nxhip_set_entry_points(nxhip_ctx* c, int on)
 
 int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHooks)
 {
+    NX_DEBUG_HOOK("nxhip_debug_set_thin");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_set_thin");
     if (lanes == 0 || lanes > 64u) return fail_invalid("nxhip_debug_set_thin: lanes must be in [1, 64]");
     NX_SYNC_ALL(c);
     c->h.thinLanes = lanes | ((inHooks & 2) ? 0x80000000u : 0u);  // (bit 31: hand over at any time, see nx_trace.hip)
@@ -2294,8 +2294,8 @@ int nxhip_debug_set_thin(nxhip_ctx* c, uint32_t lanes, uint32_t iters, int inHoo
 
 int nxhip_debug_set_requeue(nxhip_ctx* c, int on)
 {
+    NX_DEBUG_HOOK("nxhip_debug_set_requeue");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_set_requeue");
     NX_SYNC_ALL(c);
     c->h.debugRequeue = on ? 1u : 0u;
     c->stateDirty = true;
@@ -2304,8 +2304,8 @@ int nxhip_debug_set_requeue(nxhip_ctx* c, int on)
 
 int nxhip_debug_set_thin_pool(nxhip_ctx* c, uint32_t slots)
 {
+    NX_DEBUG_HOOK("nxhip_debug_set_thin_pool");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_set_thin_pool");
     NX_SYNC_ALL(c);
     c->h.thinPoolLimit = slots;
     c->stateDirty = true;
@@ -2314,8 +2314,8 @@ int nxhip_debug_set_thin_pool(nxhip_ctx* c, uint32_t slots)
 
 int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
 {
+    NX_DEBUG_HOOK("nxhip_debug_thin_counts");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_thin_counts");
     if (!counts) return fail_invalid("nxhip_debug_thin_counts: null destination");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
@@ -2326,8 +2326,8 @@ int nxhip_debug_thin_counts(nxhip_ctx* c, int32_t counts[2])
 
 int nxhip_debug_thin_counts_of_pass(nxhip_ctx* c, uint32_t bounce, int32_t counts[2])
 {
+    NX_DEBUG_HOOK("nxhip_debug_thin_counts_of_pass");  // (first: a release library refuses whatever it is handed)
     NX_CHECK_CTX(c);
-    NX_DEBUG_HOOK("nxhip_debug_thin_counts_of_pass");
     if (!counts || bounce >= (uint32_t)kMaxBounceSlots) return fail_invalid("nxhip_debug_thin_counts_of_pass: null destination or bounce out of range");
     NX_HIP(hipSetDevice(c->device));
     NX_SYNC_ALL(c);
