@@ -6,6 +6,7 @@
 // (Renderer/Panels/MetricsPanel.cpp:23-37: width x height per Render()ed frame over the accumulated wall time).
 //
 //   nexus_bench <dir/> <mesh.obj> [--mode reference|headline] [--frames K] [--warmup W] [--reps R] [--width X --height Y] [--path-length L]
+//               [--passes-in-flight P]
 //               [--rgba8 out.bin]
 //
 //   --mode reference : the reference's own semantics — slot-keyed random numbers, ONE frame per Render() call, rows, no entry points,
@@ -65,7 +66,7 @@ int main(int argc, char** argv)
     const std::string dir = argv[1], file = argv[2];
     std::string mode = "headline", rgbaOut;
     uint32_t width = 1920, height = 1080;
-    int frames = 20, warmup = 5, reps = 5, pathLength = 8;
+    int frames = 20, warmup = 5, reps = 5, pathLength = 8, inFlight = 1;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--mode") mode = v;
@@ -76,6 +77,7 @@ int main(int argc, char** argv)
         else if (k == "--height") height = static_cast<uint32_t>(std::atoi(v.c_str()));
         else if (k == "--path-length") pathLength = std::atoi(v.c_str());
         else if (k == "--rgba8") rgbaOut = v;
+        else if (k == "--passes-in-flight") inFlight = std::atoi(v.c_str());  // consecutive Render() calls overlap on the GPU (PathTracer::SetPassesInFlight)
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     const bool headline = mode == "headline";
@@ -132,6 +134,7 @@ int main(int argc, char** argv)
         } else {
             pathTracer.SetModes(NX_RNG_REFERENCE_SLOT, NX_COMPACT_FAST, NX_CONDUCTOR_REFERENCE);
         }
+        if (inFlight > 1) pathTracer.SetPassesInFlight(static_cast<uint32_t>(inFlight));
         pathTracer.UpdateDeviceScene(scene);
         const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
@@ -159,10 +162,10 @@ int main(int argc, char** argv)
             std::fclose(fp);
         }
         std::printf("{\"metric\": \"Msamples/sec through nexus::PathTracer::Render\", \"value\": %.1f, \"unit\": \"Msamples/s\", \"mode\": \"%s\", \"width\": %u, \"height\": %u, "
-                    "\"frames_timed\": %d, \"render_calls_per_region\": %d, \"warmup_frames\": %d, \"reps\": %d, \"median_region_ms\": %.3f, \"ms_per_frame\": %.4f, "
+                    "\"frames_timed\": %d, \"passes_in_flight\": %d, \"render_calls_per_region\": %d, \"warmup_frames\": %d, \"reps\": %d, \"median_region_ms\": %.3f, \"ms_per_frame\": %.4f, "
                     "\"instances\": %zu, \"lights\": %zu, \"frame_number\": %u, \"scene_build_s\": %.2f, \"rgba8_hash\": \"%016llx\", "
                     "\"definition\": \"width x height x frames / wall seconds of the Render() calls + device sync (MetricsPanel.cpp:23-37)\"}\n",
-                    msamples, mode.c_str(), width, height, frames, callsPerRegion, warmCalls * (headline ? frames : 1), reps, med, med / frames, scene.GetBVHInstances().size(),
+                    msamples, mode.c_str(), width, height, frames, inFlight, callsPerRegion, warmCalls * (headline ? frames : 1), reps, med, med / frames, scene.GetBVHInstances().size(),
                     scene.GetLights().size(), pathTracer.GetFrameNumber(), buildSeconds, sum);
         pathTracer.SetDeviceBlasBuild(scene, false);  // the scene outlives the path tracer in this scope
     } catch (const std::exception& e) {
